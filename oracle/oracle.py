@@ -1,0 +1,226 @@
+"""ctypes loader for the CPU oracle (oracle/mdbg_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never by the product package (rust_mdbg_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libmdbg_oracle.so")
+    src = os.path.join(_HERE, "mdbg_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libmdbg_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    L.orc_hash_bound.restype = C.c_uint64
+    L.orc_hash_bound.argtypes = [C.c_double]
+    for f in ("orc_ntf64", "orc_ntr64", "orc_ntc64"):
+        getattr(L, f).restype = C.c_int
+        getattr(L, f).argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, u64p]
+    L.orc_nthash_iter.restype = C.c_int64
+    L.orc_nthash_iter.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, u64p]
+    L.orc_encode_rle.restype = C.c_uint64
+    L.orc_encode_rle.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, u64p]
+    L.orc_revcomp.restype = None
+    L.orc_revcomp.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p]
+    L.orc_sketch.restype = C.c_void_p
+    L.orc_sketch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int]
+    L.orc_sketch_err.restype = C.c_int
+    L.orc_sketch_err.argtypes = [C.c_void_p]
+    L.orc_sketch_n.restype = C.c_uint64
+    L.orc_sketch_n.argtypes = [C.c_void_p]
+    for f in ("orc_sketch_hashes", "orc_sketch_pos", "orc_sketch_off"):
+        getattr(L, f).restype = u64p
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.orc_sketch_free.argtypes = [C.c_void_p]
+    L.orc_graph_new.restype = C.c_void_p
+    L.orc_graph_new.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_uint32, C.c_int, C.c_float]
+    L.orc_graph_ingest.restype = C.c_int
+    L.orc_graph_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.orc_graph_finalize.restype = C.c_int
+    L.orc_graph_finalize.argtypes = [C.c_void_p, C.c_int]
+    L.orc_graph_counter.restype = C.c_uint64
+    L.orc_graph_counter.argtypes = [C.c_void_p, C.c_int]
+    for f, t in (("keys", u64p), ("index", u32p), ("abundance", u16p), ("seqlen", u32p), ("shift", u16p),
+                 ("shift_full", u64p), ("src_read", u64p), ("src_start", u64p), ("src_end", u64p), ("reversed", u8p),
+                 ("edge_n1", u32p), ("edge_n2", u32p), ("edge_overlap", u32p), ("edge_o1", u8p), ("edge_o2", u8p),
+                 ("seqline_index", u32p), ("seqline_read", u64p), ("seqline_start", u64p), ("seqline_end", u64p),
+                 ("seqline_rev", u8p), ("seqline_shift", u64p)):
+        fn = getattr(L, "orc_graph_" + f)
+        fn.restype = t
+        fn.argtypes = [C.c_void_p]
+    L.orc_graph_free.argtypes = [C.c_void_p]
+    L.orc_count_threaded.restype = C.c_int64
+    L.orc_count_threaded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double,
+                                     C.c_uint32, C.c_int, C.c_int, u64p]
+    _LIB = L
+    return L
+
+
+def _arr(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def hash_bound(d):
+    return int(lib().orc_hash_bound(d))
+
+
+def ntf64(s, i, k):
+    o = C.c_uint64()
+    e = lib().orc_ntf64(s, i, k, C.byref(o))
+    if e:
+        raise ValueError("alphabet")
+    return o.value
+
+
+def ntr64(s, i, k):
+    o = C.c_uint64()
+    e = lib().orc_ntr64(s, i, k, C.byref(o))
+    if e:
+        raise ValueError("alphabet")
+    return o.value
+
+
+def ntc64(s, i, k):
+    o = C.c_uint64()
+    e = lib().orc_ntc64(s, i, k, C.byref(o))
+    if e:
+        raise ValueError("alphabet")
+    return o.value
+
+
+def nthash_iter(s, k):
+    n = len(s)
+    out = (C.c_uint64 * max(1, n))()
+    r = lib().orc_nthash_iter(s, n, k, out)
+    if r < 0:
+        raise ValueError("nthash error %d" % r)
+    return [int(out[i]) for i in range(r)]
+
+
+def encode_rle(s):
+    n = len(s)
+    hpc = C.create_string_buffer(n + 2)
+    pos = (C.c_uint64 * (n + 2))()
+    m = lib().orc_encode_rle(s, n, hpc, pos)
+    return hpc.raw[:m], [int(pos[i]) for i in range(m)]
+
+
+def revcomp(s):
+    out = C.create_string_buffer(len(s) + 1)
+    lib().orc_revcomp(s, len(s), out)
+    return out.raw[:len(s)]
+
+
+def concat_reads(reads):
+    """list[bytes] -> (uint8 array, uint64 offsets[n+1])"""
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    if reads:
+        offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, np.uint8)
+    return bases, offs
+
+
+def sketch(bases, offsets, l, density, already_hpc=False):
+    """-> dict(hashes u64[m], pos u64[m], off u64[n+1], err int)"""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    h = L.orc_sketch(bases.ctypes.data, offsets.ctypes.data, n, l, density, int(already_hpc))
+    try:
+        m = L.orc_sketch_n(h)
+        return dict(hashes=_arr(L.orc_sketch_hashes(h), m, np.uint64), pos=_arr(L.orc_sketch_pos(h), m, np.uint64),
+                    off=_arr(L.orc_sketch_off(h), n + 1, np.uint64), err=L.orc_sketch_err(h))
+    finally:
+        L.orc_sketch_free(h)
+
+
+class Graph:
+    """Sequential reference semantics (= rust-mdbg --threads 1, no --bf)."""
+
+    def __init__(self, k, l, density, minabund=2, already_hpc=False, presimp=0.01):
+        self.L = lib()
+        self.k = k
+        self.h = self.L.orc_graph_new(k, l, density, minabund, int(already_hpc), presimp)
+        self.n_ingested = 0
+
+    def ingest(self, bases, offsets, first_read_ordinal=None):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        if first_read_ordinal is None:
+            first_read_ordinal = self.n_ingested
+        e = self.L.orc_graph_ingest(self.h, bases.ctypes.data, offsets.ctypes.data, n, first_read_ordinal)
+        self.n_ingested += n
+        return e
+
+    def finalize(self, with_edges=True):
+        L, h, k = self.L, self.h, self.k
+        e = L.orc_graph_finalize(h, int(with_edges))
+        if e:
+            raise ValueError("oracle error %d at read %d" % (e, L.orc_graph_counter(h, 8)))
+        c = lambda i: int(L.orc_graph_counter(h, i))
+        n, ne, ns = c(4), c(5), c(7)
+        out = dict(
+            n_reads=c(0), n_minimizers=c(1), n_windows=c(2), n_nodes_before=c(3), n_nodes=n, n_edges=ne,
+            presimp_removed=c(6),
+            keys=_arr(L.orc_graph_keys(h), n * k, np.uint64).reshape(n, k),
+            index=_arr(L.orc_graph_index(h), n, np.uint32), abundance=_arr(L.orc_graph_abundance(h), n, np.uint16),
+            seqlen=_arr(L.orc_graph_seqlen(h), n, np.uint32), shift=_arr(L.orc_graph_shift(h), 2 * n, np.uint16).reshape(n, 2),
+            shift_full=_arr(L.orc_graph_shift_full(h), 2 * n, np.uint64).reshape(n, 2),
+            src_read=_arr(L.orc_graph_src_read(h), n, np.uint64), src_start=_arr(L.orc_graph_src_start(h), n, np.uint64),
+            src_end=_arr(L.orc_graph_src_end(h), n, np.uint64), reversed=_arr(L.orc_graph_reversed(h), n, np.uint8),
+            edge_n1=_arr(L.orc_graph_edge_n1(h), ne, np.uint32), edge_n2=_arr(L.orc_graph_edge_n2(h), ne, np.uint32),
+            edge_overlap=_arr(L.orc_graph_edge_overlap(h), ne, np.uint32),
+            edge_o1=_arr(L.orc_graph_edge_o1(h), ne, np.uint8), edge_o2=_arr(L.orc_graph_edge_o2(h), ne, np.uint8),
+            seqline_index=_arr(L.orc_graph_seqline_index(h), ns, np.uint32), seqline_read=_arr(L.orc_graph_seqline_read(h), ns, np.uint64),
+            seqline_start=_arr(L.orc_graph_seqline_start(h), ns, np.uint64), seqline_end=_arr(L.orc_graph_seqline_end(h), ns, np.uint64),
+            seqline_rev=_arr(L.orc_graph_seqline_rev(h), ns, np.uint8),
+            seqline_shift=_arr(L.orc_graph_seqline_shift(h), 2 * ns, np.uint64).reshape(ns, 2),
+        )
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.orc_graph_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def count_threaded(bases, offsets, k, l, density, minabund=2, already_hpc=False, threads=1):
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    w = C.c_uint64()
+    r = L.orc_count_threaded(bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, l, density, minabund,
+                             int(already_hpc), threads, C.byref(w))
+    if r < 0:
+        raise ValueError("oracle error %d" % r)
+    return int(r), int(w.value)

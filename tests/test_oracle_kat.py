@@ -1,0 +1,150 @@
+"""Pins the CPU oracle: nthash crate known-answer vectors, reference quirks, and an
+independent pure-Python restatement of ntHash's direct (non-rolling) definition."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+SEED = {ord("A"): 0x3C8BFBB395C60474, ord("C"): 0x3193C18562A02B4C, ord("G"): 0x20323ED082572324,
+        ord("T"): 0x295549F54BE24456, ord("N"): 0}
+COMP = {ord("A"): ord("T"), ord("C"): ord("G"), ord("G"): ord("C"), ord("T"): ord("A"), ord("N"): ord("N")}
+M = (1 << 64) - 1
+
+
+def rol(x, r):
+    r %= 64
+    return ((x << r) | (x >> (64 - r))) & M if r else x
+
+
+def py_canonical(s, i, k):
+    """direct definition: fh = XOR rol(h(s_j), k-1-j); rh = XOR rol(h(comp s_j), j)"""
+    fh = rh = 0
+    for j in range(k):
+        fh ^= rol(SEED[s[i + j]], k - 1 - j)
+        rh ^= rol(SEED[COMP[s[i + j]]], j)
+    return min(fh, rh)
+
+
+def test_nthash_crate_known_answers():
+    # nthash crate (0.5.x) README / unit tests
+    assert O.ntf64(b"TGCAG", 0, 5) == 0x0BAFA6728FC6DABF
+    assert O.ntr64(b"TGCAG", 0, 5) == 0x8CF2D4072CCA480E
+    assert O.ntc64(b"ACGTC", 0, 5) == 0x480202D54E8EBECD
+    assert O.ntf64(b"ACGTC", 0, 5) == 0xA7D01E3FB5593252
+    assert O.nthash_iter(b"ACTGC", 3) == [0x9B1EDA9A185413CE, 0x9F6ACFA2235B86FC, 0xD4A29BF149877C5C]
+
+
+@pytest.mark.parametrize("l", [1, 2, 10, 12, 14, 31, 33, 64, 70])
+def test_rolling_equals_direct(l):
+    rnd = random.Random(l)
+    s = bytes(rnd.choice(b"ACGTN" if l % 2 else b"ACGT") for _ in range(200))
+    it = O.nthash_iter(s, l)
+    assert len(it) == len(s) - l + 1
+    for i, h in enumerate(it):
+        assert h == py_canonical(s, i, l) == O.ntc64(s, i, l)
+
+
+def test_nthash_rejects_non_acgtn():
+    for bad in (b"ACGTacgt", b"ACGXACGT", b"ACG\nACGT"):
+        with pytest.raises(ValueError):
+            O.nthash_iter(bad, 3)
+    # a bad byte that no l-mer ever touches still panics in the reference iterator only when visited; all are visited
+    with pytest.raises(ValueError):
+        O.nthash_iter(b"ACGTACGTx", 3)
+
+
+def test_hash_bound():
+    assert O.hash_bound(0.0008) == 0x346DC5D638865A
+    assert O.hash_bound(0.003) == 55340232221128656 == 0xC49BA5E353F7D0
+    assert O.hash_bound(0.002) == 0x83126E978D4FE0
+    assert O.hash_bound(1.0) == M          # saturating cast
+    assert O.hash_bound(2.0) == M
+    assert O.hash_bound(0.0) == 0
+    assert O.hash_bound(-1.0) == 0
+    assert O.hash_bound(0.5) == 1 << 63
+    assert O.hash_bound(0.10) == int(0.10 * 2.0 ** 64)
+
+
+def test_encode_rle():
+    assert O.encode_rle(b"AACCCGTTN") == (b"ACGTN", [0, 2, 5, 6, 8])
+    assert O.encode_rle(b"") == (b"#", [0])
+    assert O.encode_rle(b"A") == (b"A", [0])
+    assert O.encode_rle(b"AAAA") == (b"A", [0])
+    assert O.encode_rle(b"NNNAnn") == (b"NAn", [0, 3, 4])
+    # only ACTGactgNn collapse: other bytes are kept one by one (read.rs:163)
+    assert O.encode_rle(b"XXAAXX") == (b"XXAXX", [0, 1, 2, 4, 5])
+
+
+def test_revcomp():
+    assert O.revcomp(b"ACGTNacgtuUx") == b"NAaacgtNACGT"
+
+
+def _sk(reads, l, d, hpc=False):
+    b, o = O.concat_reads(reads)
+    return O.sketch(b, o, l, d, hpc)
+
+
+def test_sketch_quirks():
+    rnd = random.Random(7)
+    s = bytes(rnd.choice(b"ACGT") for _ in range(5000))
+    l, d = 12, 0.05
+    sk = _sk([s], l, d)
+    hpc, pos = O.encode_rle(s)
+    bound = O.hash_bound(d)
+    exp = [(pos[i], py_canonical(hpc, i, l)) for i in range(len(hpc) - l + 1) if py_canonical(hpc, i, l) <= bound]
+    assert list(zip(sk["pos"].tolist(), sk["hashes"].tolist())) == exp and len(exp) > 50
+    # positions are raw run starts, strictly ascending
+    assert np.all(np.diff(sk["pos"].astype(np.int64)) > 0)
+    # --skiphpc: positions are plain indices into the given string
+    sk2 = _sk([hpc], l, d, hpc=True)
+    assert sk2["hashes"].tolist() == sk["hashes"].tolist()
+    assert sk2["pos"].tolist() == [i for i in range(len(hpc) - l + 1) if py_canonical(hpc, i, l) <= bound]
+    # inclusive bound: density chosen so that bound == one of the hashes keeps it
+    h0 = int(sk["hashes"].min())
+    dd = (h0 + 0.0) / 2.0 ** 64
+    if O.hash_bound(dd) == h0:
+        assert h0 in _sk([s], l, dd)["hashes"].tolist()
+    # reads with HPC length < l give nothing, even with bad bytes (read.rs:193 precedes hashing)
+    assert _sk([b"ACGTACGTAAAAAAAA"], 12, 1.0)["off"].tolist() == [0, 0]
+    assert _sk([b"xxxx"], 12, 1.0)["err"] == 0
+    assert _sk([b"ACGTACGTACGTx"], 12, 1.0)["err"] != 0
+    # N hashes as 0 and is not skipped
+    n = _sk([b"ACGTNACGTACGTAC"], 5, 1.0)
+    assert n["err"] == 0 and len(n["hashes"]) == 11
+
+
+def test_window_strictness_and_palindrome():
+    # build a read whose sketch has exactly k minimizers -> no window (strict '>'), k+1 -> 2 windows
+    rnd = random.Random(3)
+    s = bytes(rnd.choice(b"ACGT") for _ in range(3000))
+    l, d = 8, 0.02
+    m = len(_sk([s], l, d)["hashes"])
+    assert m > 6
+    for k, exp in ((m, 0), (m - 1, 2), (m + 1, 0)):
+        g = O.Graph(k, l, d, 1)
+        b, o = O.concat_reads([s])
+        g.ingest(b, o)
+        assert g.finalize()["n_windows"] == exp
+
+
+def test_abundance_semantics():
+    rnd = random.Random(5)
+    s = bytes(rnd.choice(b"ACGT") for _ in range(4000))
+    l, d, k = 8, 0.02, 3
+    reads = [s, s, O.revcomp(s), s[:2000]]
+    b, o = O.concat_reads(reads)
+    g1 = O.Graph(k, l, d, 1); g1.ingest(b, o); r1 = g1.finalize()
+    g3 = O.Graph(k, l, d, 3); g3.ingest(b, o); r3 = g3.finalize()
+    assert r1["n_nodes"] == r1["n_nodes_before"] and r3["n_nodes"] <= r1["n_nodes"]
+    assert r3["abundance"].min() >= 3
+    # index = first-sighting order over ALL keys; minabund=1 keeps them all -> 0..n-1
+    assert r1["index"].tolist() == list(range(r1["n_nodes"]))
+    # minabund=1 metadata comes from the first sighting (read 0); minabund=3 from the third (read 2, the revcomp copy)
+    assert set(r1["src_read"].tolist()) == {0}
+    assert set(r3["src_read"].tolist()) <= {2, 3}
+    full = r3["src_read"] == 2
+    assert full.any()
+    # seqlen = pos_last - pos_first + 2 ; src_end - src_start = pos_last + l - pos_first
+    assert np.all(r3["seqlen"] == (r3["src_end"] - r3["src_start"] - l + 2).astype(np.uint32))
