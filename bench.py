@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — Gbases/s ingested to the k-min-mer graph on synthetic HiFi-shaped reads (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch already resident in HBM:
+    reset -> sketch (HPC + ntHash + density filter) -> k-min-mer windows -> counting table -> finalized node table.
+Workload at N=1: BASELINE.json configs[2] (synthetic D. melanogaster: 140 Mb genome @50x, ~15 kb reads, 0.1 % errors,
+k=35 l=12 d=0.002 minabund=2).  For N>1 every rank holds a fixed-size shard of reads of a genome N times larger (weak
+scaling, coverage constant) and the k-min-mer occurrences are routed to their owning rank by key range with one RCCL
+all-to-all per step (rust_mdbg_amd/dist.py).
+
+Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_tile_kernel) and is measured live with
+HIP events on the stream the kernel is launched on; `cpu_baseline` is the CPU oracle (a port of the reference's path)
+timed on a bounded sample of the same reads on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=140.0, help="genome size per GPU in Mb")
+    ap.add_argument("--coverage", type=float, default=50.0)
+    ap.add_argument("-k", type=int, default=35)
+    ap.add_argument("-l", type=int, default=12)
+    ap.add_argument("--density", type=float, default=0.002)
+    ap.add_argument("--minabund", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def hip():
+    return C.CDLL("/opt/rocm/lib/libamdhip64.so")
+
+
+def d2h(ptr, nbytes):
+    import numpy as np
+    out = np.empty(nbytes, dtype=np.uint8)
+    e = hip().hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2)
+    assert e == 0, "hipMemcpy D2H failed: %d" % e
+    return out
+
+
+def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
+    """Times the CPU oracle on a bounded prefix of the same reads, one worker per host core."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    offs = d2h(d_off, (n_reads + 1) * 8).view(np.uint64)
+    # calibrate on ~40 Mbases
+    r0 = int(np.searchsorted(offs, 40_000_000, side="right"))
+    r0 = max(1, min(r0, n_reads))
+    b0 = d2h(d_bases, int(offs[r0]))
+    t = time.perf_counter()
+    O.count_threaded(b0, offs[:r0 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
+    dt = time.perf_counter() - t
+    rate = float(offs[r0]) / dt
+    target = min(float(n_bases), rate * args.cpu_seconds)
+    r1 = int(np.searchsorted(offs, target, side="right"))
+    r1 = max(r0, min(r1, n_reads))
+    b1 = d2h(d_bases, int(offs[r1]))
+    t = time.perf_counter()
+    solid, wins = O.count_threaded(b1, offs[:r1 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
+    dt = time.perf_counter() - t
+    return {"value": float(offs[r1]) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads (%.3f Gbases) of the same synthetic workload, %d threads, %.1f s; reads in RAM -> filtered node count"
+                      % (r1, float(offs[r1]) / 1e9, cores, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import rust_mdbg_amd as R
+
+    genome_len = int(args.genome_mb * 1e6) * world            # weak scaling: coverage constant, genome grows with N
+    reads_per_gpu = int(args.genome_mb * 1e6 * args.coverage / 15000.0)
+    m = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank)
+    d_bases, d_off, n_bases = m.synth_reads_device(seed=1, genome_len=genome_len, n_reads=reads_per_gpu, mean_len=15000, sd_len=1500,
+                                                   min_len=8000, max_len=25000, err_ppm=1000, first_read=rank * reads_per_gpu)
+    first_ordinal = rank * reads_per_gpu
+
+    if world > 1:
+        from rust_mdbg_amd import dist as D
+        runner = D.DistributedMdbg(m, dist, torch)
+
+    def step():
+        m.reset(0)
+        if world == 1:
+            m.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
+            return m.finalize_device().n
+        runner.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
+        return runner.finalize_device_count()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        m.sync()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    m.reset(0)
+    t0 = time.perf_counter()
+    n_nodes = 0
+    for _ in range(args.steps):
+        n_nodes = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        nb = torch.tensor([n_bases], device="cuda", dtype=torch.int64)
+        dist.all_reduce(nb)
+        total_bases = int(nb.item())
+    else:
+        total_bases = n_bases
+    st = m.stats()          # stats of the last step only (reset clears the timers)
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = total_bases * args.steps / dt / 1e9
+        mins_per_base = st["n_minimizers"] / max(1, st["n_bases"])
+        alg_bytes = st["n_sketch_tile_bases"] * (1.0 + 12.0 * mins_per_base)     # b_in (ASCII) + 12*m per raw base
+        roof = None
+        if st["n_sketch_tile_launches"]:
+            avg_ms = st["ms_sketch_tile"] / st["n_sketch_tile_launches"]
+            ach = alg_bytes / st["n_sketch_tile_launches"] / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "sketch_tile_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "launches_per_step": st["n_sketch_tile_launches"], "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_base": 1.0 + 12.0 * mins_per_base,
+                    "kernel_gbases_per_s": st["n_sketch_tile_bases"] / (st["ms_sketch_tile"] * 1e-3) / 1e9}
+        cpu = None
+        if args.cpu_seconds > 0:
+            cpu = cpu_baseline(m, d_bases, d_off, reads_per_gpu, n_bases, args)
+        out = {"metric": "Gbases/s ingested to k-min-mer graph", "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "synthetic D. melanogaster 140 Mb @50x per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1% errors",
+                          "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
+                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": "reads sharded by record x%d, key-range all-to-all" % world if world > 1 else "single GPU"},
+               "roofline": roof, "cpu_baseline": cpu,
+               "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_tile_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
+               "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
+                         "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"]}}
+        print(json.dumps(out))
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

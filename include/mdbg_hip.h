@@ -1,0 +1,162 @@
+/* mdbg_hip.h — C ABI of libmdbg_hip.so: MI355X-native minimizer sketching + k-min-mer counting.
+ *
+ * This is the drop-in boundary for rust-mdbg's per-read hot path.  The reference has NO plugin/FFI
+ * interface for it (the path is a set of closures inside fn main()), so the boundary is cut along the
+ * seams SURVEY.md §8b identifies; each entry point names the reference code it replaces
+ * (paths relative to the rust-mdbg tree):
+ *
+ *   mdbg_create            Params {k,l,density,min_kmer_abundance,reads_already_hpc}   src/main.rs:92-114,515-537
+ *                          + dbg_nodes / NODE_INDEX construction                       src/main.rs:595-598
+ *   mdbg_ingest_batch      process_read_aux over a batch of records                    src/main.rs:730-785
+ *     (= Read::extract_density  src/read.rs:176-211, encode_rle src/read.rs:157-174, nthash::NtHashIterator,
+ *        the k-min-mer window loop src/main.rs:756-781, KmerVec::normalize src/kmer_vec.rs:34-39 and
+ *        add_kminmer's counting upsert src/main.rs:632-691)
+ *   mdbg_sketch_only       Read::extract (density scheme)                              src/read.rs:85-90,176-211
+ *   mdbg_finalize          abundance filter + read-only view of dbg_nodes              src/main.rs:922-929,1014-1016
+ *                          + what the .sequences line of a node is built from          src/main.rs:693-708
+ *   mdbg_reset             a new k over the same reads (utils/multik:69-78 re-runs the binary per k)
+ *   mdbg_destroy           process exit
+ *
+ * Conventions: every function returns 0 (MDBG_OK) or a negative error code and never aborts (the reference
+ * panics); strings are (ptr,len); the caller owns its input buffers and may free them when a call returns;
+ * the library owns the context and every buffer it hands out until the next call that documents otherwise
+ * or mdbg_destroy.  Semantics are those of the reference run with `--threads 1` and without `--bf`:
+ * results do not depend on how reads are split into batches or on the order of the calls, only on
+ * `first_read_ordinal` (the position of the batch's first record in the input file).
+ *
+ * No torch / HIP types appear here: device buffers are plain pointers.
+ */
+#ifndef MDBG_HIP_H
+#define MDBG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDBG_ABI_VERSION 1
+
+enum {
+    MDBG_OK = 0,
+    MDBG_E_PARAM = -1,    /* bad parameter (k<2, l out of range, minabund==0, null pointer ...) */
+    MDBG_E_ALPHABET = -2, /* a read whose HPC length is >= l holds a byte outside "ACGTN" (reference: nthash panics) */
+    MDBG_E_CAPACITY = -3, /* a fixed limit was exceeded (e.g. more than 2^26 minimizers in one read) */
+    MDBG_E_DEVICE = -4,   /* HIP runtime failure; text via mdbg_last_error */
+    MDBG_E_NOMEM = -5,    /* device or host allocation failed */
+    MDBG_E_STATE = -6     /* call not valid in the context's current state (e.g. ingest after an error) */
+};
+
+#define MDBG_MAX_L 32u         /* l-mers longer than this are rejected (reference: unbounded) */
+#define MDBG_MAX_MINABUND 8u   /* the table tracks the A smallest ordinals per node for A <= 8 */
+
+typedef struct mdbg_ctx mdbg_ctx;
+
+/* src/main.rs:92-114 (the fields this path reads) */
+typedef struct mdbg_params {
+    uint32_t k;                 /* k-min-mer length, >= 2                                   (-k) */
+    uint32_t l;                 /* minimizer length, 2..MDBG_MAX_L                          (-l) */
+    double density;             /* hash_bound = floor(density * 2^64), src/read.rs:183      (--density) */
+    uint32_t min_abundance;     /* 1..MDBG_MAX_MINABUND                                     (--minabund) */
+    uint32_t reads_already_hpc; /* nonzero: skip homopolymer compression                    (--skiphpc) */
+    int32_t device;             /* HIP device ordinal, -1 = current device */
+    uint32_t flags;             /* reserved, 0 */
+    uint64_t table_capacity_hint; /* expected number of distinct k-min-mers, 0 = size from the data */
+    uint64_t reserved[4];
+} mdbg_params;
+
+/* Read-only view of the abundance-filtered node table (what src/main.rs:1014-1117 iterates).
+ * Nodes are sorted by `index`.  All arrays are library-owned HOST memory, valid until the next
+ * mdbg_finalize / mdbg_reset / mdbg_destroy on the context. */
+typedef struct mdbg_nodes {
+    uint64_t n;                 /* number of nodes after the abundance filter (main.rs:927) */
+    uint32_t k;
+    const uint64_t* keys;       /* n*k : canonical k-min-mer (KmerVec::normalize().0) */
+    const uint32_t* index;      /* n   : DbgEntry.index = rank of first sighting among ALL distinct k-min-mers (NODE_INDEX) */
+    const uint16_t* abundance;  /* n   : DbgEntry.abundance (u16, wraps like the reference) */
+    const uint32_t* seqlen;     /* n   : DbgEntry.seqlen of the A-th sighting (main.rs:680-682,778) */
+    const uint16_t* shift;      /* n*2 : DbgEntry.shift, truncated to u16 (main.rs:675) */
+    const uint64_t* shift_full; /* n*2 : un-truncated shift as printed in the .sequences line (main.rs:702) */
+    const uint64_t* src_read;   /* n   : ordinal of the read the A-th sighting came from */
+    const uint64_t* src_start;  /* n   : raw offset of the node's sequence in that read  (read_offsets.0) */
+    const uint64_t* src_end;    /* n   : raw end (exclusive) = pos[i+k-1] + l              (read_offsets.1) */
+    const uint8_t* reversed;    /* n   : seq_reversed of that sighting (sequence must be reverse-complemented, main.rs:701) */
+    uint64_t n_distinct;        /* "Number of nodes before abundance filter" (main.rs:926) */
+    uint64_t n_wrapped;         /* nodes seen >= 65536 times: abundance wrapped (reference: u16), metadata is that of the A-th sighting */
+} mdbg_nodes;
+
+typedef struct mdbg_stats {
+    uint64_t n_reads, n_bases, n_minimizers, n_windows, n_distinct, table_capacity;
+    uint64_t n_slow_tiles;      /* tiles that took the generic exact path (N, dense candidates, l > 14) */
+    uint64_t n_tiles;
+    double ms_sketch, ms_insert, ms_finalize; /* device time (HIP events) accumulated over calls since create/reset */
+    double ms_sketch_tile;      /* of ms_sketch: time inside sketch_tile_kernel launches only (HIP events around each launch) */
+    uint64_t n_sketch_tile_launches;
+    uint64_t n_sketch_tile_bases; /* raw bases covered by those launches */
+    uint64_t reserved[5];
+} mdbg_stats;
+
+mdbg_ctx* mdbg_create(const mdbg_params* p, int* err);
+void mdbg_destroy(mdbg_ctx* ctx);
+
+/* Ingest a batch of reads given as concatenated ASCII (HOST memory) + n_reads+1 offsets.  The bytes are
+ * copied to the device and processed there; the sketch of every read stays resident for mdbg_reset. */
+int mdbg_ingest_batch(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
+                      uint64_t first_read_ordinal);
+/* Same, with both buffers already in DEVICE memory (d_bases 16-byte aligned).  n_bases = offsets[n_reads]. */
+int mdbg_ingest_batch_device(mdbg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
+                             uint64_t n_bases, uint64_t first_read_ordinal);
+
+/* The Read::extract seam alone: sketches a batch (HOST buffers) without touching the node table.
+ * Outputs (library-owned host memory, valid until the next call on ctx): hashes[m] = Read.transformed,
+ * positions[m] = Read.minimizers_pos, per_read_offsets[n_reads+1] delimiting each read's slice. */
+int mdbg_sketch_only(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
+                     const uint64_t** hashes, const uint64_t** positions, const uint64_t** per_read_offsets,
+                     uint64_t* n_minimizers);
+
+int mdbg_finalize(mdbg_ctx* ctx, mdbg_nodes* out);
+/* Same node table, but every pointer in *out is DEVICE memory (no copy to the host). */
+int mdbg_finalize_device(mdbg_ctx* ctx, mdbg_nodes* out);
+/* Multi-k: keep every cached sketch and all allocations, clear the node table, and re-window the
+ * resident sketches with new_k (new_k == 0: also drop the sketches = start over with the same parameters). */
+int mdbg_reset(mdbg_ctx* ctx, uint32_t new_k);
+
+int mdbg_get_stats(mdbg_ctx* ctx, mdbg_stats* out);
+const char* mdbg_strerror(int err);
+const char* mdbg_last_error(mdbg_ctx* ctx); /* detail of the last failure on ctx ("" if none) */
+uint32_t mdbg_abi_version(void);
+
+/* ---- device-resident stage entry points (used by the multi-GPU driver and the benchmark) -------------
+ * Sketch stage only, device buffers in, results appended to the context's resident sketch store. */
+int mdbg_sketch_device(mdbg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
+                       uint64_t n_bases, uint64_t first_read_ordinal);
+/* Window + insert every sketch appended since the last call of this function / reset. */
+int mdbg_insert_resident(mdbg_ctx* ctx);
+/* Key-range routing for the RCCL all-to-all: packs the k-min-mer occurrences not yet
+ * inserted into `world` destination buckets (owner = mulhi64(keyhash, world)).  One record is k+1 u64:
+ * canonical key then the global ordinal.  *d_records receives a device pointer to the bucketed records
+ * (library-owned), counts[world] (HOST) the records per destination. */
+int mdbg_route_pack(mdbg_ctx* ctx, uint32_t world, const uint64_t** d_records, uint64_t* counts);
+/* Insert routed records (device memory, k+1 u64 each) received from peers. The buffer must stay valid
+ * until mdbg_finalize/mdbg_reset (node keys are referenced in place). */
+int mdbg_insert_records(mdbg_ctx* ctx, const uint64_t* d_records, uint64_t n_records);
+/* Wait for all device work queued by ctx. */
+int mdbg_sync(mdbg_ctx* ctx);
+
+/* Synthetic HiFi-shaped reads (counter-based, integer-only generator; the same bytes can be regenerated
+ * on the CPU, see rust_mdbg_amd/synth.py).  Fills library-owned DEVICE buffers. */
+typedef struct mdbg_synth_params {
+    uint64_t seed;
+    uint64_t genome_len;
+    uint64_t n_reads;
+    uint32_t mean_len, sd_len, min_len, max_len;
+    uint32_t err_ppm;           /* per-base error rate in parts per million, split sub/ins/del 1:1:1 */
+    uint32_t reserved;
+} mdbg_synth_params;
+int mdbg_synth_reads_device(mdbg_ctx* ctx, const mdbg_synth_params* sp, uint64_t first_read,
+                            const uint8_t** d_bases, const uint64_t** d_offsets, uint64_t* n_bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDBG_HIP_H */

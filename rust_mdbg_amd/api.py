@@ -1,0 +1,216 @@
+"""ctypes binding of include/mdbg_hip.h — the host-side mirror of rust-mdbg's per-read path.
+
+Names follow the reference: `Params` (src/main.rs:92-114), `Mdbg.ingest` = process_read_aux over a batch
+(src/main.rs:730-785), `Mdbg.sketch` = Read::extract (src/read.rs:85-90), `Mdbg.finalize` = the abundance filter
+plus the read-only node view the graph emitter walks (src/main.rs:922-929,1014-1016).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MDBG_OK, MDBG_E_PARAM, MDBG_E_ALPHABET, MDBG_E_CAPACITY, MDBG_E_DEVICE, MDBG_E_NOMEM, MDBG_E_STATE = 0, -1, -2, -3, -4, -5, -6
+FLAG_FORCE_GENERIC = 1   # mdbg_params.flags bit 0: every tile takes the generic exact kernel (testing)
+
+
+class MdbgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mdbg error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("l", C.c_uint32), ("density", C.c_double), ("min_abundance", C.c_uint32),
+                ("reads_already_hpc", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("table_capacity_hint", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
+class Nodes(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("k", C.c_uint32), ("keys", C.POINTER(C.c_uint64)), ("index", C.POINTER(C.c_uint32)),
+                ("abundance", C.POINTER(C.c_uint16)), ("seqlen", C.POINTER(C.c_uint32)), ("shift", C.POINTER(C.c_uint16)),
+                ("shift_full", C.POINTER(C.c_uint64)), ("src_read", C.POINTER(C.c_uint64)), ("src_start", C.POINTER(C.c_uint64)),
+                ("src_end", C.POINTER(C.c_uint64)), ("reversed", C.POINTER(C.c_uint8)), ("n_distinct", C.c_uint64),
+                ("n_wrapped", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_minimizers", C.c_uint64), ("n_windows", C.c_uint64),
+                ("n_distinct", C.c_uint64), ("table_capacity", C.c_uint64), ("n_slow_tiles", C.c_uint64), ("n_tiles", C.c_uint64),
+                ("ms_sketch", C.c_double), ("ms_insert", C.c_double), ("ms_finalize", C.c_double), ("ms_sketch_tile", C.c_double),
+                ("n_sketch_tile_launches", C.c_uint64), ("n_sketch_tile_bases", C.c_uint64), ("reserved", C.c_uint64 * 5)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_reads", C.c_uint64), ("mean_len", C.c_uint32),
+                ("sd_len", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("err_ppm", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
+           "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
+           "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device"]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmdbg_hip.so")
+
+
+def load_library():
+    """Loads libmdbg_hip.so.  No fallback: a missing library is an error (build with __graft_entry__.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError("libmdbg_hip.so not built (%s); run `make -C rust_mdbg_amd/csrc`" % p)
+    L = C.CDLL(p)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.mdbg_abi_version.restype = u32
+    L.mdbg_create.restype = vp
+    L.mdbg_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_int)]
+    L.mdbg_destroy.restype = None
+    L.mdbg_destroy.argtypes = [vp]
+    L.mdbg_ingest_batch.argtypes = [vp, vp, vp, u64, u64]
+    L.mdbg_ingest_batch_device.argtypes = [vp, vp, vp, u64, u64, u64]
+    L.mdbg_sketch_device.argtypes = [vp, vp, vp, u64, u64, u64]
+    L.mdbg_insert_resident.argtypes = [vp]
+    L.mdbg_sketch_only.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(u64)]
+    L.mdbg_finalize.argtypes = [vp, C.POINTER(Nodes)]
+    L.mdbg_finalize_device.argtypes = [vp, C.POINTER(Nodes)]
+    L.mdbg_reset.argtypes = [vp, u32]
+    L.mdbg_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.mdbg_strerror.restype = C.c_char_p
+    L.mdbg_strerror.argtypes = [C.c_int]
+    L.mdbg_last_error.restype = C.c_char_p
+    L.mdbg_last_error.argtypes = [vp]
+    L.mdbg_route_pack.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+    L.mdbg_insert_records.argtypes = [vp, vp, u64]
+    L.mdbg_sync.argtypes = [vp]
+    L.mdbg_synth_reads_device.argtypes = [vp, C.POINTER(SynthParams), u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    for f in ("mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_device", "mdbg_insert_resident", "mdbg_sketch_only",
+              "mdbg_finalize", "mdbg_finalize_device", "mdbg_reset", "mdbg_get_stats", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync",
+              "mdbg_synth_reads_device"):
+        getattr(L, f).restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _np(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def concat_reads(reads):
+    """list[bytes] -> (uint8 bases, uint64 offsets[n+1]) — the batch layout of mdbg_ingest_batch"""
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    if reads:
+        offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, np.uint8)
+    return bases, offs
+
+
+class Mdbg:
+    """One context = one device-resident sketch store + k-min-mer table (dbg_nodes, src/main.rs:595)."""
+
+    def __init__(self, k, l, density, min_abundance=2, reads_already_hpc=False, device=-1, flags=0, table_capacity_hint=0):
+        self.L = load_library()
+        self.params = Params(k=k, l=l, density=density, min_abundance=min_abundance, reads_already_hpc=int(reads_already_hpc),
+                             device=device, flags=flags, table_capacity_hint=table_capacity_hint)
+        err = C.c_int(0)
+        self.h = self.L.mdbg_create(C.byref(self.params), C.byref(err))
+        if not self.h:
+            raise MdbgError(err.value, self.L.mdbg_strerror(err.value).decode())
+        self.k = k
+
+    def _chk(self, e):
+        if e != 0:
+            raise MdbgError(e, (self.L.mdbg_last_error(self.h) or self.L.mdbg_strerror(e)).decode())
+
+    # --- process_read_aux over a batch (host buffers) ---
+    def ingest(self, bases, offsets, first_read_ordinal=0):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._chk(self.L.mdbg_ingest_batch(self.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, first_read_ordinal))
+
+    def ingest_reads(self, reads, first_read_ordinal=0):
+        b, o = concat_reads(reads)
+        self.ingest(b, o, first_read_ordinal)
+
+    # --- device-resident buffers (raw pointers, e.g. torch.Tensor.data_ptr()) ---
+    def ingest_device(self, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal=0):
+        self._chk(self.L.mdbg_ingest_batch_device(self.h, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal))
+
+    def sketch_device(self, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal=0):
+        self._chk(self.L.mdbg_sketch_device(self.h, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal))
+
+    def insert_resident(self):
+        self._chk(self.L.mdbg_insert_resident(self.h))
+
+    # --- Read::extract seam ---
+    def sketch(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        ph, pp, po = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        m = C.c_uint64()
+        self._chk(self.L.mdbg_sketch_only(self.h, bases.ctypes.data, offsets.ctypes.data, n, C.byref(ph), C.byref(pp), C.byref(po), C.byref(m)))
+        return dict(hashes=_np(ph, m.value, np.uint64), pos=_np(pp, m.value, np.uint64), off=_np(po, n + 1, np.uint64))
+
+    def finalize(self):
+        nd = Nodes()
+        self._chk(self.L.mdbg_finalize(self.h, C.byref(nd)))
+        n, k = nd.n, nd.k
+        return dict(n_nodes=int(n), n_nodes_before=int(nd.n_distinct), n_wrapped=int(nd.n_wrapped),
+                    keys=_np(nd.keys, n * k, np.uint64).reshape(n, k), index=_np(nd.index, n, np.uint32),
+                    abundance=_np(nd.abundance, n, np.uint16), seqlen=_np(nd.seqlen, n, np.uint32),
+                    shift=_np(nd.shift, 2 * n, np.uint16).reshape(n, 2), shift_full=_np(nd.shift_full, 2 * n, np.uint64).reshape(n, 2),
+                    src_read=_np(nd.src_read, n, np.uint64), src_start=_np(nd.src_start, n, np.uint64),
+                    src_end=_np(nd.src_end, n, np.uint64), reversed=_np(nd.reversed, n, np.uint8))
+
+    def finalize_device(self):
+        """node table left in device memory; returns the raw mdbg_nodes struct (device pointers)"""
+        nd = Nodes()
+        self._chk(self.L.mdbg_finalize_device(self.h, C.byref(nd)))
+        return nd
+
+    def reset(self, new_k):
+        self._chk(self.L.mdbg_reset(self.h, new_k))
+        if new_k:
+            self.k = new_k
+
+    def sync(self):
+        self._chk(self.L.mdbg_sync(self.h))
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.mdbg_get_stats(self.h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in Stats._fields_ if f != "reserved"}
+
+    def synth_reads_device(self, seed, genome_len, n_reads, mean_len=15000, sd_len=1500, min_len=8000, max_len=25000, err_ppm=1000, first_read=0):
+        """-> (d_bases ptr, d_offsets ptr, n_bases); buffers are owned by the context (valid until the next call)"""
+        sp = SynthParams(seed=seed, genome_len=genome_len, n_reads=n_reads, mean_len=mean_len, sd_len=sd_len, min_len=min_len,
+                         max_len=max_len, err_ppm=err_ppm)
+        db, do, nb = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._chk(self.L.mdbg_synth_reads_device(self.h, C.byref(sp), first_read, C.byref(db), C.byref(do), C.byref(nb)))
+        return db.value, do.value, nb.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mdbg_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

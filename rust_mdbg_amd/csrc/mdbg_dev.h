@@ -1,0 +1,89 @@
+// mdbg_dev.h — shared types, constants and device helpers for libmdbg_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---- tile geometry of the sketch kernel -------------------------------------------------------
+// One workgroup = 256 lanes (4 wave64), each lane rolls the hash over SEG contiguous raw bases.
+constexpr int TILE_THREADS = 256;
+constexpr int SEG = 256;                          // raw bases per lane
+constexpr int TILE = TILE_THREADS * SEG;          // 65536 raw bases per tile
+constexpr int HALO = 128;                         // raw bases staged in front of the tile
+constexpr int SEG_WORDS = SEG / 16;               // 2-bit codes, 16 per dword
+constexpr int SEG_STRIDE = 20;                    // padded dwords per segment in LDS: 20*i mod 64 hits 16 distinct 4-bank groups -> ds_read_b128 conflict-free
+constexpr int QCAP = 2048;                        // candidate capacity of a fast tile (slab slots)
+constexpr u32 SLOW_MARK = 0xFFFFFFFFu;            // n_cand value of a tile handed to the generic path
+constexpr int FAST_MAX_L = 14;                    // 32-bit code history: 3 + 2*l <= 31
+
+// ordinal = (global read ordinal << WIN_BITS) | window index within the read
+constexpr int WIN_BITS = 26;
+constexpr u64 WIN_MASK = (1ull << WIN_BITS) - 1;
+
+struct __attribute__((aligned(16))) Rec {         // one slab slot / one selected minimizer
+    u64 hash;
+    u32 pos;                                      // raw position relative to the read start
+    u32 read;                                     // batch-local read index, 0xFFFFFFFF = rejected candidate
+};
+
+// ntHash seeds by 2-bit code ((ascii >> 1) & 3: A=0 C=1 T=2 G=3); nthash crate 0.5.1 H_LOOKUP / RC_LOOKUP
+#define NT_SEED_A 0x3c8bfbb395c60474ull
+#define NT_SEED_C 0x3193c18562a02b4cull
+#define NT_SEED_G 0x20323ed082572324ull
+#define NT_SEED_T 0x295549f54be24456ull
+
+struct SketchConsts {
+    u64 bound;          // hash_bound (src/read.rs:183)
+    u32 l;
+    u32 hpc;            // 1: homopolymer-compress (default), 0: --skiphpc
+    // candidate filter on 32-bit partial hashes (see DESIGN.md "sketch kernel")
+    u32 thrF, thrR, maskR, G0, R0, bfe_off;
+    u32 tbl[32];        // 16 x {XF, XR} indexed by out*4+in
+};
+
+__host__ __device__ inline u64 rol64(u64 x, unsigned r) { r &= 63; return (x << r) | (x >> ((64 - r) & 63)); }
+
+// ntHash contribution of an ASCII byte; N -> 0; any other byte -> 0 (the error is raised elsewhere)
+__device__ inline u64 nt_h_ascii(u8 c) {
+    return c == 'A' ? NT_SEED_A : c == 'C' ? NT_SEED_C : c == 'G' ? NT_SEED_G : c == 'T' ? NT_SEED_T : 0ull;
+}
+__device__ inline u64 nt_rc_ascii(u8 c) {
+    return c == 'A' ? NT_SEED_T : c == 'C' ? NT_SEED_G : c == 'G' ? NT_SEED_C : c == 'T' ? NT_SEED_A : 0ull;
+}
+// src/read.rs:163 — only these bytes collapse into homopolymer runs
+__device__ inline bool in_hpc_set(u8 c) {
+    return c == 'A' || c == 'C' || c == 'T' || c == 'G' || c == 'a' || c == 'c' || c == 't' || c == 'g' || c == 'N' || c == 'n';
+}
+
+// ---- wave / block scans (wave = 64 lanes) -------------------------------------------------------
+__device__ inline u32 wave_incl_scan(u32 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// exclusive scan over a 256-thread block; tmp must hold 5 u32 in LDS; every thread gets `total`
+__device__ inline u32 block_excl_scan_256(u32 v, u32* tmp, u32& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 inc = wave_incl_scan(v);
+    __syncthreads();                       // tmp may still be read by a previous call
+    if (lane == 63) tmp[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u32 t = tmp[i]; if (i < w) base += t; tot += t; }
+    total = tot;
+    return base + inc - v;
+}
+
+// 64-bit finaliser (murmur3 fmix64)
+__host__ __device__ inline u64 fmix64(u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x;
+}

@@ -1,0 +1,455 @@
+// sketch.hip — HPC + ntHash + density filter, fused (gfx950).
+//
+// Replaces Read::encode_rle + Read::extract_density (rust-mdbg src/read.rs:157-211) and the nthash
+// crate's NtHashIterator for a whole batch of reads.  Layout and algorithm: DESIGN.md §"sketch kernel".
+//
+//   sketch_tile_kernel   fast path: one workgroup per 64 Ki raw bases of the concatenated batch.
+//                        ASCII is read once with coalesced 16-byte loads, packed to 2-bit codes in LDS,
+//                        each lane then rolls 32-bit partial fwd/rev ntHash values over its own 256-base
+//                        segment (HPC = "push only when the code changes"), flags candidates in a bitmap,
+//                        and an exact 64-bit fix-up (walk back over l run starts) validates every candidate.
+//   slow_tile_kernel     exact generic path straight from ASCII (N, invalid bytes, l > 14, dense tiles).
+//   gather_kernel        squeezes the per-tile candidate slabs into the final, position-ordered arrays.
+#include "mdbg_dev.h"
+
+struct TileArgs {
+    const u8* bases; u64 n_bases; const u64* offsets; u32 n_reads;
+    const u32* bread;            // read containing the first base of tile t, [n_tiles_total + 1]
+    u64 tile0; u32 n_tiles;      // this launch covers tiles [tile0, tile0 + n_tiles)
+    Rec* slab;                   // [n_tiles][QCAP]
+    u32* n_cand; u32* n_valid;   // per tile of the launch
+    u32* slow_list; u32* slow_count;
+    u32* err_flag;               // set when a byte outside ACGTN is seen
+    const u32* tbl;              // device copy of SketchConsts::tbl
+    u32 read_base;               // slot index of the batch's first read in the resident store
+    SketchConsts c;
+};
+
+// largest r in [lo, hi] with off[r] <= p
+__device__ inline u32 find_read(const u64* __restrict__ off, u32 lo, u32 hi, u64 p) {
+    while (lo < hi) { u32 mid = lo + ((hi - lo + 1) >> 1); if (off[mid] <= p) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ void bread_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_tiles_total, u32* __restrict__ bread) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles_total) return;
+    bread[t] = (t == n_tiles_total) ? n_reads - 1 : find_read(off, 0, n_reads - 1, t * (u64)TILE);
+}
+
+// ---- exact generic walker on ASCII (src/read.rs:157-174 semantics) -----------------------------
+template <bool HPC>
+__device__ inline bool kept_ascii(const u8* __restrict__ b, u64 rlo, u64 p) {
+    if (!HPC || p == rlo) return true;
+    u8 c = b[p];
+    return !(c == b[p - 1] && in_hpc_set(c));
+}
+// l-mer whose LAST HPC base is the run starting at p.  false: fewer than l HPC bases precede p in the read.
+template <bool HPC>
+__device__ inline bool walk_lmer_ascii(const u8* __restrict__ b, u64 rlo, u64 p, u32 l, u64& start, u64& hash) {
+    u64 q = p, fh = 0, rh = 0;
+    for (int j = (int)l - 1;; --j) {
+        u8 c = b[q];
+        fh ^= rol64(nt_h_ascii(c), l - 1 - j);
+        rh ^= rol64(nt_rc_ascii(c), j);
+        if (j == 0) break;
+        if (q == rlo) return false;
+        u64 q2 = q - 1;
+        if (HPC) { u8 c2 = b[q2]; if (in_hpc_set(c2)) while (q2 > rlo && b[q2 - 1] == c2) --q2; }
+        q = q2;
+    }
+    start = q; hash = fh < rh ? fh : rh;
+    return true;
+}
+
+// ---- generic exact tile kernel -------------------------------------------------------------------
+// WRITE=false: counts the selected minimizers of every slow tile (n_valid).  WRITE=true: writes them at tile_base.
+template <bool HPC, bool WRITE>
+__global__ __launch_bounds__(256) void slow_tile_kernel(TileArgs a, const u64* __restrict__ tile_base,
+                                                        u64* __restrict__ out_hash, u32* __restrict__ out_pos,
+                                                        u32* __restrict__ out_read, u64 out_cap) {
+    __shared__ u32 tmp[8];
+    const u32 s = blockIdx.x;
+    if (s >= *a.slow_count) return;
+    const u32 t = a.slow_list[s];
+    const u64 gt = a.tile0 + t;
+    const u64 tile_start = gt * (u64)TILE;
+    const u64 tile_end = tile_start + TILE < a.n_bases ? tile_start + TILE : a.n_bases;
+    const u32 rl = a.bread[gt], rh_ = a.bread[gt + 1];
+    u32 running = 0;
+    for (u64 base = tile_start; base < tile_end; base += 256) {
+        const u64 p = base + threadIdx.x;
+        u32 sel = 0; u64 hash = 0, start = 0; u32 r = 0; u64 rlo = 0;
+        if (p < tile_end) {
+            r = find_read(a.offsets, rl, rh_, p);
+            rlo = a.offsets[r];
+            if (kept_ascii<HPC>(a.bases, rlo, p) && walk_lmer_ascii<HPC>(a.bases, rlo, p, a.c.l, start, hash) && hash <= a.c.bound) sel = 1;
+        }
+        u32 total;
+        u32 rank = block_excl_scan_256(sel, tmp, total);
+        if (WRITE && sel) {
+            u64 idx = tile_base[t] + running + rank;
+            if (idx < out_cap) { out_hash[idx] = hash; out_pos[idx] = (u32)(start - rlo); out_read[idx] = r + a.read_base; }
+        }
+        running += total;
+    }
+    if (!WRITE && threadIdx.x == 0) a.n_valid[t] = running;
+}
+
+// marks every tile of the launch slow (l > FAST_MAX_L or forced)
+__global__ void all_slow_kernel(u32 n_tiles, u32* __restrict__ n_cand, u32* __restrict__ slow_list, u32* __restrict__ slow_count) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles) { n_cand[t] = SLOW_MARK; slow_list[t] = t; }
+    if (t == 0) *slow_count = n_tiles;
+}
+
+// ---- fast tile kernel ------------------------------------------------------------------------------
+constexpr int LDS_CODES = (TILE_THREADS + 1) * SEG_STRIDE;   // segment -1 holds the halo (last 8 words)
+constexpr int LDS_LIST = QCAP / 2;
+constexpr int LDS_TBL = 32;
+constexpr int LDS_HC = 16;
+constexpr int LDS_MISC = 16;
+constexpr int LDS_TOTAL = LDS_CODES + LDS_LIST + LDS_TBL + LDS_HC + LDS_MISC;
+
+__device__ inline int codes_addr(int j) { return ((j >> 4) + 1) * SEG_STRIDE + (j & 15); }   // j = logical word index, >= -8
+
+__device__ inline u32 pack16(uint4 v, u32& bad) {
+    u32 out = 0;
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 s = (w[i] >> 1) & 0x03030303u;
+        u32 recon = __builtin_amdgcn_perm(0u, 0x47544341u /* 'A','C','T','G' by code */, s);
+        bad |= recon ^ w[i];
+        u32 byte = __builtin_amdgcn_udot4(s, 0x40100401u, 0u, false);   // c0 + 4 c1 + 16 c2 + 64 c3
+        out |= byte << (8 * i);
+    }
+    return out;
+}
+
+template <bool HPC>
+__global__ __launch_bounds__(TILE_THREADS) void sketch_tile_kernel(TileArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 lds[LDS_TOTAL];
+    u32* const codes = lds;
+    u16* const list = (u16*)(lds + LDS_CODES);
+    u32* const tbl = lds + LDS_CODES + LDS_LIST;
+    u64* const hc = (u64*)(tbl + LDS_TBL);             // hc[0..3] = h by code, hc[4..7] = rc by code
+    u32* const misc = tbl + LDS_TBL + LDS_HC;          // [0..4] scan tmp, [8] slow flag
+
+    const int tid = threadIdx.x;
+    const u32 t = blockIdx.x;
+    const u64 gt = a.tile0 + t;
+    const int64_t tile_start = (int64_t)(gt * (u64)TILE);
+    const int64_t nb = (int64_t)a.n_bases;
+    const u32 l = a.c.l;
+
+    if (tid < 32) tbl[tid] = a.tbl[tid];
+    if (tid == 32) { hc[0] = NT_SEED_A; hc[1] = NT_SEED_C; hc[2] = NT_SEED_T; hc[3] = NT_SEED_G;
+                     hc[4] = NT_SEED_T; hc[5] = NT_SEED_G; hc[6] = NT_SEED_A; hc[7] = NT_SEED_C; }
+    if (tid == 33) misc[8] = 0;
+    __syncthreads();
+
+    // ---- phase 1: ASCII -> 2-bit codes in LDS (coalesced 16-byte loads) ---------------------------
+    {
+        u32 bad_any = 0;
+        constexpr int NCHUNK = (TILE + HALO) / 16;
+        for (int ci = tid; ci < NCHUNK; ci += TILE_THREADS) {
+            const int j = ci - HALO / 16;
+            const int64_t pos = tile_start + 16 * (int64_t)j;
+            uint4 v = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+            if (pos >= 0 && pos + 16 <= nb) v = *(const uint4*)(a.bases + pos);
+            else if (pos >= 0 && pos < nb) {
+                __attribute__((aligned(16))) u8 tmpb[16];
+                for (int i = 0; i < 16; ++i) tmpb[i] = (pos + i < nb) ? a.bases[pos + i] : (u8)'A';
+                v = *(const uint4*)tmpb;
+            }
+            u32 bad = 0;
+            codes[codes_addr(j)] = pack16(v, bad);
+            bad_any |= bad;
+        }
+        if (bad_any) {                       // some byte of my chunks is not one of ACGT
+            misc[8] = 1;                     // whole tile takes the generic exact path
+            for (int ci = tid; ci < NCHUNK; ci += TILE_THREADS) {
+                const int64_t pos = tile_start + 16 * (int64_t)(ci - HALO / 16);
+                for (int i = 0; i < 16; ++i) {
+                    int64_t q = pos + i;
+                    if (q >= 0 && q < nb) { u8 c = a.bases[q]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') *a.err_flag = 1; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (misc[8]) {
+        if (tid == 0) { a.n_cand[t] = SLOW_MARK; a.slow_list[atomicAdd(a.slow_count, 1u)] = t; }
+        return;
+    }
+
+    // ---- phase 2: per-lane rolling partial hashes over SEG raw bases ------------------------------
+    const u32 thrF = a.c.thrF, thrR = a.c.thrR, maskR = a.c.maskR, bfe_off = a.c.bfe_off;
+    u32 hist, G, R, prev, npush;
+    u32 cb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cb[i] = 0;
+    bool force = false;                       // first l-1 pushes of my segment must all be candidates
+
+#define MDBG_STEP(w, i, EMIT, cbv, bit)                                                     \
+    {                                                                                        \
+        const u32 c_ = ((w) >> (2 * (i))) & 3u;                                              \
+        if (!HPC || c_ != prev) {                                                            \
+            const u32 c8_ = c_ << 3;                                                         \
+            const u32 out_ = __builtin_amdgcn_ubfe(hist, bfe_off, 2u);                       \
+            const u32 ad_ = (out_ << 5) | c8_;                                               \
+            hist = (hist << 2) | c8_;                                                        \
+            const uint2 x_ = *(const uint2*)((const char*)tbl + ad_);                        \
+            G = (G << 1) ^ x_.x;                                                             \
+            R = (R >> 1) ^ x_.y;                                                             \
+            if (EMIT) { if (G <= thrF || (R & maskR) <= thrR) cbv |= (1u << (bit)); }        \
+            else ++npush;                                                                    \
+        }                                                                                    \
+        prev = c_;                                                                           \
+    }
+
+    const bool active = tile_start + (int64_t)tid * SEG < nb;
+    if (active) {
+    {
+        int nW = 2;                           // warm-up words (32 raw bases), then 8 (the whole halo)
+        for (;;) {
+            hist = 0; G = a.c.G0; R = a.c.R0; npush = 0;
+            const int ws = tid * SEG_WORDS - nW;
+            prev = (ws - 1 >= -HALO / 16) ? codes[codes_addr(ws - 1)] >> 30 : 4u;
+            for (int k = 0; k < nW; ++k) {
+                const u32 w = codes[codes_addr(ws + k)];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) MDBG_STEP(w, i, false, cb[0], 0)
+            }
+            if (npush >= l || nW == 8) break;
+            nW = 8;
+        }
+        if (npush < l) {
+            // rare: fewer than l code changes in the 128 bases before my segment (long homopolymer).
+            // Replay from global memory, at most 4096 bases back; if that is still not enough, or a byte
+            // outside ACGT is met, the partial hashes of my first l-1 pushes cannot be trusted -> force them.
+            const int64_t seg0 = tile_start + (int64_t)tid * SEG;
+            int64_t q = seg0; u32 runs = 0; bool dirty = false;
+            while (q > 0 && runs < l + 1 && seg0 - q < 4096) {
+                --q;
+                const u8 b0 = a.bases[q];
+                if (b0 != 'A' && b0 != 'C' && b0 != 'G' && b0 != 'T') dirty = true;
+                if (!HPC || q == 0 || (((u32)a.bases[q - 1] >> 1) & 3u) != (((u32)b0 >> 1) & 3u)) ++runs;
+            }
+            if (dirty || (runs < l + 1 && q > 0)) force = true;
+            hist = 0; G = a.c.G0; R = a.c.R0; npush = 0;
+            prev = q > 0 ? (((u32)a.bases[q - 1] >> 1) & 3u) : 4u;
+            for (; q < seg0; ++q) { const u32 w = ((u32)a.bases[q] >> 1) & 3u; MDBG_STEP(w, 0, false, cb[0], 0) }
+        }
+    }
+    {
+        const uint4* segp = (const uint4*)(codes + (tid + 1) * SEG_STRIDE);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint4 v = segp[g];
+            const u32 w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 w = w4[k];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) MDBG_STEP(w, i, true, cb[g * 2 + (k >> 1)], (k & 1) * 16 + i)
+            }
+        }
+    }
+    if (force) {                              // mark the first l-1 pushes of my segment
+        u32 pushes = 0; u32 pv = codes[codes_addr(tid * SEG_WORDS - 1)] >> 30;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            for (int b = 0; b < 32 && pushes < l - 1; ++b) {
+                const int p = i * 32 + b;
+                const u32 c = (codes[codes_addr(tid * SEG_WORDS + (p >> 4))] >> (2 * (p & 15))) & 3u;
+                if (!HPC || c != pv) { cb[i] |= 1u << b; ++pushes; }
+                pv = c;
+            }
+        }
+    }
+    }   // active
+#undef MDBG_STEP
+
+    // ---- phase 3: ordered candidate list -------------------------------------------------------------
+    u32 cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cnt += __popc(cb[i]);
+    u32 n_cand;
+    u32 base = block_excl_scan_256(cnt, misc, n_cand);
+    if (n_cand > QCAP) {                      // too dense for the slab: generic path
+        if (tid == 0) { a.n_cand[t] = SLOW_MARK; a.slow_list[atomicAdd(a.slow_count, 1u)] = t; }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 m = cb[i];
+        while (m) { const int b = __ffs(m) - 1; m &= m - 1; list[base++] = (u16)(tid * SEG + i * 32 + b); }
+    }
+    __syncthreads();
+
+    // ---- phase 4: exact 64-bit fix-up of every candidate ----------------------------------------------
+    const u32 rl = a.bread[gt], rhi = a.bread[gt + 1];
+    const int64_t lds_lo = tile_start - HALO;            // first raw position staged in LDS
+    auto code_at = [&](int64_t q) -> u32 { const int rel = (int)(q - tile_start); return (codes[codes_addr(rel >> 4)] >> (2 * (rel & 15))) & 3u; };
+    u32 nval = 0;
+    Rec* slab = a.slab + (size_t)t * QCAP;
+    for (u32 j = tid; j < n_cand; j += TILE_THREADS) {
+        const int64_t p = tile_start + list[j];
+        Rec rec; rec.hash = 0; rec.pos = 0; rec.read = 0xFFFFFFFFu;
+        if (p < nb) {
+            const u32 r = find_read(a.offsets, rl, rhi, (u64)p);
+            const int64_t rlo = (int64_t)a.offsets[r];
+            bool ok = true, in_lds = true;
+            u64 fh = 0, rh = 0; int64_t q = p;
+            if (HPC && p != rlo && code_at(p - 1) == code_at(p)) ok = false;      // not a run start inside its read
+            for (int jj = (int)l - 1; ok; --jj) {
+                const u32 c = code_at(q);
+                fh ^= rol64(hc[c], l - 1 - jj);
+                rh ^= rol64(hc[4 + c], jj);
+                if (jj == 0) break;
+                if (q == rlo) { ok = false; break; }
+                int64_t q2 = q - 1;
+                if (q2 < lds_lo) { in_lds = false; break; }
+                if (HPC) {
+                    const u32 c2 = code_at(q2);
+                    while (q2 > rlo) { if (q2 - 1 < lds_lo) { in_lds = false; break; } if (code_at(q2 - 1) != c2) break; --q2; }
+                    if (!in_lds) break;
+                }
+                q = q2;
+            }
+            u64 h = fh < rh ? fh : rh, start = (u64)q;
+            if (ok && !in_lds) ok = walk_lmer_ascii<HPC>(a.bases, (u64)rlo, (u64)p, l, start, h);   // ran off the staged region
+            if (ok && h <= a.c.bound) { rec.hash = h; rec.pos = (u32)(start - (u64)rlo); rec.read = r + a.read_base; ++nval; }
+        }
+        slab[j] = rec;
+    }
+    u32 tot;
+    (void)block_excl_scan_256(nval, misc, tot);
+    if (tid == 0) { a.n_cand[t] = n_cand; a.n_valid[t] = tot; }
+}
+
+// ---- gather: slabs -> final position-ordered arrays ---------------------------------------------
+__global__ __launch_bounds__(256) void gather_kernel(u32 n_tiles, const Rec* __restrict__ slab, const u32* __restrict__ n_cand,
+                                                     const u64* __restrict__ tile_base, u64* __restrict__ out_hash,
+                                                     u32* __restrict__ out_pos, u32* __restrict__ out_read, u64 out_cap) {
+    __shared__ u32 tmp[8];
+    const u32 t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const u32 nc = n_cand[t];
+    if (nc == SLOW_MARK || nc == 0) return;
+    const Rec* s = slab + (size_t)t * QCAP;
+    u64 base = tile_base[t];
+    for (u32 j0 = 0; j0 < nc; j0 += 256) {
+        const u32 j = j0 + threadIdx.x;
+        Rec r; r.read = 0xFFFFFFFFu;
+        if (j < nc) r = s[j];
+        const u32 v = r.read != 0xFFFFFFFFu;
+        u32 total;
+        const u32 rank = block_excl_scan_256(v, tmp, total);
+        if (v) { const u64 idx = base + rank; if (idx < out_cap) { out_hash[idx] = r.hash; out_pos[idx] = r.pos; out_read[idx] = r.read; } }
+        base += total;
+    }
+}
+
+// exclusive scan of n_valid over the tiles of one launch, single workgroup; carry[0] in/out = running total
+__global__ __launch_bounds__(1024) void tile_scan_kernel(u32 n, const u32* __restrict__ n_valid, u64* __restrict__ tile_base, u64* __restrict__ carry) {
+    __shared__ u64 wsum[16];
+    __shared__ u64 run;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) run = carry[0];
+    __syncthreads();
+    for (u32 i0 = 0; i0 < n; i0 += 1024) {
+        const u32 i = i0 + tid;
+        const u32 v = i < n ? n_valid[i] : 0;
+        u32 inc = wave_incl_scan(v);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        u64 b = run; u64 tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < w) b += wsum[k]; tot += wsum[k]; }
+        if (i < n) tile_base[i] = b + inc - v;
+        __syncthreads();
+        if (tid == 0) run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) carry[0] = run;
+}
+
+// per-read offsets into the ordered minimizer arrays: off[slot] = first i with mread[i] >= slot, for the batch's
+// slots [slot0, slot0 + n_reads]; mread holds absolute slot indices and is sorted.
+__global__ void read_offsets_kernel(const u32* __restrict__ mread, u64 m0, u64 m1, u32 slot0, u32 n_reads, u64* __restrict__ off) {
+    const u64 i = m0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > m1) return;
+    const int64_t prev = (i == m0) ? (int64_t)slot0 - 1 : (int64_t)mread[i - 1];
+    const int64_t cur = (i == m1) ? (int64_t)slot0 + n_reads : (int64_t)mread[i];
+    for (int64_t r = prev + 1; r <= cur; ++r) off[r] = i;
+}
+__global__ void acc_slow_kernel(const u32* __restrict__ slow_count, u64* __restrict__ slow_total) { *slow_total += *slow_count; }
+
+// ---- host launchers -------------------------------------------------------------------------------
+struct SketchLaunch {
+    const u8* bases; u64 n_bases; const u64* offsets; u32 n_reads;
+    u32* bread; u64 n_tiles_total;
+    Rec* slab; u32* n_cand; u32* n_valid; u64* tile_base; u32* slow_list; u32* slow_count; u32* err_flag; u64* carry;
+    u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
+    SketchConsts c; const u32* tbl; bool force_slow; u64* slow_total; u32 read_base;
+};
+
+void launch_bread(const SketchLaunch& L, hipStream_t s) {
+    const u64 n = L.n_tiles_total + 1;
+    hipLaunchKernelGGL(bread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, L.offsets, L.n_reads, L.n_tiles_total, L.bread);
+}
+
+// one chunk of tiles [tile0, tile0+n): tile kernel, slow count, scan, gather, slow write
+void launch_sketch_chunk(const SketchLaunch& L, u64 tile0, u32 n, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+    TileArgs a;
+    a.bases = L.bases; a.n_bases = L.n_bases; a.offsets = L.offsets; a.n_reads = L.n_reads; a.bread = L.bread;
+    a.tile0 = tile0; a.n_tiles = n; a.slab = L.slab; a.n_cand = L.n_cand; a.n_valid = L.n_valid;
+    a.slow_list = L.slow_list; a.slow_count = L.slow_count; a.err_flag = L.err_flag; a.c = L.c; a.tbl = L.tbl; a.read_base = L.read_base;
+    (void)hipMemsetAsync(L.slow_count, 0, sizeof(u32), s);
+    const bool hpc = L.c.hpc != 0;
+    if (L.force_slow || L.c.l > (u32)FAST_MAX_L) {
+        hipLaunchKernelGGL(all_slow_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, L.n_cand, L.slow_list, L.slow_count);
+    } else {
+        if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        if (hpc) hipLaunchKernelGGL(sketch_tile_kernel<true>, dim3(n), dim3(TILE_THREADS), 0, s, a);
+        else     hipLaunchKernelGGL(sketch_tile_kernel<false>, dim3(n), dim3(TILE_THREADS), 0, s, a);
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+    }
+    if (hpc) hipLaunchKernelGGL((slow_tile_kernel<true, false>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    else     hipLaunchKernelGGL((slow_tile_kernel<false, false>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n, L.n_valid, L.tile_base, L.carry);
+    hipLaunchKernelGGL(gather_kernel, dim3(n), dim3(256), 0, s, n, L.slab, L.n_cand, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    if (hpc) hipLaunchKernelGGL((slow_tile_kernel<true, true>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    else     hipLaunchKernelGGL((slow_tile_kernel<false, true>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    hipLaunchKernelGGL(acc_slow_kernel, dim3(1), dim3(1), 0, s, L.slow_count, L.slow_total);
+}
+
+void launch_read_offsets(const u32* mread, u64 m0, u64 m1, u32 slot0, u32 n_reads, u64* off, hipStream_t s) {
+    const u64 n = m1 - m0 + 1;
+    hipLaunchKernelGGL(read_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mread, m0, m1, slot0, n_reads, off);
+}
+
+// Host side: constants of the candidate filter.  Codes: A=0 C=1 T=2 G=3.
+void make_sketch_consts(u32 l, double density, bool hpc, SketchConsts& c) {
+    double v = density * 18446744073709551616.0;              // src/read.rs:183
+    u64 bound = !(v > 0.0) ? 0 : (v >= 18446744073709551616.0 ? ~0ull : (u64)v);
+    c.bound = bound; c.l = l; c.hpc = hpc ? 1 : 0;
+    const u64 h[4] = {NT_SEED_A, NT_SEED_C, NT_SEED_T, NT_SEED_G};
+    const u64 rc[4] = {NT_SEED_T, NT_SEED_G, NT_SEED_A, NT_SEED_C};
+    const u32 ll = l <= (u32)FAST_MAX_L ? l : (u32)FAST_MAX_L;    // constants only used by the fast kernel
+    const u32 bh = (u32)(bound >> 32);
+    c.thrF = bh | ((1u << (ll - 1)) - 1u);
+    c.thrR = bh >> (ll - 1);
+    c.maskR = (u32)((1ull << (33 - ll)) - 1ull);
+    c.bfe_off = 2 * ll + 1;
+    u32 G0 = 0, R0 = 0;
+    for (u32 t = 0; t < ll; ++t) { G0 ^= (u32)(h[0] >> 32) << (ll - 1 - t); R0 ^= (u32)(rc[0] >> 32) >> (ll - 1 - t); }
+    c.G0 = G0; c.R0 = R0;
+    for (u32 o = 0; o < 4; ++o) for (u32 i = 0; i < 4; ++i) {
+        const u32 uFo = (u32)(h[o] >> 32), uFi = (u32)(h[i] >> 32), uRo = (u32)(rc[o] >> 32), uRi = (u32)(rc[i] >> 32);
+        c.tbl[2 * (o * 4 + i)] = (ll < 32 ? (uFo << ll) : 0u) ^ uFi;
+        c.tbl[2 * (o * 4 + i) + 1] = (uRo >> ll) ^ uRi;
+    }
+}

@@ -1,0 +1,313 @@
+// table.hip — k-min-mer windows, canonicalisation and the GPU-resident counting table (gfx950).
+//
+// Replaces the window loop of process_read_aux (rust-mdbg src/main.rs:756-781), KmerVec::normalize
+// (src/kmer_vec.rs:34-39), add_kminmer's counting upsert on DashMap (src/main.rs:632-691, non-Bloom
+// branch) and the abundance filter (src/main.rs:922-929).
+//
+// Table: open addressing, linear probing, 32-byte slots.  A slot is claimed with ONE 64-bit CAS on
+//   word = fingerprint(30) | src(1) | rev(1) | rep(32)
+// where `rep` points at a representative occurrence of the key (an index into the resident minimizer
+// array, or into the routed-record arena when src=1) — the k*8-byte key itself is never copied.  A
+// fingerprint hit is confirmed by comparing the full canonical key with the representative's, so the
+// table is exact.  Per node the table keeps the count and the A smallest occurrence ordinals
+// (ordinal = read ordinal << 26 | window index): the smallest gives DbgEntry.index (order of first
+// sighting), the A-th gives the sighting whose seqlen/shift the reference stores.
+#include "mdbg_dev.h"
+
+struct __attribute__((aligned(32))) Slot {
+    u64 word;      // ~0 = empty
+    u64 m1;        // smallest ordinal
+    u64 m2;        // second smallest (A >= 2)
+    u32 count;
+    u32 pad;
+};
+constexpr u64 EMPTY = ~0ull;
+constexpr u64 HMUL = 0x9E3779B97F4A7C15ull;
+
+struct KeySrc {                   // where representative keys live
+    const u64* mh;                // resident minimizer hashes (src = 0): key = mh[rep .. rep+k), orientation in the slot word
+    const u64* arena;             // routed records (src = 1): key = arena[rep*(k+1) .. +k), already canonical
+    u32 k;
+};
+
+__device__ inline u64 load_relaxed(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// canonical element j of the key a slot word stands for
+__device__ inline u64 rep_elem(const KeySrc& ks, u64 word, u32 j) {
+    const u32 rep = (u32)word;
+    if (word & (1ull << 33)) return ks.arena[(u64)rep * (ks.k + 1) + j];
+    return (word & (1ull << 32)) ? ks.mh[(u64)rep + ks.k - 1 - j] : ks.mh[(u64)rep + j];
+}
+
+// KmerVec::normalize (src/kmer_vec.rs:34-39): true = the reversed vector is the canonical one (ties included)
+__device__ inline bool window_reversed(const u64* __restrict__ w, u32 k) {
+    for (u32 j = 0; j < k / 2 + 1 && j < k; ++j) {
+        const u64 a = w[j], b = w[k - 1 - j];
+        if (a < b) return false;
+        if (a > b) return true;
+    }
+    return true;
+}
+__device__ inline u64 key_hash_window(const u64* __restrict__ w, u32 k, bool rev) {
+    u64 h = 0x243F6A8885A308D3ull;
+    for (u32 j = 0; j < k; ++j) { const u64 x = rev ? w[k - 1 - j] : w[j]; h = (h ^ x) * HMUL; h ^= h >> 29; }
+    return fmix64(h);
+}
+__device__ inline u64 key_hash_canon(const u64* __restrict__ key, u32 k) {
+    u64 h = 0x243F6A8885A308D3ull;
+    for (u32 j = 0; j < k; ++j) { h = (h ^ key[j]) * HMUL; h ^= h >> 29; }
+    return fmix64(h);
+}
+
+struct TableArgs {
+    Slot* tab; u64 mask;          // capacity - 1 (power of two)
+    u64* mx;                      // [capacity][A-2] further minima when A > 2, else null
+    u32 A;
+    u64* n_distinct;              // device counter
+    KeySrc ks;
+};
+
+// insert ordinal x into the slot's A smallest
+__device__ inline void push_ordinal(const TableArgs& T, u64 s, u64 x) {
+    Slot* e = T.tab + s;
+    const u32 A = T.A;
+    // cheap reject: x larger than the current A-th smallest (values only ever decrease)
+    const u64* last = A == 1 ? &e->m1 : A == 2 ? &e->m2 : &T.mx[s * (A - 2) + (A - 3)];
+    if (x > load_relaxed(last)) return;
+    u64 carry = x;
+    for (u32 lvl = 0; lvl < A && carry != EMPTY; ++lvl) {
+        u64* m = lvl == 0 ? &e->m1 : lvl == 1 ? &e->m2 : &T.mx[s * (A - 2) + (lvl - 2)];
+        const u64 old = atomicMin((unsigned long long*)m, (unsigned long long)carry);
+        if (old > carry) carry = old;          // I displaced `old`; it moves one level down
+    }
+}
+
+// find-or-claim the slot of a key given by an accessor mine(j) = canonical element j
+template <class KeyFn>
+__device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyFn mine) {
+    const u64 fp = (h >> 34) & 0x3FFFFFFFull;
+    const u64 myword = (fp << 34) | myword_lo;
+    u64 s = h & T.mask;
+    for (;;) {
+        u64 w = load_relaxed(&T.tab[s].word);
+        if (w == EMPTY) {
+            const u64 old = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)myword);
+            if (old == EMPTY) { atomicAdd((unsigned long long*)T.n_distinct, 1ull); return s; }
+            w = old;
+        }
+        if ((w >> 34) == fp) {
+            bool eq = true;
+            for (u32 j = 0; j < T.ks.k; ++j) if (rep_elem(T.ks, w, j) != mine(j)) { eq = false; break; }
+            if (eq) return s;
+        }
+        s = (s + 1) & T.mask;
+    }
+}
+
+// one thread per minimizer index i in [i0, i1): if a window of k starts at i inside its read, upsert it.
+// src/main.rs:756 — only reads with MORE than k minimizers contribute.
+__global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
+                                                             const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
+                                                             u64* __restrict__ n_windows, u32* __restrict__ cap_err) {
+    const u64 i = i0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= i1) return;
+    const u32 k = T.ks.k;
+    const u32 slot = mread[i];
+    const u64 rs = roff[slot], re = roff[slot + 1];
+    if (re - rs <= k || i + k > re) return;
+    const u64 win = i - rs;
+    if (win > WIN_MASK) { *cap_err = 1; return; }
+    const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
+    const u64* w = mh + i;
+    const bool rev = window_reversed(w, k);
+    const u64 h = key_hash_window(w, k, rev);
+    const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u32 j) { return rev ? w[k - 1 - j] : w[j]; });
+    atomicAdd(&T.tab[s].count, 1u);
+    push_ordinal(T, s, ord);
+    atomicAdd((unsigned long long*)n_windows, 1ull);
+}
+
+// routed records (k canonical u64 + ordinal), already copied into the arena at record index r0..
+__global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0, u64 r1, u64* __restrict__ n_windows) {
+    const u64 r = r0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r1) return;
+    const u32 k = T.ks.k;
+    const u64* key = T.ks.arena + r * (k + 1);
+    const u64 h = key_hash_canon(key, k);
+    const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u32 j) { return key[j]; });
+    atomicAdd(&T.tab[s].count, 1u);
+    push_ordinal(T, s, key[k]);
+    atomicAdd((unsigned long long*)n_windows, 1ull);
+}
+
+__global__ void clear_table_kernel(Slot* __restrict__ tab, u64 cap, u64* __restrict__ mx, u64 n_mx) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) {
+        uint4* p = (uint4*)(tab + i);
+        p[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);     // word, m1
+        p[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);                         // m2, count, pad
+    }
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_mx; i += stride) mx[i] = EMPTY;
+}
+
+// grow: move every occupied slot of the old table into the new one (keys are unique: claim the first empty slot)
+__global__ void rehash_kernel(const Slot* __restrict__ old, u64 old_cap, const u64* __restrict__ old_mx, TableArgs T) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= old_cap) return;
+    const Slot e = old[i];
+    if (e.word == EMPTY) return;
+    const u32 k = T.ks.k;
+    u64 h = 0x243F6A8885A308D3ull;
+    for (u32 j = 0; j < k; ++j) { h = (h ^ rep_elem(T.ks, e.word, j)) * HMUL; h ^= h >> 29; }
+    h = fmix64(h);
+    u64 s = h & T.mask;
+    for (;;) {
+        const u64 oldw = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)e.word);
+        if (oldw == EMPTY) break;
+        s = (s + 1) & T.mask;
+    }
+    T.tab[s].m1 = e.m1; T.tab[s].m2 = e.m2; T.tab[s].count = e.count;
+    for (u32 j = 0; j + 2 < T.A; ++j) T.mx[s * (T.A - 2) + j] = old_mx[i * (T.A - 2) + j];
+}
+
+// ---- finalize --------------------------------------------------------------------------------------
+struct BatchTab {                 // batches sorted by first_ordinal (device copy)
+    const u64* first_ordinal; const u32* n_reads; const u32* slot0; const u64* rank_base; u32 n;
+};
+struct FinArgs {
+    const Slot* tab; u64 cap; const u64* mx; u32 A; u32 k; u32 l;
+    const u64* mh; const u32* mpos; const u64* roff;
+    BatchTab bt;
+    u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
+    const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
+    u64* counters;                           // [0] n_solid, [1] n_wrapped, [2] n_distinct (recount)
+    // outputs (device), node order = rank of first sighting among solid nodes
+    u64* o_keys; u32* o_index; u16* o_abund; u32* o_seqlen; u16* o_shift; u64* o_shift_full;
+    u64* o_src_read; u64* o_src_start; u64* o_src_end; u8* o_rev;
+};
+
+// ordinal -> (minimizer array index i, dense ordered index D)
+__device__ inline void decode_ordinal(const FinArgs& F, u64 ord, u64& i, u64& D) {
+    const u64 ro = ord >> WIN_BITS, win = ord & WIN_MASK;
+    u32 lo = 0, hi = F.bt.n - 1;
+    while (lo < hi) { const u32 mid = lo + ((hi - lo + 1) >> 1); if (F.bt.first_ordinal[mid] <= ro) lo = mid; else hi = mid - 1; }
+    const u32 s0 = F.bt.slot0[lo];
+    const u32 slot = s0 + (u32)(ro - F.bt.first_ordinal[lo]);
+    i = F.roff[slot] + win;
+    D = F.bt.rank_base[lo] + (i - F.roff[s0]);
+}
+__device__ inline bool slot_solid(const FinArgs& F, const Slot& e) { return F.A == 1 || (u16)e.count >= (u16)F.A; }   // src/main.rs:922-929
+
+__global__ void fin_mark_kernel(FinArgs F) {
+    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= F.cap) return;
+    const Slot e = F.tab[s];
+    if (e.word == EMPTY) return;
+    u64 i, D; decode_ordinal(F, e.m1, i, D);
+    atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
+    atomicAdd((unsigned long long*)&F.counters[2], 1ull);
+    if (slot_solid(F, e)) {
+        atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
+        atomicAdd((unsigned long long*)&F.counters[0], 1ull);
+    }
+    if (e.count >= 65536u) atomicAdd((unsigned long long*)&F.counters[1], 1ull);
+}
+
+__global__ void fin_emit_kernel(FinArgs F) {
+    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= F.cap) return;
+    const Slot e = F.tab[s];
+    if (e.word == EMPTY || !slot_solid(F, e)) return;
+    const u32 k = F.k;
+    u64 i1, D; decode_ordinal(F, e.m1, i1, D);
+    const u64 below = (1ull << (D & 63)) - 1;
+    const u64 n = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);            // output row
+    F.o_index[n] = F.pre_first[D >> 6] + __popcll(F.bm_first[D >> 6] & below);           // NODE_INDEX order (main.rs:661)
+    F.o_abund[n] = (u16)e.count;
+    // the A-th sighting (main.rs:680-684): seqlen, shift and the sequence's origin
+    const u64 oa = F.A == 1 ? e.m1 : F.A == 2 ? e.m2 : F.mx[s * (F.A - 2) + (F.A - 3)];
+    u64 i, Da; decode_ordinal(F, oa, i, Da);
+    const u64* w = F.mh + i; const u32* p = F.mpos + i;
+    const bool rev = window_reversed(w, k);
+    for (u32 j = 0; j < k; ++j) F.o_keys[n * k + j] = rev ? w[k - 1 - j] : w[j];
+    const u64 first = p[1] - p[0], last = p[k - 1] - p[k - 2];                             // main.rs:769-776
+    const u64 s0 = rev ? last : first, s1 = rev ? first : last;
+    F.o_seqlen[n] = (u32)((u64)p[k - 1] + 1 - p[0] + 1);                                   // main.rs:778 (read_offsets.2)
+    F.o_shift[2 * n] = (u16)s0; F.o_shift[2 * n + 1] = (u16)s1;                            // main.rs:675
+    F.o_shift_full[2 * n] = s0; F.o_shift_full[2 * n + 1] = s1;
+    F.o_src_read[n] = oa >> WIN_BITS; F.o_src_start[n] = p[0]; F.o_src_end[n] = (u64)p[k - 1] + F.l;
+    F.o_rev[n] = rev ? 1 : 0;
+}
+
+// exclusive prefix of popcounts over 64-bit words: pre[w] = sum_{v<w} popc(bm[v]); three kernels
+__global__ __launch_bounds__(1024) void popc_block_kernel(const u64* __restrict__ bm, u64 n_words, u32* __restrict__ block_sum) {
+    __shared__ u32 ws[16];
+    const u64 w = (u64)blockIdx.x * 1024 + threadIdx.x;
+    u32 v = w < n_words ? __popcll(bm[w]) : 0;
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < 16; ++i) t += ws[i]; block_sum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void popc_scan_blocks_kernel(u32* __restrict__ block_sum, u32 n_blocks) {
+    __shared__ u32 ws[16]; __shared__ u32 run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) run = 0;
+    __syncthreads();
+    for (u32 i0 = 0; i0 < n_blocks; i0 += 1024) {
+        const u32 i = i0 + tid;
+        const u32 v = i < n_blocks ? block_sum[i] : 0;
+        const u32 inc = wave_incl_scan(v);
+        if (lane == 63) ws[wv] = inc;
+        __syncthreads();
+        u32 b = run, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wv) b += ws[q]; tot += ws[q]; }
+        if (i < n_blocks) block_sum[i] = b + inc - v;
+        __syncthreads();
+        if (tid == 0) run += tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void popc_prefix_kernel(const u64* __restrict__ bm, u64 n_words, const u32* __restrict__ block_base, u32* __restrict__ pre) {
+    __shared__ u32 ws[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 w = (u64)blockIdx.x * 1024 + tid;
+    const u32 v = w < n_words ? __popcll(bm[w]) : 0;
+    const u32 inc = wave_incl_scan(v);
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    u32 b = block_base[blockIdx.x];
+    for (int q = 0; q < wv; ++q) b += ws[q];
+    if (w < n_words) pre[w] = b + inc - v;
+}
+
+// ---- host launchers -------------------------------------------------------------------------------
+void launch_clear_table(Slot* tab, u64 cap, u64* mx, u64 n_mx, hipStream_t s) {
+    hipLaunchKernelGGL(clear_table_kernel, dim3(2048), dim3(256), 0, s, tab, cap, mx, n_mx);
+}
+void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 slot0,
+                           u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s) {
+    if (i1 <= i0) return;
+    hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, i0, i1, slot0,
+                       first_ordinal, n_windows, cap_err);
+}
+void launch_insert_records(const TableArgs& T, u64 r0, u64 r1, u64* n_windows, hipStream_t s) {
+    if (r1 <= r0) return;
+    hipLaunchKernelGGL(insert_records_kernel, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, T, r0, r1, n_windows);
+}
+void launch_rehash(const Slot* old, u64 old_cap, const u64* old_mx, const TableArgs& T, hipStream_t s) {
+    hipLaunchKernelGGL(rehash_kernel, dim3((unsigned)((old_cap + 255) / 256)), dim3(256), 0, s, old, old_cap, old_mx, T);
+}
+void launch_popc_prefix(const u64* bm, u64 n_words, u32* block_tmp, u32* pre, hipStream_t s) {
+    if (!n_words) return;
+    const u32 nb = (u32)((n_words + 1023) / 1024);
+    hipLaunchKernelGGL(popc_block_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp);
+    hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_tmp, nb);
+    hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp, pre);
+}
+void launch_fin_mark(const FinArgs& F, hipStream_t s) {
+    hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 255) / 256)), dim3(256), 0, s, F);
+}
+void launch_fin_emit(const FinArgs& F, hipStream_t s) {
+    hipLaunchKernelGGL(fin_emit_kernel, dim3((unsigned)((F.cap + 255) / 256)), dim3(256), 0, s, F);
+}

@@ -1,0 +1,330 @@
+"""GPU parity: libmdbg_hip.so (through its C ABI) against the CPU oracle, bit-exact.
+
+Every test here needs a real MI355X (`-m gpu`).  Inputs are seeded; sizes are chosen so the oracle finishes in
+seconds.  Edge cases follow SURVEY.md §8a-Q: empty / short / ragged reads, N, bad bytes, long homopolymers,
+reads straddling tile boundaries, strict `> k`, palindromes, batch splitting and ordering, multi-k.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mdbg():
+    import rust_mdbg_amd as R
+    return R
+
+
+def rand_reads(seed, n, lo, hi, alphabet=b"ACGT", hp=0.0):
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        ln = rnd.randint(lo, hi)
+        s = bytearray()
+        while len(s) < ln:
+            c = rnd.choice(alphabet)
+            run = 1
+            if hp and rnd.random() < hp:
+                run = rnd.randint(2, 40)
+            s.extend([c] * run)
+        out.append(bytes(s[:ln]))
+    return out
+
+
+def oracle_graph(reads, k, l, d, A, hpc=False, splits=None):
+    g = O.Graph(k, l, d, A, already_hpc=hpc)
+    b, o = O.concat_reads(reads)
+    assert g.ingest(b, o) == 0
+    return g.finalize(with_edges=False)
+
+
+def assert_sketch_equal(got, exp):
+    assert np.array_equal(got["off"], exp["off"])
+    assert np.array_equal(got["hashes"], exp["hashes"])
+    assert np.array_equal(got["pos"], exp["pos"])
+
+
+NODE_FIELDS = ("keys", "index", "abundance", "seqlen", "shift", "shift_full", "src_read", "src_start", "src_end", "reversed")
+
+
+def assert_nodes_equal(got, exp):
+    assert got["n_nodes_before"] == exp["n_nodes_before"]
+    assert got["n_nodes"] == exp["n_nodes"]
+    for f in NODE_FIELDS:
+        assert np.array_equal(got[f], exp[f]), f
+
+
+def run_gpu(reads, k, l, d, A, hpc=False, flags=0, batches=None, hint=0):
+    R = _mdbg()
+    with R.Mdbg(k, l, d, A, reads_already_hpc=hpc, flags=flags, table_capacity_hint=hint) as m:
+        if batches is None:
+            m.ingest_reads(reads, 0)
+        else:
+            for (lo, hi) in batches:
+                m.ingest_reads(reads[lo:hi], lo)
+        return m.finalize(), m.stats()
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_example_cfg1(example_reads):
+    """BASELINE.json configs[0]: example/reads-0.00.fa.gz, k=7 l=10 d=0.0008 minabund=2"""
+    gold = json.load(open(os.path.join(GOLDEN, "example_cfg1.json")))
+    z = np.load(os.path.join(GOLDEN, "example_cfg1_nodes.npz"))
+    c = gold["config"]
+    R = _mdbg()
+    b, o = O.concat_reads(example_reads)
+    with R.Mdbg(c["k"], c["l"], c["density"], c["minabund"]) as m:
+        sk = m.sketch(b, o)
+        assert len(sk["hashes"]) == gold["n_minimizers"]
+        assert_sketch_equal(sk, dict(hashes=z["hashes"], pos=z["pos"], off=z["off"]))
+        m.ingest(b, o, 0)
+        r = m.finalize()
+        st = m.stats()
+    assert st["n_windows"] == gold["n_windows"] and st["n_minimizers"] == gold["n_minimizers"]
+    assert r["n_nodes"] == gold["n_nodes"] and r["n_nodes_before"] == gold["n_nodes_before"]
+    for f in ("keys", "index", "abundance", "seqlen", "shift", "shift_full", "src_read", "src_start", "src_end", "reversed"):
+        assert np.array_equal(r[f], z[f]), f
+    assert st["n_slow_tiles"] == 0
+
+
+@pytest.mark.parametrize("l,d", [(10, 0.0008), (12, 0.003), (14, 0.003), (12, 0.002), (5, 0.01), (2, 0.02), (13, 0.02)])
+@pytest.mark.parametrize("hpc", [False, True])
+def test_sketch_random_reads(l, d, hpc):
+    reads = rand_reads(100 + l, 40, 0, 60000, hp=0.05)
+    reads += [b"", b"A", b"ACGT" * 2, b"", b"C" * 500, rand_reads(5, 1, 200000, 200000)[0], b""]
+    b, o = O.concat_reads(reads)
+    exp = O.sketch(b, o, l, d, hpc)
+    assert exp["err"] == 0
+    R = _mdbg()
+    with R.Mdbg(5, l, d, 2, reads_already_hpc=hpc) as m:
+        assert_sketch_equal(m.sketch(b, o), exp)
+    with R.Mdbg(5, l, d, 2, reads_already_hpc=hpc, flags=1) as m:      # generic exact kernel on every tile
+        assert_sketch_equal(m.sketch(b, o), exp)
+
+
+@pytest.mark.parametrize("l", [15, 20, 31, 32])
+def test_sketch_long_l_takes_generic_path(l):
+    reads = rand_reads(l, 10, 100, 30000)
+    b, o = O.concat_reads(reads)
+    exp = O.sketch(b, o, l, 0.01)
+    R = _mdbg()
+    with R.Mdbg(5, l, 0.01, 2) as m:
+        assert_sketch_equal(m.sketch(b, o), exp)
+
+
+def test_sketch_dense_density_overflows_to_generic():
+    """default density of the reference CLI is 0.10: far more candidates than a slab holds"""
+    reads = rand_reads(9, 6, 50000, 90000)
+    b, o = O.concat_reads(reads)
+    for d in (0.1, 0.5, 1.0):
+        exp = O.sketch(b, o, 12, d)
+        R = _mdbg()
+        with R.Mdbg(10, 12, d, 2) as m:
+            assert_sketch_equal(m.sketch(b, o), exp)
+
+
+def test_sketch_low_complexity_and_long_homopolymers():
+    rnd = random.Random(4)
+    core = rand_reads(1, 1, 3000, 3000)[0]
+    reads = [
+        b"AC" * 40000,                                                   # every l-mer has one of two hashes
+        core + b"A" * 100 + core,                                        # homopolymer shorter than the halo
+        core + b"T" * 5000 + core[:700] + b"G" * 70000 + core,           # homopolymers longer than a tile
+        b"G" * 300000 + core,                                            # read starts with a 300 kb run
+        (b"ACGTTGCA" * 3 + b"C" * 200) * 300,
+        bytes(rnd.choice(b"AC") for _ in range(100000)),
+    ]
+    b, o = O.concat_reads(reads)
+    for l, d in ((12, 0.003), (10, 0.05), (14, 0.3)):
+        exp = O.sketch(b, o, l, d)
+        R = _mdbg()
+        with R.Mdbg(5, l, d, 2) as m:
+            assert_sketch_equal(m.sketch(b, o), exp)
+
+
+def test_sketch_with_N():
+    rnd = random.Random(8)
+    base = rand_reads(2, 8, 20000, 90000)
+    reads = []
+    for i, r in enumerate(base):
+        r = bytearray(r)
+        for _ in range(i):                                               # read 0 stays clean
+            p = rnd.randrange(len(r))
+            r[p:p + rnd.choice([1, 1, 2, 30])] = b"N" * rnd.choice([1, 1, 2, 30])
+        reads.append(bytes(r))
+    reads += [b"N" * 1000, b"ACGTN" * 5000, b"N" + base[0][:5000] + b"N",
+              base[1][:3000] + b"N" + b"A" * 400 + base[2][:3000],      # N then a homopolymer longer than the halo
+              base[1][:70000] + b"N" * 200000 + base[2][:70000]]        # N gap spanning whole tiles
+    b, o = O.concat_reads(reads)
+    for l, d in ((12, 0.003), (10, 0.02)):
+        exp = O.sketch(b, o, l, d)
+        assert exp["err"] == 0
+        R = _mdbg()
+        with R.Mdbg(5, l, d, 2) as m:
+            assert_sketch_equal(m.sketch(b, o), exp)
+
+
+def test_alphabet_error_rule():
+    """reference: nthash panics iff a read with HPC length >= l holds a byte outside ACGTN"""
+    R = _mdbg()
+    good = rand_reads(3, 3, 5000, 6000)
+    for bad, is_err in ((b"ACGTacgtACGTACGTAC", True), (b"AAAAAAAAAAAAAAAAAAAAx", False), (b"xxxxxxxxxxxxxxxx", True),
+                        (good[0][:2000] + b"R" + good[0][2000:], True), (b"ACGTx", False)):
+        reads = [good[1], bad, good[2]]
+        b, o = O.concat_reads(reads)
+        exp = O.sketch(b, o, 12, 0.01)
+        assert (exp["err"] != 0) == is_err
+        with R.Mdbg(5, 12, 0.01, 2) as m:
+            if is_err:
+                with pytest.raises(R.MdbgError) as ei:
+                    m.sketch(b, o)
+                assert ei.value.code == -2
+                # sketch_only does not poison the context; ingest does
+                with pytest.raises(R.MdbgError):
+                    m.ingest(b, o, 0)
+                with pytest.raises(R.MdbgError) as e2:
+                    m.ingest_reads(good, 10)
+                assert e2.value.code == -6
+            else:
+                assert_sketch_equal(m.sketch(b, o), exp)
+
+
+def test_many_tiny_reads_and_tile_straddling():
+    rnd = random.Random(11)
+    reads = []
+    for _ in range(30000):
+        reads.append(bytes(rnd.choice(b"ACGT") for _ in range(rnd.choice([0, 1, 2, 11, 12, 13, 30, 31, 80]))))
+    reads += rand_reads(12, 5, 65530, 65545)                             # ends right at tile boundaries
+    b, o = O.concat_reads(reads)
+    exp = O.sketch(b, o, 12, 0.02)
+    R = _mdbg()
+    with R.Mdbg(3, 12, 0.02, 1) as m:
+        assert_sketch_equal(m.sketch(b, o), exp)
+        m.ingest(b, o)
+        assert_nodes_equal(m.finalize(), oracle_graph(reads, 3, 12, 0.02, 1))
+
+
+@pytest.mark.parametrize("k,l,d,A", [(7, 10, 0.0008, 2), (21, 12, 0.003, 2), (35, 12, 0.002, 2), (5, 12, 0.01, 1), (3, 8, 0.02, 3),
+                                     (4, 12, 0.01, 4), (10, 12, 0.003, 8), (2, 12, 0.003, 2)])
+def test_graph_synthetic_reads(k, l, d, A):
+    """HiFi-shaped reads (0.1 % errors, both strands) over a small genome: 30-50x coverage"""
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(k * 100 + l, 400000, 900, mean_len=15000, sd_len=1500, min_len=8000, max_len=25000, err_ppm=1000)
+    exp = oracle_graph(reads, k, l, d, A)
+    got, st = run_gpu(reads, k, l, d, A)
+    assert st["n_windows"] == exp["n_windows"] and st["n_minimizers"] == exp["n_minimizers"]
+    assert_nodes_equal(got, exp)
+    assert exp["n_nodes"] > 100
+
+
+def test_graph_skiphpc_and_generic_path_agree():
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(77, 200000, 300, mean_len=12000, sd_len=1500, min_len=3000, max_len=20000, err_ppm=2000)
+    exp = oracle_graph(reads, 9, 12, 0.004, 2, hpc=True)
+    got, _ = run_gpu(reads, 9, 12, 0.004, 2, hpc=True)
+    assert_nodes_equal(got, exp)
+    got2, st2 = run_gpu(reads, 9, 12, 0.004, 2, hpc=True, flags=1)
+    assert_nodes_equal(got2, exp)
+    assert st2["n_slow_tiles"] == st2["n_tiles"] > 0
+
+
+def test_batch_split_and_order_invariance():
+    """results depend on first_read_ordinal only, not on batch boundaries or call order"""
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(5, 150000, 400, mean_len=9000, sd_len=2000, min_len=1000, max_len=20000, err_ppm=1500)
+    k, l, d, A = 8, 12, 0.004, 2
+    exp = oracle_graph(reads, k, l, d, A)
+    one, _ = run_gpu(reads, k, l, d, A)
+    assert_nodes_equal(one, exp)
+    split, _ = run_gpu(reads, k, l, d, A, batches=[(0, 1), (1, 130), (130, 131), (131, 400)])
+    assert_nodes_equal(split, exp)
+    shuffled, _ = run_gpu(reads, k, l, d, A, batches=[(300, 400), (0, 50), (120, 300), (50, 120)])
+    assert_nodes_equal(shuffled, exp)
+    # tiny initial table: forces several grow-and-rehash rounds
+    grown, st = run_gpu(reads, k, l, d, A, batches=[(i, i + 40) for i in range(0, 400, 40)])
+    assert_nodes_equal(grown, exp)
+
+
+def test_strict_k_and_palindromes():
+    rnd = random.Random(21)
+    s = bytes(rnd.choice(b"ACGT") for _ in range(6000))
+    l, d = 8, 0.02
+    b, o = O.concat_reads([s])
+    m_exp = len(O.sketch(b, o, l, d)["hashes"])
+    R = _mdbg()
+    for k in (m_exp - 1, m_exp, m_exp + 1):
+        got, st = run_gpu([s], k, l, d, 1)
+        exp = oracle_graph([s], k, l, d, 1)
+        assert st["n_windows"] == exp["n_windows"] == (2 if k == m_exp - 1 else 0)
+        assert_nodes_equal(got, exp)
+    # a read followed by its reverse complement sketches to the mirrored minimizer list: with k=2..3 windows of the
+    # junction are palindromic k-min-mers (window == reversed window): normalize() must report reversed=true
+    rc = O.revcomp(s)
+    n_pal = 0
+    for k in (2, 3, 4):
+        reads = [s + rc, rc + s]
+        exp = oracle_graph(reads, k, l, d, 1)
+        got, _ = run_gpu(reads, k, l, d, 1)
+        assert_nodes_equal(got, exp)
+        pal = [i for i in range(exp["n_nodes"]) if list(exp["keys"][i]) == list(exp["keys"][i][::-1])]
+        assert all(exp["reversed"][i] == 1 for i in pal)
+        n_pal += len(pal)
+    assert n_pal > 0
+
+
+def test_multik_reset_reuses_resident_sketches():
+    """utils/multik: same reads, k = 10, 15, 20 ... — sketches stay resident, the table is cleared and refilled"""
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(31, 200000, 300, mean_len=14000, sd_len=1500, min_len=5000, max_len=20000, err_ppm=1000)
+    l, d, A = 12, 0.003, 2
+    R = _mdbg()
+    with R.Mdbg(10, l, d, A) as m:
+        m.ingest_reads(reads, 0)
+        for k in (10, 15, 20, 25, 10):
+            if k != m.k or k == 10:
+                m.reset(k)
+            got = m.finalize()
+            assert_nodes_equal(got, oracle_graph(reads, k, l, d, A))
+        m.reset(0)                                                        # drop everything
+        assert m.stats()["n_minimizers"] == 0
+        m.ingest_reads(reads[:50], 0)
+        assert_nodes_equal(m.finalize(), oracle_graph(reads[:50], 10, l, d, A))
+
+
+def test_param_validation():
+    R = _mdbg()
+    for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
+               dict(k=5, l=12, density=0.01, min_abundance=0), dict(k=5, l=12, density=0.01, min_abundance=9)):
+        with pytest.raises(R.MdbgError) as e:
+            R.Mdbg(**kw)
+        assert e.value.code == -1
+
+
+def test_device_synth_matches_cpu_regenerator():
+    import ctypes as C
+    from rust_mdbg_amd import synth
+    R = _mdbg()
+    kw = dict(mean_len=6000, sd_len=1500, min_len=500, max_len=12000, err_ppm=3000)
+    with R.Mdbg(5, 12, 0.01, 2) as m:
+        db, do, nb = m.synth_reads_device(seed=9, genome_len=123457, n_reads=64, first_read=1000, **kw)
+        cpu = synth.synth_reads(9, 123457, 64, first_read=1000, **kw)
+        assert nb == sum(map(len, cpu))
+        hb = (C.c_uint8 * nb)()
+        ho = (C.c_uint64 * 65)()
+        hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        assert hip.hipMemcpy(hb, C.c_void_p(db), C.c_size_t(nb), 2) == 0
+        assert hip.hipMemcpy(ho, C.c_void_p(do), C.c_size_t(65 * 8), 2) == 0
+        assert bytes(hb) == b"".join(cpu)
+        assert list(ho) == list(np.concatenate([[0], np.cumsum([len(x) for x in cpu])]))
+        # and the device-resident ingest path equals the host path on the same bytes
+        m.ingest_device(db, do, 64, nb, 0)
+        got = m.finalize()
+    exp = oracle_graph(cpu, 5, 12, 0.01, 2)
+    assert_nodes_equal(got, exp)
