@@ -13,7 +13,6 @@ HIP events on the stream the kernel is launched on; `cpu_baseline` is the CPU or
 timed on a bounded sample of the same reads on this box's host cores.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -41,28 +40,16 @@ def parse():
     return ap.parse_args()
 
 
-def hip():
-    return C.CDLL("/opt/rocm/lib/libamdhip64.so")
-
-
-def d2h(ptr, nbytes):
-    import numpy as np
-    out = np.empty(nbytes, dtype=np.uint8)
-    e = hip().hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2)
-    assert e == 0, "hipMemcpy D2H failed: %d" % e
-    return out
-
-
 def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     """Times the CPU oracle on a bounded prefix of the same reads, one worker per host core."""
     import numpy as np
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    offs = d2h(d_off, (n_reads + 1) * 8).view(np.uint64)
+    offs = m_ctx.to_host(d_off, (n_reads + 1) * 8, np.uint64)
     # calibrate on ~40 Mbases
     r0 = int(np.searchsorted(offs, 40_000_000, side="right"))
     r0 = max(1, min(r0, n_reads))
-    b0 = d2h(d_bases, int(offs[r0]))
+    b0 = m_ctx.to_host(d_bases, int(offs[r0]))
     t = time.perf_counter()
     O.count_threaded(b0, offs[:r0 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
     dt = time.perf_counter() - t
@@ -70,7 +57,7 @@ def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     target = min(float(n_bases), rate * args.cpu_seconds)
     r1 = int(np.searchsorted(offs, target, side="right"))
     r1 = max(r0, min(r1, n_reads))
-    b1 = d2h(d_bases, int(offs[r1]))
+    b1 = m_ctx.to_host(d_bases, int(offs[r1]))
     t = time.perf_counter()
     solid, wins = O.count_threaded(b1, offs[:r1 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
     dt = time.perf_counter() - t

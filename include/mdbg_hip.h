@@ -48,7 +48,8 @@ enum {
 };
 
 #define MDBG_MAX_L 32u         /* l-mers longer than this are rejected (reference: unbounded) */
-#define MDBG_MAX_MINABUND 8u   /* the table tracks the A smallest ordinals per node for A <= 8 */
+#define MDBG_MAX_MINABUND 8u
+#define MDBG_FLAG_FORCE_GENERIC 1u /* every tile takes the generic exact sketch kernel (testing / cross-check) */   /* the table tracks the A smallest ordinals per node for A <= 8 */
 
 typedef struct mdbg_ctx mdbg_ctx;
 
@@ -60,7 +61,7 @@ typedef struct mdbg_params {
     uint32_t min_abundance;     /* 1..MDBG_MAX_MINABUND                                     (--minabund) */
     uint32_t reads_already_hpc; /* nonzero: skip homopolymer compression                    (--skiphpc) */
     int32_t device;             /* HIP device ordinal, -1 = current device */
-    uint32_t flags;             /* reserved, 0 */
+    uint32_t flags;             /* MDBG_FLAG_* */
     uint64_t table_capacity_hint; /* expected number of distinct k-min-mers, 0 = size from the data */
     uint64_t reserved[4];
 } mdbg_params;
@@ -142,6 +143,9 @@ int mdbg_route_pack(mdbg_ctx* ctx, uint32_t world, const uint64_t** d_records, u
 int mdbg_insert_records(mdbg_ctx* ctx, const uint64_t* d_records, uint64_t n_records);
 /* Wait for all device work queued by ctx. */
 int mdbg_sync(mdbg_ctx* ctx);
+/* Plain copies between host memory and device buffers handed out by / given to this library. */
+int mdbg_copy_to_host(mdbg_ctx* ctx, void* dst, const void* d_src, uint64_t nbytes);
+int mdbg_copy_to_device(mdbg_ctx* ctx, void* d_dst, const void* src, uint64_t nbytes);
 
 /* Synthetic HiFi-shaped reads (counter-based, integer-only generator; the same bytes can be regenerated
  * on the CPU, see rust_mdbg_amd/synth.py).  Fills library-owned DEVICE buffers. */

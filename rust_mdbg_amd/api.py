@@ -51,7 +51,7 @@ class SynthParams(C.Structure):
 
 EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
-           "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device"]
+           "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device"]
 
 
 def lib_path():
@@ -89,10 +89,12 @@ def load_library():
     L.mdbg_route_pack.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_insert_records.argtypes = [vp, vp, u64]
     L.mdbg_sync.argtypes = [vp]
+    L.mdbg_copy_to_host.argtypes = [vp, vp, vp, u64]
+    L.mdbg_copy_to_device.argtypes = [vp, vp, vp, u64]
     L.mdbg_synth_reads_device.argtypes = [vp, C.POINTER(SynthParams), u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     for f in ("mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_device", "mdbg_insert_resident", "mdbg_sketch_only",
               "mdbg_finalize", "mdbg_finalize_device", "mdbg_reset", "mdbg_get_stats", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync",
-              "mdbg_synth_reads_device"):
+              "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device"):
         getattr(L, f).restype = C.c_int
     _LIB = L
     return L
@@ -181,6 +183,12 @@ class Mdbg:
         self._chk(self.L.mdbg_reset(self.h, new_k))
         if new_k:
             self.k = new_k
+
+    def to_host(self, d_ptr, nbytes, dtype=np.uint8):
+        """copy nbytes of device memory into a fresh numpy array"""
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._chk(self.L.mdbg_copy_to_host(self.h, out.ctypes.data, d_ptr, out.nbytes))
+        return out
 
     def sync(self):
         self._chk(self.L.mdbg_sync(self.h))

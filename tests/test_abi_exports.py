@@ -1,0 +1,48 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every symbol include/mdbg_hip.h declares
+(no compute calls — there is no GPU here)."""
+import os
+import re
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    h = open(os.path.join(ROOT, "include", "mdbg_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdbg_[a-z_0-9]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rust_mdbg_amd import api
+    L = api.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(api.EXPORTS) == syms
+    assert L.mdbg_abi_version() == 1
+    assert L.mdbg_strerror(0) == b"ok" and b"ACGTN" in L.mdbg_strerror(-2)
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from rust_mdbg_amd import api
+    assert C.sizeof(api.Params) == 4 + 4 + 8 + 4 + 4 + 4 + 4 + 8 + 32
+    assert C.sizeof(api.Stats) == 8 * 8 + 4 * 8 + 2 * 8 + 5 * 8
+    assert C.sizeof(api.SynthParams) == 3 * 8 + 6 * 4
+    assert api.Nodes.keys.offset == 16 and api.Nodes.n_distinct.offset == 16 + 10 * 8
+
+
+def test_create_without_gpu_fails_cleanly():
+    """no silent CPU fallback: without a device mdbg_create reports MDBG_E_DEVICE"""
+    import torch
+    import pytest
+    import rust_mdbg_amd as R
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(R.MdbgError) as e:
+        R.Mdbg(5, 12, 0.01)
+    assert e.value.code == -4
+    with pytest.raises(R.MdbgError) as e:
+        R.Mdbg(1, 12, 0.01)
+    assert e.value.code == -1

@@ -308,7 +308,6 @@ def test_param_validation():
 
 
 def test_device_synth_matches_cpu_regenerator():
-    import ctypes as C
     from rust_mdbg_amd import synth
     R = _mdbg()
     kw = dict(mean_len=6000, sd_len=1500, min_len=500, max_len=12000, err_ppm=3000)
@@ -316,13 +315,10 @@ def test_device_synth_matches_cpu_regenerator():
         db, do, nb = m.synth_reads_device(seed=9, genome_len=123457, n_reads=64, first_read=1000, **kw)
         cpu = synth.synth_reads(9, 123457, 64, first_read=1000, **kw)
         assert nb == sum(map(len, cpu))
-        hb = (C.c_uint8 * nb)()
-        ho = (C.c_uint64 * 65)()
-        hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
-        assert hip.hipMemcpy(hb, C.c_void_p(db), C.c_size_t(nb), 2) == 0
-        assert hip.hipMemcpy(ho, C.c_void_p(do), C.c_size_t(65 * 8), 2) == 0
-        assert bytes(hb) == b"".join(cpu)
-        assert list(ho) == list(np.concatenate([[0], np.cumsum([len(x) for x in cpu])]))
+        hb = m.to_host(db, nb)
+        ho = m.to_host(do, 65 * 8, np.uint64)
+        assert hb.tobytes() == b"".join(cpu)
+        assert ho.tolist() == np.concatenate([[0], np.cumsum([len(x) for x in cpu])]).tolist()
         # and the device-resident ingest path equals the host path on the same bytes
         m.ingest_device(db, do, 64, nb, 0)
         got = m.finalize()
