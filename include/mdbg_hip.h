@@ -133,14 +133,35 @@ int mdbg_sketch_device(mdbg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_
                        uint64_t n_bases, uint64_t first_read_ordinal);
 /* Window + insert every sketch appended since the last call of this function / reset. */
 int mdbg_insert_resident(mdbg_ctx* ctx);
-/* Key-range routing for the RCCL all-to-all: packs the k-min-mer occurrences not yet
- * inserted into `world` destination buckets (owner = mulhi64(keyhash, world)).  One record is k+1 u64:
- * canonical key then the global ordinal.  *d_records receives a device pointer to the bucketed records
- * (library-owned), counts[world] (HOST) the records per destination. */
+/* ---- multi-GPU: one process per GPU, reads sharded by record, ONE all-to-all of k-min-mer records ----------
+ * (the exchanges themselves are done by the host driver over RCCL, see rust_mdbg_amd/dist.py)
+ *
+ * Key-range routing: packs every k-min-mer occurrence of the sketches not yet inserted into `world` (<= 64)
+ * destination buckets, owner = mulhi64(keyhash, world).  One record is k+1 u64: canonical key, then the global
+ * ordinal (read ordinal << 26 | window index).  *d_records receives a DEVICE pointer to the bucketed records
+ * (library-owned, valid until the next route_pack/reset), counts[world] (HOST) the records per destination. */
 int mdbg_route_pack(mdbg_ctx* ctx, uint32_t world, const uint64_t** d_records, uint64_t* counts);
-/* Insert routed records (device memory, k+1 u64 each) received from peers. The buffer must stay valid
- * until mdbg_finalize/mdbg_reset (node keys are referenced in place). */
+/* Owner side: insert records received from peers (DEVICE memory, k+1 u64 each).  The records are copied into the
+ * context's arena, so the caller's buffer may be released when the call returns.  After the first call the
+ * context is in routed mode: mdbg_finalize is replaced by the four calls below. */
 int mdbg_insert_records(mdbg_ctx* ctx, const uint64_t* d_records, uint64_t n_records);
+/* Owner side: compact view of the table, one entry per distinct k-min-mer (DEVICE pointers, library-owned):
+ * first[n] = smallest ordinal (first sighting), ath[n] = A-th smallest ordinal or ~0 when the node fails the abundance
+ * filter (src/main.rs:922-929), count[n] = occurrences, slot[n] = handle for mdbg_routed_keys. */
+int mdbg_routed_export(mdbg_ctx* ctx, uint64_t* n, const uint64_t** d_first, const uint64_t** d_ath, const uint32_t** d_count,
+                       const uint64_t** d_slot);
+/* Generator side (the rank whose reads the ordinals belong to): for n first-sighting ordinals (DEVICE) with their solid
+ * flags, rank_first[i] = number of queried ordinals smaller than ord[i] (-> DbgEntry.index once the totals of the ranks
+ * holding earlier reads are added), rank_solid[i] = the same among solid ones (-> row of the node in index order).
+ * ALL queries for this rank must be passed in one call.  Outputs are caller-owned DEVICE buffers of n u64. */
+int mdbg_resolve_first(mdbg_ctx* ctx, const uint64_t* d_ord, const uint8_t* d_solid, uint64_t n, uint64_t* d_rank_first,
+                       uint64_t* d_rank_solid, uint64_t* total_first, uint64_t* total_solid);
+/* Generator side: what the reference stores from the sighting with ordinal ord[i] (src/main.rs:675-684,778), 6 u64 per
+ * query into the caller-owned DEVICE buffer d_meta: {seqlen | reversed << 32, shift0, shift1, src_read, src_start,
+ * src_end}; all zero for ord[i] == ~0. */
+int mdbg_resolve_meta(mdbg_ctx* ctx, const uint64_t* d_ord, uint64_t n, uint64_t* d_meta);
+/* Owner side: canonical keys (k u64 each) of the given slot handles into the caller-owned DEVICE buffer d_keys. */
+int mdbg_routed_keys(mdbg_ctx* ctx, const uint64_t* d_slot, uint64_t n, uint64_t* d_keys);
 /* Wait for all device work queued by ctx. */
 int mdbg_sync(mdbg_ctx* ctx);
 /* Plain copies between host memory and device buffers handed out by / given to this library. */

@@ -51,7 +51,8 @@ class SynthParams(C.Structure):
 
 EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
-           "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device"]
+           "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
+           "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys"]
 
 
 def lib_path():
@@ -87,6 +88,10 @@ def load_library():
     L.mdbg_last_error.restype = C.c_char_p
     L.mdbg_last_error.argtypes = [vp]
     L.mdbg_route_pack.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+    L.mdbg_routed_export.argtypes = [vp, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.mdbg_resolve_first.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.mdbg_resolve_meta.argtypes = [vp, vp, u64, vp]
+    L.mdbg_routed_keys.argtypes = [vp, vp, u64, vp]
     L.mdbg_insert_records.argtypes = [vp, vp, u64]
     L.mdbg_sync.argtypes = [vp]
     L.mdbg_copy_to_host.argtypes = [vp, vp, vp, u64]
@@ -94,7 +99,8 @@ def load_library():
     L.mdbg_synth_reads_device.argtypes = [vp, C.POINTER(SynthParams), u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     for f in ("mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_device", "mdbg_insert_resident", "mdbg_sketch_only",
               "mdbg_finalize", "mdbg_finalize_device", "mdbg_reset", "mdbg_get_stats", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync",
-              "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device"):
+              "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device", "mdbg_routed_export", "mdbg_resolve_first",
+              "mdbg_resolve_meta", "mdbg_routed_keys"):
         getattr(L, f).restype = C.c_int
     _LIB = L
     return L
@@ -183,6 +189,35 @@ class Mdbg:
         self._chk(self.L.mdbg_reset(self.h, new_k))
         if new_k:
             self.k = new_k
+
+    # --- multi-GPU stage calls (raw device pointers; see rust_mdbg_amd/dist.py for the driver) ---
+    def route_pack(self, world):
+        """-> (device pointer to bucketed records of k+1 u64, [records per destination])"""
+        ptr = C.c_void_p()
+        counts = (C.c_uint64 * 64)()
+        self._chk(self.L.mdbg_route_pack(self.h, world, C.byref(ptr), counts))
+        return ptr.value or 0, [int(counts[i]) for i in range(world)]
+
+    def insert_records(self, d_records, n):
+        self._chk(self.L.mdbg_insert_records(self.h, d_records, n))
+
+    def routed_export(self):
+        """-> (n, d_first, d_ath, d_count, d_slot) device pointers"""
+        n = C.c_uint64()
+        a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.mdbg_routed_export(self.h, C.byref(n), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return n.value, a.value or 0, b.value or 0, c.value or 0, d.value or 0
+
+    def resolve_first(self, d_ord, d_solid, n, d_rank_first, d_rank_solid):
+        tf, ts = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.mdbg_resolve_first(self.h, d_ord, d_solid, n, d_rank_first, d_rank_solid, C.byref(tf), C.byref(ts)))
+        return tf.value, ts.value
+
+    def resolve_meta(self, d_ord, n, d_meta):
+        self._chk(self.L.mdbg_resolve_meta(self.h, d_ord, n, d_meta))
+
+    def routed_keys(self, d_slot, n, d_keys):
+        self._chk(self.L.mdbg_routed_keys(self.h, d_slot, n, d_keys))
 
     def to_host(self, d_ptr, nbytes, dtype=np.uint8):
         """copy nbytes of device memory into a fresh numpy array"""

@@ -83,6 +83,18 @@ __device__ inline u32 block_excl_scan_256(u32 v, u32* tmp, u32& total) {
     return base + inc - v;
 }
 
+// one atomic per wave instead of one per lane: every ACTIVE lane calls this; adds the number of active lanes
+__device__ inline void wave_agg_inc(u64* ctr) {
+    const u64 act = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    if (lane == __ffsll((unsigned long long)act) - 1) atomicAdd((unsigned long long*)ctr, (unsigned long long)__popcll(act));
+}
+// adds popcount(pred over the wave) with one atomic; must be called by all lanes of the wave (convergent)
+__device__ inline void wave_count_add(bool pred, u64* ctr) {
+    const u64 m = __ballot(pred);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd((unsigned long long*)ctr, (unsigned long long)__popcll(m));
+}
+
 // 64-bit finaliser (murmur3 fmix64)
 __host__ __device__ inline u64 fmix64(u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x;

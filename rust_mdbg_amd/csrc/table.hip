@@ -92,7 +92,7 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
         u64 w = load_relaxed(&T.tab[s].word);
         if (w == EMPTY) {
             const u64 old = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)myword);
-            if (old == EMPTY) { atomicAdd((unsigned long long*)T.n_distinct, 1ull); return s; }
+            if (old == EMPTY) { wave_agg_inc(T.n_distinct); return s; }
             w = old;
         }
         if ((w >> 34) == fp) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u32 j) { return rev ? w[k - 1 - j] : w[j]; });
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
-    atomicAdd((unsigned long long*)n_windows, 1ull);
+    (void)n_windows;
 }
 
 // routed records (k canonical u64 + ordinal), already copied into the arena at record index r0..
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0
     const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u32 j) { return key[j]; });
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, key[k]);
-    atomicAdd((unsigned long long*)n_windows, 1ull);
+    wave_agg_inc(n_windows);
 }
 
 __global__ void clear_table_kernel(Slot* __restrict__ tab, u64 cap, u64* __restrict__ mx, u64 n_mx) {
@@ -200,17 +200,28 @@ __device__ inline bool slot_solid(const FinArgs& F, const Slot& e) { return F.A 
 
 __global__ void fin_mark_kernel(FinArgs F) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= F.cap) return;
-    const Slot e = F.tab[s];
-    if (e.word == EMPTY) return;
-    u64 i, D; decode_ordinal(F, e.m1, i, D);
-    atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
-    atomicAdd((unsigned long long*)&F.counters[2], 1ull);
-    if (slot_solid(F, e)) {
-        atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
-        atomicAdd((unsigned long long*)&F.counters[0], 1ull);
+    bool occ = false, solid = false, wrapped = false;
+    if (s < F.cap) {
+        const Slot e = F.tab[s];
+        if (e.word != EMPTY) {
+            occ = true; solid = slot_solid(F, e); wrapped = e.count >= 65536u;
+            u64 i, D; decode_ordinal(F, e.m1, i, D);
+            atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
+            if (solid) atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
+        }
     }
-    if (e.count >= 65536u) atomicAdd((unsigned long long*)&F.counters[1], 1ull);
+    wave_count_add(occ, &F.counters[2]);
+    wave_count_add(solid, &F.counters[0]);
+    wave_count_add(wrapped, &F.counters[1]);
+}
+
+// number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
+__global__ void count_windows_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32 k, u64* __restrict__ out) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 w = 0;
+    if (r < n_reads) { const u64 n = roff[slot0 + r + 1] - roff[slot0 + r]; if (n > k) w = n - k + 1; }
+    for (int d = 32; d; d >>= 1) w += __shfl_down(w, d, 64);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)out, (unsigned long long)w);
 }
 
 __global__ void fin_emit_kernel(FinArgs F) {
@@ -304,6 +315,10 @@ void launch_popc_prefix(const u64* bm, u64 n_words, u32* block_tmp, u32* pre, hi
     hipLaunchKernelGGL(popc_block_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp);
     hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_tmp, nb);
     hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp, pre);
+}
+void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* out, hipStream_t s) {
+    if (!n_reads) return;
+    hipLaunchKernelGGL(count_windows_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, roff, slot0, n_reads, k, out);
 }
 void launch_fin_mark(const FinArgs& F, hipStream_t s) {
     hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 255) / 256)), dim3(256), 0, s, F);

@@ -1,0 +1,117 @@
+"""CPU stand-in for GpuEngine (tests only): same stage interface as rust_mdbg_amd.dist.GpuEngine, with the sketch taken
+from the oracle and everything else in plain Python/numpy.  Lets the multi-rank driver logic (routing, ordering,
+cross-rank resolution) run under gloo / threads without a GPU."""
+import hashlib
+
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+WIN_BITS = 26
+
+
+def _i64(x):
+    return np.asarray(x, dtype=np.uint64).view(np.int64)
+
+
+class NumpyEngine:
+    def __init__(self, k, l, density, minabund):
+        self.k, self.l, self.d, self.A = k, l, density, minabund
+        self.device = torch.device("cpu")
+        self.reset()
+
+    def reset(self):
+        self.ranges, self.batches, self.pending = [], [], []
+        self.table = {}          # key tuple -> [count, sorted ordinals]
+        self.keys_list = []
+
+    def sketch_host(self, bases, offsets, first_ordinal):
+        sk = O.sketch(bases, offsets, self.l, self.d)
+        assert sk["err"] == 0
+        b = dict(first=int(first_ordinal), n=len(offsets) - 1, sk=sk)
+        self.batches.append(b)
+        self.pending.append(b)
+        self.ranges.append((int(first_ordinal), len(offsets) - 1))
+
+    def _windows(self, b):
+        sk, k = b["sk"], self.k
+        for r in range(b["n"]):
+            lo, hi = int(sk["off"][r]), int(sk["off"][r + 1])
+            if hi - lo > k:
+                for i in range(hi - lo - k + 1):
+                    w = [int(x) for x in sk["hashes"][lo + i:lo + i + k]]
+                    rev = not (w < w[::-1])
+                    yield tuple(w[::-1] if rev else w), ((b["first"] + r) << WIN_BITS) | i
+
+    def route_pack(self, world):
+        buckets = [[] for _ in range(world)]
+        for b in self.pending:
+            for key, ordn in self._windows(b):
+                h = int.from_bytes(hashlib.blake2b(np.asarray(key, dtype=np.uint64).tobytes(), digest_size=8).digest(), "little")
+                buckets[(h * world) >> 64].append(list(key) + [ordn])
+        self.pending = []
+        counts = [len(x) for x in buckets]
+        rows = [r for bk in buckets for r in bk]
+        arr = _i64(np.asarray(rows, dtype=np.uint64).reshape(len(rows), self.k + 1))
+        return torch.from_numpy(arr.copy()), counts
+
+    def insert_records(self, recs):
+        a = recs.numpy().view(np.uint64)
+        for row in a:
+            key = tuple(int(x) for x in row[:self.k])
+            e = self.table.get(key)
+            if e is None:
+                e = self.table[key] = [0, []]
+                self.keys_list.append(key)
+            e[0] += 1
+            e[1].append(int(row[self.k]))
+
+    def export(self):
+        first, ath, cnt = [], [], []
+        for key in self.keys_list:
+            c, ords = self.table[key]
+            ords = sorted(ords)
+            first.append(ords[0])
+            solid = self.A == 1 or (c & 0xFFFF) >= self.A
+            ath.append(ords[self.A - 1] if solid else (1 << 64) - 1)
+            cnt.append(c)
+        n = len(first)
+        return (torch.from_numpy(_i64(first).copy()), torch.from_numpy(_i64(ath).copy()), torch.tensor(cnt, dtype=torch.int64),
+                torch.arange(n, dtype=torch.int64))
+
+    def resolve_first(self, ords, solid):
+        o = ords.numpy().view(np.uint64)
+        s = solid.numpy().astype(bool)
+        order = np.argsort(o, kind="stable")
+        rf = np.empty(len(o), dtype=np.int64)
+        rf[order] = np.arange(len(o))
+        rs = np.empty(len(o), dtype=np.int64)
+        rs[order] = np.cumsum(s[order]) - s[order]
+        return torch.from_numpy(rf), torch.from_numpy(rs), int(len(o)), int(s.sum())
+
+    def _locate(self, ordn):
+        ro, win = ordn >> WIN_BITS, ordn & ((1 << WIN_BITS) - 1)
+        for b in self.batches:
+            if b["first"] <= ro < b["first"] + b["n"]:
+                return b["sk"], int(b["sk"]["off"][ro - b["first"]]) + win
+        raise KeyError(ordn)
+
+    def resolve_meta(self, ords):
+        out = np.zeros((len(ords), 6), dtype=np.uint64)
+        k, l = self.k, self.l
+        for q, ordn in enumerate(ords.numpy().view(np.uint64).tolist()):
+            if ordn == (1 << 64) - 1:
+                continue
+            sk, i = self._locate(ordn)
+            w = [int(x) for x in sk["hashes"][i:i + k]]
+            p = [int(x) for x in sk["pos"][i:i + k]]
+            rev = not (w < w[::-1])
+            first, last = p[1] - p[0], p[k - 1] - p[k - 2]
+            out[q] = [((p[k - 1] + 1 - p[0] + 1) & 0xFFFFFFFF) | (int(rev) << 32), last if rev else first, first if rev else last,
+                      ordn >> WIN_BITS, p[0], p[k - 1] + l]
+        return torch.from_numpy(out.view(np.int64).copy())
+
+    def keys(self, slots):
+        arr = np.asarray([self.keys_list[int(s)] for s in slots.tolist()], dtype=np.uint64).reshape(len(slots), self.k)
+        return torch.from_numpy(arr.view(np.int64).copy())

@@ -1,0 +1,103 @@
+"""Multi-rank driver (rust_mdbg_amd/dist.py) on CPU: world_size-2 gloo processes and in-process thread ranks, with the
+numpy stand-in engine.  The merged node table must equal the sequential reference semantics (the oracle)."""
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, TESTS
+from oracle import oracle as O
+from rust_mdbg_amd import dist as D, synth
+
+K, L, DENS, A = 6, 12, 0.004, 2
+
+
+def workload():
+    return synth.synth_reads(3, 120000, 160, mean_len=9000, sd_len=2000, min_len=2000, max_len=15000, err_ppm=1500)
+
+
+def to_np(part):
+    return {f: (v.cpu().numpy().view(np.uint64) if hasattr(v, "cpu") else v) for f, v in part.items()}
+
+
+def check_against_oracle(parts, reads, k=K, l=L, d=DENS, a=A):
+    tab = D.gather_node_table([to_np(p) for p in parts])
+    g = O.Graph(k, l, d, a)
+    b, o = O.concat_reads(reads)
+    g.ingest(b, o)
+    exp = g.finalize(with_edges=False)
+    assert tab["n_nodes"] == exp["n_nodes"] and tab["n_nodes_before"] == exp["n_nodes_before"]
+    assert np.array_equal(tab["row"], np.arange(exp["n_nodes"], dtype=np.uint64))
+    assert np.array_equal(tab["keys"], exp["keys"])
+    for f in ("index", "abundance", "seqlen", "reversed", "src_read", "src_start", "src_end"):
+        assert np.array_equal(tab[f].astype(np.uint64), exp[f].astype(np.uint64)), f
+    assert np.array_equal(tab["shift_full"], exp["shift_full"])
+
+
+def run_rank(rank, world, comm, reads, out, batches_per_rank=2):
+    from engine_numpy import NumpyEngine
+    eng = NumpyEngine(K, L, DENS, A)
+    drv = D.DistributedMdbg(eng, comm, torch)
+    per = len(reads) // world
+    lo, hi = rank * per, (len(reads) if rank == world - 1 else (rank + 1) * per)
+    step = (hi - lo + batches_per_rank - 1) // batches_per_rank
+    for s in range(lo, hi, step):
+        bb, oo = O.concat_reads(reads[s:min(hi, s + step)])
+        drv.ingest_host(bb, oo, s)
+    out[rank] = drv.finalize()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_thread_ranks_numpy_engine(world):
+    reads = workload()
+    tw = D.ThreadWorld(world)
+    out = [None] * world
+    errs = []
+
+    def body(r):
+        try:
+            run_rank(r, world, D.ThreadComm(tw, r, torch), reads, out)
+        except BaseException as e:           # noqa: BLE001
+            errs.append(e)
+            tw.barrier.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    check_against_oracle(out, reads)
+
+
+def _gloo_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = [None] * world
+    run_rank(rank, world, D.TorchDistComm(dist, torch, torch.device("cpu")), workload(), out)
+    np.savez(os.path.join(tmpdir, "part%d.npz" % rank), **{f: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for f, v in out[rank].items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = []
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "part%d.npz" % r))
+        parts.append({f: (z[f].view(np.uint64) if z[f].dtype == np.int64 and z[f].ndim else z[f]) for f in z.files})
+    for p in parts:
+        for f in ("n_nodes", "n_nodes_before", "n_local"):
+            p[f] = int(p[f])
+    check_against_oracle(parts, workload())
