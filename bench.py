@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--density", type=float, default=0.002)
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     return ap.parse_args()
 
 
@@ -76,9 +77,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    routed = world > 1 or args.force_dist
+    if routed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import rust_mdbg_amd as R
 
     genome_len = int(args.genome_mb * 1e6) * world            # weak scaling: coverage constant, genome grows with N
@@ -88,13 +92,18 @@ def main():
                                                    min_len=8000, max_len=25000, err_ppm=1000, first_read=rank * reads_per_gpu)
     first_ordinal = rank * reads_per_gpu
 
-    if world > 1:
+    if routed:
         from rust_mdbg_amd import dist as D
-        runner = D.DistributedMdbg(m, dist, torch)
+        dev = torch.device("cuda", local_rank)
+        engine = D.GpuEngine(m, torch, dev)
+        runner = D.DistributedMdbg(engine, D.TorchDistComm(dist, torch, dev), torch)
 
     def step():
-        m.reset(0)
-        if world == 1:
+        if routed:
+            engine.reset()
+        else:
+            m.reset(0)
+        if not routed:
             m.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
             return m.finalize_device().n
         runner.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
@@ -109,7 +118,6 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    m.reset(0)
     t0 = time.perf_counter()
     n_nodes = 0
     for _ in range(args.steps):
@@ -147,7 +155,7 @@ def main():
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "synthetic D. melanogaster 140 Mb @50x per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1% errors",
                           "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
-                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": "reads sharded by record x%d, key-range all-to-all" % world if world > 1 else "single GPU"},
+                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": "reads sharded by record x%d, key-range all-to-all over RCCL" % world if routed else "single GPU"},
                "roofline": roof, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_tile_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),

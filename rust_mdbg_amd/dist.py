@@ -17,19 +17,52 @@ WIN_BITS = 26
 
 # ------------------------------------------------------------------------------------------- communicators
 class TorchDistComm:
-    def __init__(self, dist, torch, device):
-        self.dist, self.torch, self.device = dist, torch, device
+    """torch.distributed communicator (backend "nccl" = RCCL over xGMI on GPUs, "gloo" on CPU).
+
+    Large exchanges are cut into rounds of at most `max_bytes` per (source, destination) message: RCCL 2.26 was
+    observed to deliver only the first ~0.95 GB of a 1.9 GB all_to_all_single message (profiles/r01_notes.md), and
+    bounded rounds also bound the staging memory of the collective."""
+
+    def __init__(self, dist, torch, device, max_bytes=256 << 20):
+        self.dist, self.torch, self.device, self.max_bytes = dist, torch, device, max_bytes
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
     def alltoallv(self, send, counts):
         """send: [n, ...] rows grouped by destination; counts[d] rows go to rank d -> (recv rows, recv counts)"""
         t, dist = self.torch, self.dist
+        counts = [int(c) for c in counts]
         sc = t.tensor(counts, dtype=t.int64, device=self.device)
         rc = t.empty_like(sc)
         dist.all_to_all_single(rc, sc)
         rcl = [int(x) for x in rc.tolist()]
+        send = send.contiguous()
         recv = t.empty((sum(rcl),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.device)
-        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rcl, input_split_sizes=[int(c) for c in counts])
+        row_bytes = max(1, send.element_size() * (send.numel() // max(1, send.shape[0]) if send.shape[0] else 1))
+        max_rows = max(1, self.max_bytes // row_bytes)
+        biggest = t.tensor([max(counts + rcl + [0])], dtype=t.int64, device=self.device)
+        dist.all_reduce(biggest, op=dist.ReduceOp.MAX)
+        rounds = (int(biggest.item()) + max_rows - 1) // max_rows
+        if rounds <= 1:
+            dist.all_to_all_single(recv, send, output_split_sizes=rcl, input_split_sizes=counts)
+            return recv, rcl
+        so, ro = [0], [0]
+        for c in counts:
+            so.append(so[-1] + c)
+        for c in rcl:
+            ro.append(ro[-1] + c)
+        for r in range(rounds):
+            a = r * max_rows
+            ins = [send[so[d] + min(a, counts[d]): so[d] + min(a + max_rows, counts[d])] for d in range(self.world)]
+            outs = [recv[ro[s] + min(a, rcl[s]): ro[s] + min(a + max_rows, rcl[s])] for s in range(self.world)]
+            i_sp, o_sp = [int(x.shape[0]) for x in ins], [int(x.shape[0]) for x in outs]
+            sbuf = t.cat(ins, 0) if self.world > 1 else ins[0]
+            rbuf = t.empty((sum(o_sp),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.device) if self.world > 1 else outs[0]
+            dist.all_to_all_single(rbuf, sbuf, output_split_sizes=o_sp, input_split_sizes=i_sp)
+            if self.world > 1:
+                o = 0
+                for s in range(self.world):
+                    outs[s].copy_(rbuf[o:o + o_sp[s]])
+                    o += o_sp[s]
         return recv, rcl
 
     def allgather_obj(self, obj):
