@@ -83,16 +83,21 @@ __device__ inline u32 block_excl_scan_256(u32 v, u32* tmp, u32& total) {
     return base + inc - v;
 }
 
-// one atomic per wave instead of one per lane: every ACTIVE lane calls this; adds the number of active lanes
+// Sharded counters.  Same-address device atomics serialise at ~12 ns each on MI355X (MI355X_MICROARCH.md "fanin"), so
+// a hot counter is spread over CTR_SHARDS addresses chosen by (block, wave); sum_shards_kernel folds them when the
+// host needs the value.
+constexpr int CTR_SHARDS = 4096;
+__device__ inline u64* ctr_shard(u64* ctr) { return ctr + (((u32)blockIdx.x * 4u + (threadIdx.x >> 6)) * 2654435761u >> 20); }
+// every ACTIVE lane calls this; adds the number of active lanes with one atomic per wave
 __device__ inline void wave_agg_inc(u64* ctr) {
     const u64 act = __ballot(1);
     const int lane = threadIdx.x & 63;
-    if (lane == __ffsll((unsigned long long)act) - 1) atomicAdd((unsigned long long*)ctr, (unsigned long long)__popcll(act));
+    if (lane == __ffsll((unsigned long long)act) - 1) atomicAdd((unsigned long long*)ctr_shard(ctr), (unsigned long long)__popcll(act));
 }
 // adds popcount(pred over the wave) with one atomic; must be called by all lanes of the wave (convergent)
 __device__ inline void wave_count_add(bool pred, u64* ctr) {
     const u64 m = __ballot(pred);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd((unsigned long long*)ctr, (unsigned long long)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd((unsigned long long*)ctr_shard(ctr), (unsigned long long)__popcll(m));
 }
 
 // 64-bit finaliser (murmur3 fmix64)

@@ -47,20 +47,27 @@ __global__ __launch_bounds__(256) void route_kernel(RouteArgs a) {
     }
 }
 
-// compact list of occupied slots: m1, A-th ordinal (~0 when the node fails the abundance filter), count, slot id
-__global__ void export_kernel(const Slot* __restrict__ tab, u64 cap, const u64* __restrict__ mx, u32 A, u64* __restrict__ counter,
-                              u64* __restrict__ o_m1, u64* __restrict__ o_ma, u32* __restrict__ o_count, u64* __restrict__ o_slot) {
+// compact list of occupied slots: m1, A-th ordinal (~0 when the node fails the abundance filter), count, slot id.
+// One allocation atomic per 1024-thread block (same-address atomics serialise).
+__global__ __launch_bounds__(1024) void export_kernel(const Slot* __restrict__ tab, u64 cap, const u64* __restrict__ mx, u32 A, u64* __restrict__ counter,
+                                                      u64* __restrict__ o_m1, u64* __restrict__ o_ma, u32* __restrict__ o_count, u64* __restrict__ o_slot) {
+    __shared__ u32 wcnt[16];
+    __shared__ u64 bbase;
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     bool occ = false; Slot e{};
     if (s < cap) { e = tab[s]; occ = e.word != EMPTY; }
     const u64 m = __ballot(occ);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    u64 base = 0;
-    if (lane == 0) base = atomicAdd((unsigned long long*)counter, (unsigned long long)__popcll(m));
-    base = __shfl(base, 0, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wv] = (u32)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = 0;
+        for (int i = 0; i < 16; ++i) { const u32 c = wcnt[i]; wcnt[i] = tot; tot += c; }
+        bbase = tot ? atomicAdd((unsigned long long*)counter, (unsigned long long)tot) : 0;
+    }
+    __syncthreads();
     if (occ) {
-        const u64 idx = base + __popcll(m & ((1ull << lane) - 1));
+        const u64 idx = bbase + wcnt[wv] + __popcll(m & ((1ull << lane) - 1));
         const bool solid = A == 1 || (u16)e.count >= (u16)A;
         const u64 ma = A == 1 ? e.m1 : A == 2 ? e.m2 : mx[s * (A - 2) + (A - 3)];
         o_m1[idx] = e.m1; o_ma[idx] = solid ? ma : EMPTY; o_count[idx] = e.count; o_slot[idx] = s;
@@ -115,7 +122,7 @@ void launch_route(const RouteArgs& a, bool write, hipStream_t s) {
     else hipLaunchKernelGGL(route_kernel<false>, dim3(nb), dim3(256), 0, s, a);
 }
 void launch_export(const Slot* tab, u64 cap, const u64* mx, u32 A, u64* counter, u64* o_m1, u64* o_ma, u32* o_count, u64* o_slot, hipStream_t s) {
-    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, tab, cap, mx, A, counter, o_m1, o_ma, o_count, o_slot);
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((cap + 1023) / 1024)), dim3(1024), 0, s, tab, cap, mx, A, counter, o_m1, o_ma, o_count, o_slot);
 }
 void launch_resolve_mark(const FinArgs& F, const u64* ord, const u8* solid, u64 n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(resolve_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, F, ord, solid, n);

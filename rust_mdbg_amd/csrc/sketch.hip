@@ -128,7 +128,7 @@ __device__ inline u32 pack16(uint4 v, u32& bad) {
 }
 
 template <bool HPC>
-__global__ __launch_bounds__(TILE_THREADS) void sketch_tile_kernel(TileArgs a) {
+__global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a) {
     __shared__ __attribute__((aligned(16))) u32 lds[LDS_TOTAL];
     u32* const codes = lds;
     u16* const list = (u16*)(lds + LDS_CODES);
@@ -149,13 +149,13 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_tile_kernel(TileArgs a) {
     if (tid == 33) misc[8] = 0;
     __syncthreads();
 
-    // ---- phase 1: ASCII -> 2-bit codes in LDS (coalesced 16-byte loads) ---------------------------
+    // ---- phase 1: ASCII -> 2-bit codes in LDS (coalesced 16-byte loads, 8 in flight per lane) ------
     {
         u32 bad_any = 0;
-        constexpr int NCHUNK = (TILE + HALO) / 16;
-        for (int ci = tid; ci < NCHUNK; ci += TILE_THREADS) {
-            const int j = ci - HALO / 16;
-            const int64_t pos = tile_start + 16 * (int64_t)j;
+        constexpr int NCHUNK = (TILE + HALO) / 16;                 // 4104 = 16 * 256 + 8
+        const bool interior = tile_start >= HALO && tile_start + TILE <= nb;
+        auto load_chunk = [&](int ci) -> uint4 {                   // careful path (first / last tile)
+            const int64_t pos = tile_start + 16 * (int64_t)(ci - HALO / 16);
             uint4 v = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
             if (pos >= 0 && pos + 16 <= nb) v = *(const uint4*)(a.bases + pos);
             else if (pos >= 0 && pos < nb) {
@@ -163,9 +163,20 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_tile_kernel(TileArgs a) {
                 for (int i = 0; i < 16; ++i) tmpb[i] = (pos + i < nb) ? a.bases[pos + i] : (u8)'A';
                 v = *(const uint4*)tmpb;
             }
-            u32 bad = 0;
-            codes[codes_addr(j)] = pack16(v, bad);
-            bad_any |= bad;
+            return v;
+        };
+        const uint4* src = (const uint4*)(a.bases + (tile_start - HALO));      // chunk ci lives at src[ci] (interior tiles)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int ci = tid + TILE_THREADS * (half * 8 + u); v[u] = interior ? src[ci] : load_chunk(ci); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int ci = tid + TILE_THREADS * (half * 8 + u); u32 bad = 0; codes[codes_addr(ci - HALO / 16)] = pack16(v[u], bad); bad_any |= bad; }
+        }
+        if (tid < NCHUNK - 16 * TILE_THREADS) {
+            const int ci = 16 * TILE_THREADS + tid; u32 bad = 0;
+            codes[codes_addr(ci - HALO / 16)] = pack16(interior ? src[ci] : load_chunk(ci), bad); bad_any |= bad;
         }
         if (bad_any) {                       // some byte of my chunks is not one of ACGT
             misc[8] = 1;                     // whole tile takes the generic exact path
@@ -244,6 +255,10 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_tile_kernel(TileArgs a) {
         }
     }
     {
+        // Branch-free form: per 16-base word, first the code history / table addresses of all 16 steps (a short ALU
+        // chain), then the 16 LDS table reads back to back, then the G/R chains.  Lanes whose base is not a run start
+        // compute the same values and discard them with v_cndmask (exec-mask branches would put every ds_read's latency
+        // on the critical path: some lane always pushes, so the branch is never skipped anyway).
         const uint4* segp = (const uint4*)(codes + (tid + 1) * SEG_STRIDE);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -252,8 +267,30 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_tile_kernel(TileArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const u32 w = w4[k];
+                u32 ad[16]; bool kp[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) MDBG_STEP(w, i, true, cb[g * 2 + (k >> 1)], (k & 1) * 16 + i)
+                for (int i = 0; i < 16; ++i) {
+                    const u32 c_ = (w >> (2 * i)) & 3u;
+                    kp[i] = !HPC || c_ != prev;
+                    const u32 c8_ = c_ << 3;
+                    ad[i] = (__builtin_amdgcn_ubfe(hist, bfe_off, 2u) << 5) | c8_;
+                    const u32 hn = (hist << 2) | c8_;
+                    hist = kp[i] ? hn : hist;
+                    prev = c_;
+                }
+                uint2 x[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] = *(const uint2*)((const char*)tbl + ad[i]);
+                u32 cw = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const u32 Gn = (G << 1) ^ x[i].x, Rn = (R >> 1) ^ x[i].y;
+                    G = kp[i] ? Gn : G;
+                    R = kp[i] ? Rn : R;
+                    const bool cand = kp[i] && (Gn <= thrF || (Rn & maskR) <= thrR);
+                    cw |= (cand ? 1u : 0u) << i;
+                }
+                cb[g * 2 + (k >> 1)] |= cw << ((k & 1) * 16);
             }
         }
     }

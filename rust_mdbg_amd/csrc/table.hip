@@ -65,6 +65,7 @@ struct TableArgs {
     u32 A;
     u64* n_distinct;              // device counter
     KeySrc ks;
+    u32 dbg;                      // experiment switches (MDBG_DBG), 0 in production
 };
 
 // insert ordinal x into the slot's A smallest
@@ -97,7 +98,7 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
         }
         if ((w >> 34) == fp) {
             bool eq = true;
-            for (u32 j = 0; j < T.ks.k; ++j) if (rep_elem(T.ks, w, j) != mine(j)) { eq = false; break; }
+            if (!(T.dbg & 4)) for (u32 j = 0; j < T.ks.k; ++j) if (rep_elem(T.ks, w, j) != mine(j)) { eq = false; break; }
             if (eq) return s;
         }
         s = (s + 1) & T.mask;
@@ -121,9 +122,10 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     const u64* w = mh + i;
     const bool rev = window_reversed(w, k);
     const u64 h = key_hash_window(w, k, rev);
+    if (T.dbg & 8) { if (h == 12345) *cap_err = 2; return; }
     const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u32 j) { return rev ? w[k - 1 - j] : w[j]; });
-    atomicAdd(&T.tab[s].count, 1u);
-    push_ordinal(T, s, ord);
+    if (!(T.dbg & 1)) atomicAdd(&T.tab[s].count, 1u);
+    if (!(T.dbg & 2)) push_ordinal(T, s, ord);
     (void)n_windows;
 }
 
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0
     const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u32 j) { return key[j]; });
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, key[k]);
-    wave_agg_inc(n_windows);
+    (void)n_windows;
 }
 
 __global__ void clear_table_kernel(Slot* __restrict__ tab, u64 cap, u64* __restrict__ mx, u64 n_mx) {
@@ -180,7 +182,7 @@ struct FinArgs {
     BatchTab bt;
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
     const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
-    u64* counters;                           // [0] n_solid, [1] n_wrapped, [2] n_distinct (recount)
+    u64* sh_solid; u64* sh_wrapped; u64* sh_distinct;   // sharded counters (CTR_SHARDS u64 each)
     // outputs (device), node order = rank of first sighting among solid nodes
     u64* o_keys; u32* o_index; u16* o_abund; u32* o_seqlen; u16* o_shift; u64* o_shift_full;
     u64* o_src_read; u64* o_src_start; u64* o_src_end; u8* o_rev;
@@ -210,9 +212,9 @@ __global__ void fin_mark_kernel(FinArgs F) {
             if (solid) atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
         }
     }
-    wave_count_add(occ, &F.counters[2]);
-    wave_count_add(solid, &F.counters[0]);
-    wave_count_add(wrapped, &F.counters[1]);
+    wave_count_add(occ, F.sh_distinct);
+    wave_count_add(solid, F.sh_solid);
+    wave_count_add(wrapped, F.sh_wrapped);
 }
 
 // number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
@@ -292,7 +294,22 @@ __global__ __launch_bounds__(1024) void popc_prefix_kernel(const u64* __restrict
     if (w < n_words) pre[w] = b + inc - v;
 }
 
+// out[j] = sum of shard array j (CTR_SHARDS u64 each); one block per array
+__global__ __launch_bounds__(256) void sum_shards_kernel(const u64* __restrict__ shards, u64* __restrict__ out) {
+    __shared__ u64 ws[4];
+    const u64* s = shards + (size_t)blockIdx.x * CTR_SHARDS;
+    u64 v = 0;
+    for (int i = threadIdx.x; i < CTR_SHARDS; i += 256) v += s[i];
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
 // ---- host launchers -------------------------------------------------------------------------------
+void launch_sum_shards(const u64* shards, u32 n_arrays, u64* out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_shards_kernel, dim3(n_arrays), dim3(256), 0, s, shards, out);
+}
 void launch_clear_table(Slot* tab, u64 cap, u64* mx, u64 n_mx, hipStream_t s) {
     hipLaunchKernelGGL(clear_table_kernel, dim3(2048), dim3(256), 0, s, tab, cap, mx, n_mx);
 }
