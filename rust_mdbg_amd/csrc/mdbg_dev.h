@@ -15,7 +15,7 @@ constexpr int SEG = 256;                          // raw bases per lane
 constexpr int TILE = TILE_THREADS * SEG;          // 65536 raw bases per tile
 constexpr int HALO = 128;                         // raw bases staged in front of the tile
 constexpr int SEG_WORDS = SEG / 16;               // 2-bit codes, 16 per dword
-constexpr int SEG_STRIDE = 20;                    // padded dwords per segment in LDS: 20*i mod 64 hits 16 distinct 4-bank groups -> ds_read_b128 conflict-free
+constexpr int MDBG_MAX_L_DEV = 32;                // = MDBG_MAX_L of the C ABI
 constexpr int QCAP = 2048;                        // candidate capacity of a fast tile (slab slots)
 constexpr u32 SLOW_MARK = 0xFFFFFFFFu;            // n_cand value of a tile handed to the generic path
 constexpr int FAST_MAX_L = 14;                    // 32-bit code history: 3 + 2*l <= 31

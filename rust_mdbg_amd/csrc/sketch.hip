@@ -22,6 +22,8 @@ struct TileArgs {
     u32* err_flag;               // set when a byte outside ACGTN is seen
     const u32* tbl;              // device copy of SketchConsts::tbl
     u32 read_base;               // slot index of the batch's first read in the resident store
+    u64* dbg;                    // diagnostic: per-tile phase timestamps [n_tiles][8] (null in production)
+    u32 dbgflags;                // diagnostic ablation switches (MDBG_TILE_DBG), 0 in production
     SketchConsts c;
 };
 
@@ -104,14 +106,14 @@ __global__ void all_slow_kernel(u32 n_tiles, u32* __restrict__ n_cand, u32* __re
 }
 
 // ---- fast tile kernel ------------------------------------------------------------------------------
-constexpr int LDS_CODES = (TILE_THREADS + 1) * SEG_STRIDE;   // segment -1 holds the halo (last 8 words)
+// LDS (dwords): 2-bit codes of the tile + halo | candidate list (u16) | rotate tables of the fix-up | transition table
+constexpr int LDS_CODES = (TILE_THREADS + 1) * SEG_WORDS;   // logical word j (>= -HALO/16) lives at index j + SEG_WORDS
 constexpr int LDS_LIST = QCAP / 2;
-constexpr int LDS_TBL = 32;
-constexpr int LDS_HC = 16;
+constexpr int LDS_RT = MDBG_MAX_L_DEV * 4 * 4;              // {rol(h[c], l-1-j), rol(rc[c], j)} for j < 32, c < 4: 16 B each
+constexpr int LDS_TBL = 36;                                 // 16 x {XF, XR} + one all-zero entry
 constexpr int LDS_MISC = 16;
-constexpr int LDS_TOTAL = LDS_CODES + LDS_LIST + LDS_TBL + LDS_HC + LDS_MISC;
-
-__device__ inline int codes_addr(int j) { return ((j >> 4) + 1) * SEG_STRIDE + (j & 15); }   // j = logical word index, >= -8
+constexpr int LDS_TOTAL = LDS_CODES + LDS_LIST + LDS_RT + LDS_TBL + LDS_MISC;   // 5700 dwords = 22.8 KB -> 7 workgroups per CU
+static_assert(LDS_TOTAL * 4 * 7 <= 160 * 1024, "7 workgroups per CU");
 
 __device__ inline u32 pack16(uint4 v, u32& bad) {
     u32 out = 0;
@@ -127,14 +129,63 @@ __device__ inline u32 pack16(uint4 v, u32& bad) {
     return out;
 }
 
+// acc = 2*acc + (lane's bit of mask): one VALU instruction (v_addc with the carry-in taken from an SGPR pair)
+__device__ inline u32 shift_in_bit(u32 acc, u64 mask) {
+    u32 out; u64 carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(carry_out) : "v"(acc), "s"(mask));
+    return out;
+}
+
+struct RollState { u32 hist, G, R, prev; };
+
+// Eight steps of the rolling partial hashes over the low 16 bits of w (8 two-bit codes), branch-free: the code history /
+// table addresses of all 8 steps first (a short ALU chain), then the 8 LDS reads back to back, then the G/R chains.
+// Lanes whose base is not a run start compute the same values and discard them with v_cndmask: with 64 lanes some lane
+// always pushes, so an exec-mask branch would never be skipped and would serialise every ds_read's latency.
+// Returns 8 bits, step 0 in bit 7: candidate flags (EMIT) or kept flags (!EMIT).
+template <bool HPC, bool EMIT>
+__device__ inline u32 roll8(RollState& st, u32 w, const u32* tbl, u32 bfe_off, u32 thrF, u32 thrR, u32 maskR) {
+    u32 ad[8]; u64 kpm[8]; bool kp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 c_ = (w >> (2 * i)) & 3u;
+        kp[i] = !HPC || c_ != st.prev;
+        kpm[i] = __builtin_amdgcn_ballot_w64(kp[i]);
+        const u32 c8_ = c_ << 3;
+        ad[i] = (__builtin_amdgcn_ubfe(st.hist, bfe_off, 2u) << 5) | c8_;
+        const u32 hn = (st.hist << 2) | c8_;
+        st.hist = __builtin_unpredictable(kp[i]) ? hn : st.hist;
+        st.prev = c_;
+    }
+    uint2 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = *(const uint2*)((const char*)tbl + ad[i]);
+    u32 bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 Gn = (st.G << 1) ^ x[i].x, Rn = (st.R >> 1) ^ x[i].y;
+        st.G = __builtin_unpredictable(kp[i]) ? Gn : st.G;
+        st.R = __builtin_unpredictable(kp[i]) ? Rn : st.R;
+        if (EMIT) {
+            // a run continuation keeps G/R, so it repeats its predecessor's verdict: harmless, the fix-up rejects
+            // positions that are not run starts
+            const u64 cm = __builtin_amdgcn_ballot_w64(st.G <= thrF) | __builtin_amdgcn_ballot_w64((st.R & maskR) <= thrR);
+            bits = shift_in_bit(bits, cm);
+        } else {
+            bits = shift_in_bit(bits, kpm[i]);
+        }
+    }
+    return bits;
+}
+
 template <bool HPC>
-__global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a) {
+__global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a) {
     __shared__ __attribute__((aligned(16))) u32 lds[LDS_TOTAL];
-    u32* const codes = lds;
+    u32* const codes = lds + SEG_WORDS;                  // codes[j], j >= -HALO/16
     u16* const list = (u16*)(lds + LDS_CODES);
-    u32* const tbl = lds + LDS_CODES + LDS_LIST;
-    u64* const hc = (u64*)(tbl + LDS_TBL);             // hc[0..3] = h by code, hc[4..7] = rc by code
-    u32* const misc = tbl + LDS_TBL + LDS_HC;          // [0..4] scan tmp, [8] slow flag
+    u64* const rt = (u64*)(lds + LDS_CODES + LDS_LIST);  // rt[(j*4 + c)*2 + {0,1}]
+    u32* const tbl = lds + LDS_CODES + LDS_LIST + LDS_RT;
+    u32* const misc = tbl + LDS_TBL;                     // [0..4] scan tmp, [8] slow flag
 
     const int tid = threadIdx.x;
     const u32 t = blockIdx.x;
@@ -142,46 +193,61 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a
     const int64_t tile_start = (int64_t)(gt * (u64)TILE);
     const int64_t nb = (int64_t)a.n_bases;
     const u32 l = a.c.l;
+#define MDBG_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(size_t)t * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    MDBG_STAMP(0);
 
     if (tid < 32) tbl[tid] = a.tbl[tid];
-    if (tid == 32) { hc[0] = NT_SEED_A; hc[1] = NT_SEED_C; hc[2] = NT_SEED_T; hc[3] = NT_SEED_G;
-                     hc[4] = NT_SEED_T; hc[5] = NT_SEED_G; hc[6] = NT_SEED_A; hc[7] = NT_SEED_C; }
-    if (tid == 33) misc[8] = 0;
+    if (tid >= 32 && tid < 36) tbl[tid] = 0;
+    if (tid == 36) misc[8] = 0;
+    if (tid >= 64 && tid < 64 + MDBG_MAX_L_DEV * 4) {
+        const u32 e = tid - 64, j = e >> 2, c = e & 3;
+        const u64 h4[4] = {NT_SEED_A, NT_SEED_C, NT_SEED_T, NT_SEED_G}, r4[4] = {NT_SEED_T, NT_SEED_G, NT_SEED_A, NT_SEED_C};
+        u64 hv = h4[0], rv = r4[0];
+        if (c == 1) { hv = h4[1]; rv = r4[1]; } else if (c == 2) { hv = h4[2]; rv = r4[2]; } else if (c == 3) { hv = h4[3]; rv = r4[3]; }
+        rt[e * 2] = rol64(hv, (l - 1 - j) & 63);
+        rt[e * 2 + 1] = rol64(rv, j);
+    }
     __syncthreads();
 
     // ---- phase 1: ASCII -> 2-bit codes in LDS (coalesced 16-byte loads, 8 in flight per lane) ------
     {
         u32 bad_any = 0;
         constexpr int NCHUNK = (TILE + HALO) / 16;                 // 4104 = 16 * 256 + 8
+        constexpr int H16 = HALO / 16;
         const bool interior = tile_start >= HALO && tile_start + TILE <= nb;
-        auto load_chunk = [&](int ci) -> uint4 {                   // careful path (first / last tile)
-            const int64_t pos = tile_start + 16 * (int64_t)(ci - HALO / 16);
-            uint4 v = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
-            if (pos >= 0 && pos + 16 <= nb) v = *(const uint4*)(a.bases + pos);
-            else if (pos >= 0 && pos < nb) {
-                __attribute__((aligned(16))) u8 tmpb[16];
-                for (int i = 0; i < 16; ++i) tmpb[i] = (pos + i < nb) ? a.bases[pos + i] : (u8)'A';
-                v = *(const uint4*)tmpb;
+        if (interior) {
+            const uint4* src = (const uint4*)(a.bases + (tile_start - HALO));      // chunk ci lives at src[ci]
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (a.dbgflags & 1) ? make_uint4(0x41434754u ^ (tid << 1 & 6), 0x54474341u, 0x41544347u, 0x47414354u) : src[tid + TILE_THREADS * (half * 8 + u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { u32 bad = 0; codes[tid + TILE_THREADS * (half * 8 + u) - H16] = pack16(v[u], bad); bad_any |= bad; }
             }
-            return v;
-        };
-        const uint4* src = (const uint4*)(a.bases + (tile_start - HALO));      // chunk ci lives at src[ci] (interior tiles)
+            if (tid < NCHUNK - 16 * TILE_THREADS) { u32 bad = 0; codes[16 * TILE_THREADS + tid - H16] = pack16(src[16 * TILE_THREADS + tid], bad); bad_any |= bad; }
+        } else {
+            // first / last tile of the batch: positions outside [0, n_bases) read as 'A'
+#pragma unroll 1
+            for (int ci = tid; ci < NCHUNK; ci += TILE_THREADS) {
+                const int64_t pos = tile_start + 16 * (int64_t)(ci - H16);
+                uint4 v = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+                if (pos >= 0 && pos + 16 <= nb) v = *(const uint4*)(a.bases + pos);
+                else if (pos >= 0 && pos < nb) {
+                    u32 w4[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            uint4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int ci = tid + TILE_THREADS * (half * 8 + u); v[u] = interior ? src[ci] : load_chunk(ci); }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int ci = tid + TILE_THREADS * (half * 8 + u); u32 bad = 0; codes[codes_addr(ci - HALO / 16)] = pack16(v[u], bad); bad_any |= bad; }
-        }
-        if (tid < NCHUNK - 16 * TILE_THREADS) {
-            const int ci = 16 * TILE_THREADS + tid; u32 bad = 0;
-            codes[codes_addr(ci - HALO / 16)] = pack16(interior ? src[ci] : load_chunk(ci), bad); bad_any |= bad;
+                    for (int i = 0; i < 16; ++i) if (pos + i < nb) w4[i >> 2] = (w4[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((u32)a.bases[pos + i] << (8 * (i & 3)));
+                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+                u32 bad = 0;
+                codes[ci - H16] = pack16(v, bad);
+                bad_any |= bad;
+            }
         }
         if (bad_any) {                       // some byte of my chunks is not one of ACGT
             misc[8] = 1;                     // whole tile takes the generic exact path
             for (int ci = tid; ci < NCHUNK; ci += TILE_THREADS) {
-                const int64_t pos = tile_start + 16 * (int64_t)(ci - HALO / 16);
+                const int64_t pos = tile_start + 16 * (int64_t)(ci - H16);
                 for (int i = 0; i < 16; ++i) {
                     int64_t q = pos + i;
                     if (q >= 0 && q < nb) { u8 c = a.bases[q]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') *a.err_flag = 1; }
@@ -190,6 +256,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a
         }
     }
     __syncthreads();
+    MDBG_STAMP(1);
     if (misc[8]) {
         if (tid == 0) { a.n_cand[t] = SLOW_MARK; a.slow_list[atomicAdd(a.slow_count, 1u)] = t; }
         return;
@@ -197,49 +264,32 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a
 
     // ---- phase 2: per-lane rolling partial hashes over SEG raw bases ------------------------------
     const u32 thrF = a.c.thrF, thrR = a.c.thrR, maskR = a.c.maskR, bfe_off = a.c.bfe_off;
-    u32 hist, G, R, prev, npush;
     u32 cb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) cb[i] = 0;
     bool force = false;                       // first l-1 pushes of my segment must all be candidates
-
-#define MDBG_STEP(w, i, EMIT, cbv, bit)                                                     \
-    {                                                                                        \
-        const u32 c_ = ((w) >> (2 * (i))) & 3u;                                              \
-        if (!HPC || c_ != prev) {                                                            \
-            const u32 c8_ = c_ << 3;                                                         \
-            const u32 out_ = __builtin_amdgcn_ubfe(hist, bfe_off, 2u);                       \
-            const u32 ad_ = (out_ << 5) | c8_;                                               \
-            hist = (hist << 2) | c8_;                                                        \
-            const uint2 x_ = *(const uint2*)((const char*)tbl + ad_);                        \
-            G = (G << 1) ^ x_.x;                                                             \
-            R = (R >> 1) ^ x_.y;                                                             \
-            if (EMIT) { if (G <= thrF || (R & maskR) <= thrR) cbv |= (1u << (bit)); }        \
-            else ++npush;                                                                    \
-        }                                                                                    \
-        prev = c_;                                                                           \
-    }
-
-    const bool active = tile_start + (int64_t)tid * SEG < nb;
+    const bool active = tile_start + (int64_t)tid * SEG < nb && !(a.dbgflags & 2);
     if (active) {
-    {
-        int nW = 2;                           // warm-up words (32 raw bases), then 8 (the whole halo)
-        for (;;) {
-            hist = 0; G = a.c.G0; R = a.c.R0; npush = 0;
+        RollState st;
+        // warm-up: the same loop, silently, over the 32 bases before my segment (then the whole 128-base halo).  The
+        // state starts as l x 'A' with matching G0/R0, so "state = hash of the last l pushed codes" holds from the first
+        // push and is exact after l pushes.
+        u32 npush = 0;
+        for (int nW = 2;; nW = HALO / 16) {
+            st.hist = 0; st.G = a.c.G0; st.R = a.c.R0; npush = 0;
             const int ws = tid * SEG_WORDS - nW;
-            prev = (ws - 1 >= -HALO / 16) ? codes[codes_addr(ws - 1)] >> 30 : 4u;
+            st.prev = (ws - 1 >= -HALO / 16) ? codes[ws - 1] >> 30 : 4u;
             for (int k = 0; k < nW; ++k) {
-                const u32 w = codes[codes_addr(ws + k)];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) MDBG_STEP(w, i, false, cb[0], 0)
+                const u32 w = codes[ws + k];
+                npush += __popc(roll8<HPC, false>(st, w, tbl, bfe_off, thrF, thrR, maskR));
+                npush += __popc(roll8<HPC, false>(st, w >> 16, tbl, bfe_off, thrF, thrR, maskR));
             }
-            if (npush >= l || nW == 8) break;
-            nW = 8;
+            if (npush >= l || nW == HALO / 16) break;
         }
         if (npush < l) {
-            // rare: fewer than l code changes in the 128 bases before my segment (long homopolymer).
-            // Replay from global memory, at most 4096 bases back; if that is still not enough, or a byte
-            // outside ACGT is met, the partial hashes of my first l-1 pushes cannot be trusted -> force them.
+            // rare: fewer than l code changes in the 128 bases before my segment (long homopolymer).  Replay from global
+            // memory, at most 4096 bases back; if that is still not enough, or a byte outside ACGT is met, the partial
+            // hashes of my first l-1 pushes cannot be trusted -> force them to be candidates.
             const int64_t seg0 = tile_start + (int64_t)tid * SEG;
             int64_t q = seg0; u32 runs = 0; bool dirty = false;
             while (q > 0 && runs < l + 1 && seg0 - q < 4096) {
@@ -249,66 +299,50 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a
                 if (!HPC || q == 0 || (((u32)a.bases[q - 1] >> 1) & 3u) != (((u32)b0 >> 1) & 3u)) ++runs;
             }
             if (dirty || (runs < l + 1 && q > 0)) force = true;
-            hist = 0; G = a.c.G0; R = a.c.R0; npush = 0;
-            prev = q > 0 ? (((u32)a.bases[q - 1] >> 1) & 3u) : 4u;
-            for (; q < seg0; ++q) { const u32 w = ((u32)a.bases[q] >> 1) & 3u; MDBG_STEP(w, 0, false, cb[0], 0) }
-        }
-    }
-    {
-        // Branch-free form: per 16-base word, first the code history / table addresses of all 16 steps (a short ALU
-        // chain), then the 16 LDS table reads back to back, then the G/R chains.  Lanes whose base is not a run start
-        // compute the same values and discard them with v_cndmask (exec-mask branches would put every ds_read's latency
-        // on the critical path: some lane always pushes, so the branch is never skipped anyway).
-        const uint4* segp = (const uint4*)(codes + (tid + 1) * SEG_STRIDE);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint4 v = segp[g];
-            const u32 w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const u32 w = w4[k];
-                u32 ad[16]; bool kp[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const u32 c_ = (w >> (2 * i)) & 3u;
-                    kp[i] = !HPC || c_ != prev;
+            st.hist = 0; st.G = a.c.G0; st.R = a.c.R0;
+            st.prev = q > 0 ? (((u32)a.bases[q - 1] >> 1) & 3u) : 4u;
+            for (; q < seg0; ++q) {
+                const u32 c_ = ((u32)a.bases[q] >> 1) & 3u;
+                if (!HPC || c_ != st.prev) {
                     const u32 c8_ = c_ << 3;
-                    ad[i] = (__builtin_amdgcn_ubfe(hist, bfe_off, 2u) << 5) | c8_;
-                    const u32 hn = (hist << 2) | c8_;
-                    hist = kp[i] ? hn : hist;
-                    prev = c_;
+                    const u32 ad_ = (__builtin_amdgcn_ubfe(st.hist, bfe_off, 2u) << 5) | c8_;
+                    st.hist = (st.hist << 2) | c8_;
+                    const uint2 x_ = *(const uint2*)((const char*)tbl + ad_);
+                    st.G = (st.G << 1) ^ x_.x; st.R = (st.R >> 1) ^ x_.y;
                 }
-                uint2 x[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) x[i] = *(const uint2*)((const char*)tbl + ad[i]);
-                u32 cw = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const u32 Gn = (G << 1) ^ x[i].x, Rn = (R >> 1) ^ x[i].y;
-                    G = kp[i] ? Gn : G;
-                    R = kp[i] ? Rn : R;
-                    const bool cand = kp[i] && (Gn <= thrF || (Rn & maskR) <= thrR);
-                    cw |= (cand ? 1u : 0u) << i;
-                }
-                cb[g * 2 + (k >> 1)] |= cw << ((k & 1) * 16);
+                st.prev = c_;
             }
+        }
+        // main loop: 8 iterations x 32 bases; cb[] is rotated so that every index stays static (registers)
+        const uint2* segp = (const uint2*)(codes + tid * SEG_WORDS);
+#pragma unroll 1
+        for (int it = 0; it < 8; ++it) {
+            const uint2 v = segp[it];
+            u32 b0 = roll8<HPC, true>(st, v.x, tbl, bfe_off, thrF, thrR, maskR);
+            u32 b1 = roll8<HPC, true>(st, v.x >> 16, tbl, bfe_off, thrF, thrR, maskR);
+            u32 b2 = roll8<HPC, true>(st, v.y, tbl, bfe_off, thrF, thrR, maskR);
+            u32 b3 = roll8<HPC, true>(st, v.y >> 16, tbl, bfe_off, thrF, thrR, maskR);
+            // each bK holds 8 flags with step 0 in bit 7: concatenate (first step in the top bit) and reverse
+            const u32 word = __brev((b0 << 24) | (b1 << 16) | (b2 << 8) | b3);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) cb[j] = cb[j + 1];
+            cb[7] = word;
         }
     }
     if (force) {                              // mark the first l-1 pushes of my segment
-        u32 pushes = 0; u32 pv = codes[codes_addr(tid * SEG_WORDS - 1)] >> 30;
+        u32 pushes = 0; u32 pv = codes[tid * SEG_WORDS - 1] >> 30;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             for (int b = 0; b < 32 && pushes < l - 1; ++b) {
                 const int p = i * 32 + b;
-                const u32 c = (codes[codes_addr(tid * SEG_WORDS + (p >> 4))] >> (2 * (p & 15))) & 3u;
+                const u32 c = (codes[tid * SEG_WORDS + (p >> 4)] >> (2 * (p & 15))) & 3u;
                 if (!HPC || c != pv) { cb[i] |= 1u << b; ++pushes; }
                 pv = c;
             }
         }
     }
-    }   // active
-#undef MDBG_STEP
 
+    MDBG_STAMP(2);
     // ---- phase 3: ordered candidate list -------------------------------------------------------------
     u32 cnt = 0;
 #pragma unroll
@@ -326,35 +360,40 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a
     }
     __syncthreads();
 
+    MDBG_STAMP(3);
     // ---- phase 4: exact 64-bit fix-up of every candidate ----------------------------------------------
     const u32 rl = a.bread[gt], rhi = a.bread[gt + 1];
     const int64_t lds_lo = tile_start - HALO;            // first raw position staged in LDS
-    auto code_at = [&](int64_t q) -> u32 { const int rel = (int)(q - tile_start); return (codes[codes_addr(rel >> 4)] >> (2 * (rel & 15))) & 3u; };
+    auto code_at = [&](int64_t q) -> u32 { const int rel = (int)(q - tile_start); return (codes[rel >> 4] >> (2 * (rel & 15))) & 3u; };
     u32 nval = 0;
     Rec* slab = a.slab + (size_t)t * QCAP;
-    for (u32 j = tid; j < n_cand; j += TILE_THREADS) {
+    for (u32 j = tid; j < ((a.dbgflags & 4) ? 0u : n_cand); j += TILE_THREADS) {
         const int64_t p = tile_start + list[j];
         Rec rec; rec.hash = 0; rec.pos = 0; rec.read = 0xFFFFFFFFu;
         if (p < nb) {
-            const u32 r = find_read(a.offsets, rl, rhi, (u64)p);
-            const int64_t rlo = (int64_t)a.offsets[r];
             bool ok = true, in_lds = true;
+            int64_t rlo = 0; u32 r = 0;
+            // a run continuation (repeated verdicts, merged read starts) is never the end of a valid l-mer: a valid end is
+            // a run start at HPC index >= l-1 >= 1 of its read, i.e. its code differs from the base before it
+            if (HPC && code_at(p - 1) == code_at(p)) ok = false;
             u64 fh = 0, rh = 0; int64_t q = p;
-            if (HPC && p != rlo && code_at(p - 1) == code_at(p)) ok = false;      // not a run start inside its read
-            for (int jj = (int)l - 1; ok; --jj) {
-                const u32 c = code_at(q);
-                fh ^= rol64(hc[c], l - 1 - jj);
-                rh ^= rol64(hc[4 + c], jj);
-                if (jj == 0) break;
-                if (q == rlo) { ok = false; break; }
-                int64_t q2 = q - 1;
-                if (q2 < lds_lo) { in_lds = false; break; }
-                if (HPC) {
-                    const u32 c2 = code_at(q2);
-                    while (q2 > rlo) { if (q2 - 1 < lds_lo) { in_lds = false; break; } if (code_at(q2 - 1) != c2) break; --q2; }
-                    if (!in_lds) break;
+            if (ok) {
+                r = find_read(a.offsets, rl, rhi, (u64)p); rlo = (int64_t)a.offsets[r];
+                for (int jj = (int)l - 1;; --jj) {
+                    const u32 c = code_at(q);
+                    const ulonglong2 e = *(const ulonglong2*)(rt + (jj * 4 + c) * 2);
+                    fh ^= e.x; rh ^= e.y;
+                    if (jj == 0) break;
+                    if (q == rlo) { ok = false; break; }
+                    int64_t q2 = q - 1;
+                    if (q2 < lds_lo) { in_lds = false; break; }
+                    if (HPC) {
+                        const u32 c2 = code_at(q2);
+                        while (q2 > rlo) { if (q2 - 1 < lds_lo) { in_lds = false; break; } if (code_at(q2 - 1) != c2) break; --q2; }
+                        if (!in_lds) break;
+                    }
+                    q = q2;
                 }
-                q = q2;
             }
             u64 h = fh < rh ? fh : rh, start = (u64)q;
             if (ok && !in_lds) ok = walk_lmer_ascii<HPC>(a.bases, (u64)rlo, (u64)p, l, start, h);   // ran off the staged region
@@ -365,6 +404,8 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void sketch_tile_kernel(TileArgs a
     u32 tot;
     (void)block_excl_scan_256(nval, misc, tot);
     if (tid == 0) { a.n_cand[t] = n_cand; a.n_valid[t] = tot; }
+    MDBG_STAMP(4);
+#undef MDBG_STAMP
 }
 
 // ---- gather: slabs -> final position-ordered arrays ---------------------------------------------
@@ -430,7 +471,7 @@ struct SketchLaunch {
     u32* bread; u64 n_tiles_total;
     Rec* slab; u32* n_cand; u32* n_valid; u64* tile_base; u32* slow_list; u32* slow_count; u32* err_flag; u64* carry;
     u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
-    SketchConsts c; const u32* tbl; bool force_slow; u64* slow_total; u32 read_base;
+    SketchConsts c; const u32* tbl; bool force_slow; u64* slow_total; u32 read_base; u64* dbg; u32 dbgflags;
 };
 
 void launch_bread(const SketchLaunch& L, hipStream_t s) {
@@ -443,7 +484,7 @@ void launch_sketch_chunk(const SketchLaunch& L, u64 tile0, u32 n, hipStream_t s,
     TileArgs a;
     a.bases = L.bases; a.n_bases = L.n_bases; a.offsets = L.offsets; a.n_reads = L.n_reads; a.bread = L.bread;
     a.tile0 = tile0; a.n_tiles = n; a.slab = L.slab; a.n_cand = L.n_cand; a.n_valid = L.n_valid;
-    a.slow_list = L.slow_list; a.slow_count = L.slow_count; a.err_flag = L.err_flag; a.c = L.c; a.tbl = L.tbl; a.read_base = L.read_base;
+    a.slow_list = L.slow_list; a.slow_count = L.slow_count; a.err_flag = L.err_flag; a.c = L.c; a.tbl = L.tbl; a.read_base = L.read_base; a.dbg = L.dbg; a.dbgflags = L.dbgflags;
     (void)hipMemsetAsync(L.slow_count, 0, sizeof(u32), s);
     const bool hpc = L.c.hpc != 0;
     if (L.force_slow || L.c.l > (u32)FAST_MAX_L) {
