@@ -41,6 +41,26 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(bases_per_launch, args):
+    """HBM bytes per launch of sketch_tile_kernel from the committed rocprofv3 PMC passes of this very command
+    (profiles/summarize.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).  PMC counters cannot
+    be read from inside the process, so the figure is only reported when the workload of this run matches the profiled one."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(p))
+            ref = json.load(open(p.replace("_pmc_traffic.json", "_bench.json")))
+            k = j["kernels"]["sketch_tile_kernel<true>" if True else ""]
+            c = ref["config"]
+            same = (c["k"], c["l"], c["density"], c["minabund"]) == (args.k, args.l, args.density, args.minabund) and \
+                abs(c["bases_per_gpu"] / ref["roofline"]["launches_per_step"] - bases_per_launch) < 1e-6 * bases_per_launch
+            if same:
+                return k["hbm_bytes_per_launch"], os.path.relpath(p, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     """Times the CPU oracle on a bounded prefix of the same reads, one worker per host core."""
     import numpy as np
@@ -143,8 +163,10 @@ def main():
         if st["n_sketch_tile_launches"]:
             avg_ms = st["ms_sketch_tile"] / st["n_sketch_tile_launches"]
             ach = alg_bytes / st["n_sketch_tile_launches"] / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args)
             roof = {"bound": "hbm", "kernel": "sketch_tile_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "launches_per_step": st["n_sketch_tile_launches"], "avg_launch_ms": avg_ms,
+                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes / st["n_sketch_tile_launches"],
+                    "launches_per_step": st["n_sketch_tile_launches"], "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_base": 1.0 + 12.0 * mins_per_base,
                     "kernel_gbases_per_s": st["n_sketch_tile_bases"] / (st["ms_sketch_tile"] * 1e-3) / 1e9}
         cpu = None

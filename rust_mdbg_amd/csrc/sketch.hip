@@ -216,16 +216,17 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
         constexpr int H16 = HALO / 16;
         const bool interior = tile_start >= HALO && tile_start + TILE <= nb;
         if (interior) {
-            const uint4* src = (const uint4*)(a.bases + (tile_start - HALO));      // chunk ci lives at src[ci]
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4* src = (const u32x4*)(a.bases + (tile_start - HALO));      // chunk ci lives at src[ci]
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                uint4 v[8];
+            for (int grp = 0; grp < 4; ++grp) {                    // 4 x 16-byte loads in flight per lane, streamed once
+                uint4 v[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (a.dbgflags & 1) ? make_uint4(0x41434754u ^ (tid << 1 & 6), 0x54474341u, 0x41544347u, 0x47414354u) : src[tid + TILE_THREADS * (half * 8 + u)];
+                for (int u = 0; u < 4; ++u) { const u32x4 q = __builtin_nontemporal_load(src + tid + TILE_THREADS * (grp * 4 + u)); v[u] = make_uint4(q.x, q.y, q.z, q.w); }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { u32 bad = 0; codes[tid + TILE_THREADS * (half * 8 + u) - H16] = pack16(v[u], bad); bad_any |= bad; }
+                for (int u = 0; u < 4; ++u) { u32 bad = 0; codes[tid + TILE_THREADS * (grp * 4 + u) - H16] = pack16(v[u], bad); bad_any |= bad; }
             }
-            if (tid < NCHUNK - 16 * TILE_THREADS) { u32 bad = 0; codes[16 * TILE_THREADS + tid - H16] = pack16(src[16 * TILE_THREADS + tid], bad); bad_any |= bad; }
+            if (tid < NCHUNK - 16 * TILE_THREADS) { u32 bad = 0; const u32x4 q = src[16 * TILE_THREADS + tid]; codes[16 * TILE_THREADS + tid - H16] = pack16(make_uint4(q.x, q.y, q.z, q.w), bad); bad_any |= bad; }
         } else {
             // first / last tile of the batch: positions outside [0, n_bases) read as 'A'
 #pragma unroll 1
