@@ -399,6 +399,19 @@ const uint8_t* orc_graph_seqline_rev(orc_graph_t* h) { return h->sl_rev.data(); 
 const uint64_t* orc_graph_seqline_shift(orc_graph_t* h) { return h->sl_s.data(); }
 void orc_graph_free(orc_graph_t* h) { delete h; }
 
+// Test hook: run the reference's graph emitter (src/main.rs:1014-1117) on a node table supplied by the caller
+// (e.g. the one libmdbg_hip produced).  The emitter is a pure function of {key, index, abundance, seqlen, shift}.
+orc_graph_t* orc_graph_from_nodes(uint64_t k, uint64_t n, const uint64_t* keys, const uint32_t* index, const uint16_t* abundance,
+                                  const uint32_t* seqlen, const uint16_t* shift, float presimp) {
+    auto* h = new orc_graph_t(); h->err = 0; h->err_read = 0;
+    h->g.k = k; h->g.l = 0; h->g.density = 0; h->g.minabund = 1; h->g.already_hpc = false; h->g.presimp = presimp;
+    for (uint64_t i = 0; i < n; ++i) {
+        Entry e{}; e.index = index[i]; e.abundance = abundance[i]; e.seqlen = seqlen[i]; e.shift0 = shift[2 * i]; e.shift1 = shift[2 * i + 1];
+        h->g.nodes.emplace(Kmer(keys + i * k, keys + (i + 1) * k), e);
+    }
+    return h;
+}
+
 // Timing-only multi-threaded variant for bench.py's cpu_baseline leg: the same per-read functions,
 // one worker per thread over a contiguous slice of reads with a thread-local counting map, merged at
 // the end (the reference shares one DashMap between its --threads workers, main.rs:595,834).

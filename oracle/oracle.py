@@ -69,6 +69,8 @@ def lib():
         fn.restype = t
         fn.argtypes = [C.c_void_p]
     L.orc_graph_free.argtypes = [C.c_void_p]
+    L.orc_graph_from_nodes.restype = C.c_void_p
+    L.orc_graph_from_nodes.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
     L.orc_count_threaded.restype = C.c_int64
     L.orc_count_threaded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double,
                                      C.c_uint32, C.c_int, C.c_int, u64p]
@@ -212,6 +214,28 @@ class Graph:
             self.close()
         except Exception:
             pass
+
+
+def edges_from_nodes(nodes, presimp=0.01):
+    """reference emitter (src/main.rs:1014-1117) applied to a node table dict -> sorted list of (n1, o1, n2, o2, overlap)"""
+    L = lib()
+    k = nodes["keys"].shape[1] if len(nodes["keys"]) else 1
+    n = len(nodes["index"])
+    keys = np.ascontiguousarray(nodes["keys"], dtype=np.uint64)
+    idx = np.ascontiguousarray(nodes["index"], dtype=np.uint32)
+    ab = np.ascontiguousarray(nodes["abundance"], dtype=np.uint16)
+    sl = np.ascontiguousarray(nodes["seqlen"], dtype=np.uint32)
+    sh = np.ascontiguousarray(nodes["shift"], dtype=np.uint16)
+    h = L.orc_graph_from_nodes(k, n, keys.ctypes.data, idx.ctypes.data, ab.ctypes.data, sl.ctypes.data, sh.ctypes.data, presimp)
+    try:
+        assert L.orc_graph_finalize(h, 1) == 0
+        ne = int(L.orc_graph_counter(h, 5))
+        e = zip(_arr(L.orc_graph_edge_n1(h), ne, np.uint32).tolist(), _arr(L.orc_graph_edge_o1(h), ne, np.uint8).tolist(),
+                _arr(L.orc_graph_edge_n2(h), ne, np.uint32).tolist(), _arr(L.orc_graph_edge_o2(h), ne, np.uint8).tolist(),
+                _arr(L.orc_graph_edge_overlap(h), ne, np.uint32).tolist())
+        return sorted(e), int(L.orc_graph_counter(h, 6))
+    finally:
+        L.orc_graph_free(h)
 
 
 def count_threaded(bases, offsets, k, l, density, minabund=2, already_hpc=False, threads=1):

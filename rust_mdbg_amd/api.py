@@ -67,6 +67,14 @@ def load_library():
     p = lib_path()
     if not os.path.exists(p):
         raise ImportError("libmdbg_hip.so not built (%s); run `make -C rust_mdbg_amd/csrc`" % p)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if this library (linked against
+    # /opt/rocm's) is loaded first, a later `import torch` finds no GPU.  Loading torch first makes both share torch's
+    # copy (same SONAME).  Plumbing only - nothing of torch is used here.  MDBG_NO_TORCH_PRELOAD=1 disables it.
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("MDBG_NO_TORCH_PRELOAD"):
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     L = C.CDLL(p)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.mdbg_abi_version.restype = u32

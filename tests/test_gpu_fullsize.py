@@ -1,0 +1,100 @@
+"""Parity at BASELINE.json sizes (GPU).  configs[1] (100k HiFi-shaped reads, k=21 l=12 d=0.003) is compared bit for bit
+with the oracle, nodes AND edges; configs[2] (140 Mb @50x, 7 Gbases) is checked through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("keys", "index", "abundance", "seqlen", "shift", "shift_full", "src_read", "src_start", "src_end", "reversed")
+
+
+def test_config2_100k_reads_bit_exact_nodes_and_edges():
+    """BASELINE configs[1]: 30 Mb genome, 100,000 reads ~N(15 kb, 1.5 kb), 0.1 % errors, k=21 l=12 d=0.003 minabund=2"""
+    import rust_mdbg_amd as R
+    k, l, d, a = 21, 12, 0.003, 2
+    n_reads = 100000
+    with R.Mdbg(k, l, d, a) as m:
+        db, do, nb = m.synth_reads_device(seed=2, genome_len=30_000_000, n_reads=n_reads)
+        m.ingest_device(db, do, n_reads, nb, 0)
+        got = m.finalize()
+        st = m.stats()
+        bases = m.to_host(db, nb)
+        offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
+    assert 1.4e9 < nb < 1.6e9 and st["n_slow_tiles"] == 0
+    g = O.Graph(k, l, d, a)
+    assert g.ingest(bases, offs) == 0
+    exp = g.finalize(with_edges=True)
+    assert st["n_minimizers"] == exp["n_minimizers"] and st["n_windows"] == exp["n_windows"]
+    assert got["n_nodes"] == exp["n_nodes"] > 100000 and got["n_nodes_before"] == exp["n_nodes_before"]
+    for f in FIELDS:
+        assert np.array_equal(got[f], exp[f]), f
+    # edge set: the reference's emitter (pure function of the node table) on OUR table == the oracle's end-to-end edges
+    edges, removed = O.edges_from_nodes(got)
+    exp_edges = sorted(zip(exp["edge_n1"].tolist(), exp["edge_o1"].tolist(), exp["edge_n2"].tolist(), exp["edge_o2"].tolist(), exp["edge_overlap"].tolist()))
+    assert edges == exp_edges and len(edges) == exp["n_edges"] > 100000 and removed == exp["presimp_removed"]
+
+
+def test_config3_size_properties():
+    """BASELINE configs[2] size (7 Gbases on the device): invariants that need no oracle run"""
+    import rust_mdbg_amd as R
+    k, l, d, a = 35, 12, 0.002, 2
+    n_reads = 466666
+    with R.Mdbg(k, l, d, a) as m:
+        db, do, nb = m.synth_reads_device(seed=1, genome_len=140_000_000, n_reads=n_reads)
+        m.ingest_device(db, do, n_reads, nb, 0)
+        one = m.finalize()
+        st = m.stats()
+        assert st["n_slow_tiles"] == 0 and st["n_tiles"] == (nb + 65535) // 65536
+        # 1. node rows are sorted by index, indices are unique and < number of distinct keys
+        assert np.all(np.diff(one["index"].astype(np.int64)) > 0) and int(one["index"][-1]) < one["n_nodes_before"]
+        # 2. abundance filter and metadata identities (src/main.rs:778: seqlen = last - first + 2; end = last + l)
+        assert one["abundance"].min() >= a
+        assert np.array_equal(one["seqlen"], (one["src_end"] - one["src_start"] - l + 2).astype(np.uint32))
+        assert np.all(one["src_read"] < n_reads)
+        # 3. canonical keys: key <= reversed key lexicographically; every minimizer hash <= hash_bound
+        kk = one["keys"]
+        rev = kk[:, ::-1]
+        neq = kk != rev
+        first = np.argmax(neq, axis=1)
+        rows = np.arange(len(kk))
+        assert np.all((kk[rows, first] < rev[rows, first]) | ~neq.any(axis=1))
+        assert int(kk.max()) <= O.hash_bound(d)
+        # 4. determinism: drop everything and run again -> identical table (atomics / scheduling must not matter)
+        m.reset(0)
+        m.ingest_device(db, do, n_reads, nb, 0)
+        two = m.finalize()
+        for f in FIELDS:
+            assert np.array_equal(one[f], two[f]), f
+        # 5. multi-k on the resident sketches == a fresh context with that k
+        m.reset(21)
+        k21 = m.finalize()
+        st21 = m.stats()
+    assert k21["n_nodes"] > one["n_nodes"] and st21["n_minimizers"] == st["n_minimizers"] and st21["n_windows"] > st["n_windows"]
+
+
+def test_config3_size_routed_equals_local():
+    """the multi-GPU code path (route -> exchange -> insert -> cross-rank resolve) on one rank at 7 Gbases equals the local path"""
+    import torch
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import dist as D
+    k, l, d, a = 35, 12, 0.002, 2
+    n_reads = 466666
+    dev = torch.device("cuda", 0)
+    with R.Mdbg(k, l, d, a) as m:
+        db, do, nb = m.synth_reads_device(seed=1, genome_len=140_000_000, n_reads=n_reads)
+        m.ingest_device(db, do, n_reads, nb, 0)
+        loc = m.finalize()
+        eng = D.GpuEngine(m, torch, dev)
+        eng.reset()
+        drv = D.DistributedMdbg(eng, D.ThreadComm(D.ThreadWorld(1), 0, torch), torch)
+        drv.ingest_device(db, do, n_reads, nb, 0)
+        part = drv.finalize()
+        tab = D.gather_node_table([{f: (v.cpu().numpy().view(np.uint64) if hasattr(v, "cpu") else v) for f, v in part.items()}])
+    assert tab["n_nodes"] == loc["n_nodes"] and tab["n_nodes_before"] == loc["n_nodes_before"]
+    assert np.array_equal(tab["keys"], loc["keys"])
+    for f in ("index", "abundance", "seqlen", "reversed", "src_read", "src_start", "src_end"):
+        assert np.array_equal(tab[f].astype(np.uint64), loc[f].astype(np.uint64)), f
+    assert np.array_equal(tab["shift_full"], loc["shift_full"])
