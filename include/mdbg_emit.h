@@ -1,0 +1,50 @@
+/* mdbg_emit.h — host-side graph emitter above the node table of mdbg_hip.h (plain C ABI, no GPU involved).
+ *
+ * Mirrors what rust-mdbg's main() does AFTER the hot path with the read-only node view (paths in the rust-mdbg tree):
+ *   mdbg_emit_edges            (k-1)-mer index, 4-orientation overlap test, presimp            src/main.rs:1014-1117
+ *   mdbg_emit_write_gfa        "H\tVN:Z:1.0", S-lines, L-lines                                 src/main.rs:1011,1021,1095,1113
+ *   mdbg_seqfile_*             {prefix}.{tid}.sequences: header + one line per solid node,     src/main.rs:614-630,693-708
+ *                              LZ4 frame (stored blocks) readable by src/to_basespace.rs:62-66,203-241
+ * The reference iterates its DashMap in arbitrary order; here nodes are visited in index order, so files are deterministic.
+ */
+#ifndef MDBG_EMIT_H
+#define MDBG_EMIT_H
+
+#include <stdint.h>
+
+#include "mdbg_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdbg_emit mdbg_emit; /* owns the edge buffers it hands out */
+
+typedef struct mdbg_edges {
+    uint64_t n;              /* number of L-lines ("Number of mdBG edges", main.rs:1118) */
+    const uint32_t* n1;      /* DbgEntry.index of the source node */
+    const uint8_t* o1;       /* '+' or '-' */
+    const uint32_t* n2;
+    const uint8_t* o2;
+    const uint32_t* overlap; /* min(n1.seqlen - shift, n2.seqlen - 1), main.rs:1091-1092 */
+    uint64_t presimp_removed; /* "Pre-simp = ..: N edges removed" (main.rs:1120) */
+} mdbg_edges;
+
+mdbg_emit* mdbg_emit_create(void);
+void mdbg_emit_destroy(mdbg_emit* e);
+/* nodes: HOST arrays (as returned by mdbg_finalize).  presimp: --presimp, reference default 0.01 (main.rs:449). */
+int mdbg_emit_edges(mdbg_emit* e, const mdbg_nodes* nodes, float presimp, mdbg_edges* out);
+int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nodes, const mdbg_edges* edges);
+
+/* .sequences writer.  Open once, feed every batch of reads that was ingested (same buffers / ordinals as
+ * mdbg_ingest_batch): the nodes whose A-th sighting lies in that batch get their line.  Close to finish the frame. */
+typedef struct mdbg_seqfile mdbg_seqfile;
+mdbg_seqfile* mdbg_seqfile_open(const char* path, uint32_t k, uint32_t l, int* err);
+int mdbg_seqfile_write_batch(mdbg_seqfile* f, const mdbg_nodes* nodes, const uint8_t* bases, const uint64_t* offsets,
+                             uint64_t n_reads, uint64_t first_read_ordinal);
+int mdbg_seqfile_close(mdbg_seqfile* f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,202 @@
+// mdbg_emit.cpp — host-side graph emitter (libmdbg_emit.so).  See include/mdbg_emit.h.
+//
+// Written against rust-mdbg src/main.rs:1006-1121 (edges, presimp, GFA) and :614-630,693-708 (.sequences); no code is
+// shared with the CPU oracle.  Data structures differ from the reference (flat arrays + one hash map from a (k-1)-mer
+// to the nodes listing it), the emitted multiset of edges is the same.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/mdbg_emit.h"
+
+namespace {
+
+typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
+
+struct Span { const u64* p; u32 n; bool rev; };           // a (k-1)-mer view, read forwards or backwards
+inline u64 at(const Span& s, u32 i) { return s.rev ? s.p[s.n - 1 - i] : s.p[i]; }
+inline bool equal(const Span& a, const Span& b) { for (u32 i = 0; i < a.n; ++i) if (at(a, i) != at(b, i)) return false; return true; }
+// KmerVec::normalize().0 of a span: the lexicographically smaller of the span and its reversal (ties: reversal)
+inline Span normalized(const Span& s) {
+    for (u32 i = 0; i < s.n; ++i) { u64 a = at(s, i), b = at(s, s.n - 1 - i); if (a < b) return s; if (a > b) break; }
+    Span r = s; r.rev = !s.rev; return r;
+}
+inline u64 hash_span(const Span& s) {
+    u64 h = 0x9E3779B97F4A7C15ull;
+    for (u32 i = 0; i < s.n; ++i) { h ^= at(s, i); h *= 0xff51afd7ed558ccdull; h ^= h >> 29; }
+    return h;
+}
+
+// ---- XXH32 (for the LZ4 frame header checksum) ------------------------------------------------------
+inline u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+u32 xxh32(const u8* p, size_t len, u32 seed) {
+    const u32 P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const u8* end = p + len; u32 h;
+    auto rd = [](const u8* q) { u32 v; memcpy(&v, q, 4); return v; };
+    if (len >= 16) {
+        u32 v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do { v1 = rotl32(v1 + rd(p) * P2, 13) * P1; p += 4; v2 = rotl32(v2 + rd(p) * P2, 13) * P1; p += 4;
+             v3 = rotl32(v3 + rd(p) * P2, 13) * P1; p += 4; v4 = rotl32(v4 + rd(p) * P2, 13) * P1; p += 4; } while (p + 16 <= end);
+        h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else h = seed + P5;
+    h += (u32)len;
+    while (p + 4 <= end) { h = rotl32(h + rd(p) * P3, 17) * P4; p += 4; }
+    while (p < end) { h = rotl32(h + (*p) * P5, 11) * P1; ++p; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+
+char switch_base(char c) {                                    // src/utils.rs:10-24
+    switch (c) { case 'a': return 't'; case 'c': return 'g'; case 't': return 'a'; case 'g': return 'c'; case 'u': return 'a';
+                 case 'A': return 'T'; case 'C': return 'G'; case 'T': return 'A'; case 'G': return 'C'; case 'U': return 'A'; default: return 'N'; }
+}
+
+}  // namespace
+
+struct mdbg_emit { std::vector<u32> n1, n2, ov; std::vector<u8> o1, o2; };
+
+struct mdbg_seqfile {
+    FILE* f = nullptr; u32 k = 0, l = 0; std::string buf;
+    // LZ4 frame, independent stored blocks of <= 4 MiB
+    bool flush_block() {
+        size_t off = 0;
+        while (off < buf.size()) {
+            const u32 n = (u32)std::min<size_t>(buf.size() - off, 4u << 20);
+            const u32 hdr = n | 0x80000000u;                  // highest bit: block is not compressed
+            if (fwrite(&hdr, 4, 1, f) != 1 || fwrite(buf.data() + off, 1, n, f) != n) return false;
+            off += n;
+        }
+        buf.clear();
+        return true;
+    }
+};
+
+extern "C" {
+
+mdbg_emit* mdbg_emit_create(void) { return new mdbg_emit(); }
+void mdbg_emit_destroy(mdbg_emit* e) { delete e; }
+
+int mdbg_emit_edges(mdbg_emit* E, const mdbg_nodes* nd, float presimp, mdbg_edges* out) {
+    if (!E || !nd || !out || nd->k < 2) return MDBG_E_PARAM;
+    const u64 n = nd->n; const u32 k = nd->k, km = k - 1;
+    E->n1.clear(); E->n2.clear(); E->ov.clear(); E->o1.clear(); E->o2.clear();
+    // km_index (main.rs:1017-1033): every node is listed under its normalized prefix AND under its normalized suffix
+    // (twice in the same list when both coincide).  Buckets are keyed by a hash of the (k-1)-mer; each entry remembers
+    // which listing it is, and a query compares the full (k-1)-mer, so hash collisions cannot add or drop a listing.
+    struct Listing { u32 row; u8 suffix; };
+    std::unordered_map<u64, std::vector<Listing>> index;
+    index.reserve(n * 2);
+    auto key_of = [&](u64 row, bool suffix) { return normalized(Span{nd->keys + row * k + (suffix ? 1 : 0), km, false}); };
+    for (u64 i = 0; i < n; ++i) {
+        index[hash_span(key_of(i, false))].push_back({(u32)i, 0});
+        index[hash_span(key_of(i, true))].push_back({(u32)i, 1});
+    }
+    struct Pot { u32 row; char o1, o2; };
+    std::vector<Pot> pot;
+    struct Ed { u32 r1; char o1; u32 r2; char o2; u32 ov; };
+    std::vector<Ed> cand;
+    std::unordered_set<u64> removed;
+    u64 presimp_removed = 0;
+    for (u64 i = 0; i < n; ++i) {                              // main.rs:1041
+        const u64* k1 = nd->keys + i * k;
+        const Span n1_suf{k1 + 1, km, false}, n1_pre{k1, km, false};
+        const Span rev1_suf{k1, km, true};                     // suffix of reversed n1 = its prefix read backwards
+        const Span qk[2] = {normalized(n1_suf), normalized(n1_pre)};   // key1 = suffix, key2 = prefix (main.rs:1051-1053)
+        for (int q = 0; q < 2; ++q) {
+            auto it = index.find(hash_span(qk[q]));
+            if (it == index.end()) continue;
+            pot.clear();
+            for (const Listing& li : it->second) {
+                if (!equal(key_of(li.row, li.suffix != 0), qk[q])) continue;
+                const u64* k2 = nd->keys + (u64)li.row * k;
+                const Span n2_pre{k2, km, false}, rev2_pre{k2 + 1, km, true};   // prefix of reversed n2 = its suffix read backwards
+                if (equal(n1_suf, n2_pre)) pot.push_back({li.row, '+', '+'});    // main.rs:1062-1075
+                if (equal(n1_suf, rev2_pre)) pot.push_back({li.row, '+', '-'});
+                if (equal(rev1_suf, n2_pre)) pot.push_back({li.row, '-', '+'});
+                if (equal(rev1_suf, rev2_pre)) pot.push_back({li.row, '-', '-'});
+            }
+            if (pot.empty()) continue;
+            u16 amax = 0; for (auto& p : pot) amax = std::max(amax, nd->abundance[p.row]);
+            const u16 aref = std::min(amax, nd->abundance[i]);
+            for (auto& p : pot) {                              // main.rs:1078-1102
+                if (presimp > 0.0f && pot.size() >= 2 && (float)nd->abundance[p.row] < presimp * (float)aref) {
+                    ++presimp_removed; removed.insert(((u64)nd->index[i] << 32) | nd->index[p.row]); continue;
+                }
+                const u16 shift = p.o1 == '+' ? nd->shift[2 * i] : nd->shift[2 * i + 1];
+                const u32 ov = std::min((u32)(nd->seqlen[i] - (u32)shift), (u32)(nd->seqlen[p.row] - 1u));
+                cand.push_back({(u32)i, p.o1, p.row, p.o2, ov});
+            }
+        }
+    }
+    for (auto& e : cand) {                                     // main.rs:1104-1115
+        const u64 a = nd->index[e.r1], b = nd->index[e.r2];
+        if (presimp > 0.0f && (removed.count((a << 32) | b) || removed.count((b << 32) | a))) continue;
+        E->n1.push_back((u32)a); E->o1.push_back((u8)e.o1); E->n2.push_back((u32)b); E->o2.push_back((u8)e.o2); E->ov.push_back(e.ov);
+    }
+    out->n = E->n1.size(); out->n1 = E->n1.data(); out->o1 = E->o1.data(); out->n2 = E->n2.data(); out->o2 = E->o2.data();
+    out->overlap = E->ov.data(); out->presimp_removed = presimp_removed;
+    return MDBG_OK;
+}
+
+int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nd, const mdbg_edges* ed) {
+    if (!path || !nd) return MDBG_E_PARAM;
+    FILE* f = fopen(path, "wb");
+    if (!f) return MDBG_E_PARAM;
+    fprintf(f, "H\tVN:Z:1.0\n");                                                                   // main.rs:1011
+    for (u64 i = 0; i < nd->n; ++i) fprintf(f, "S\t%u\t*\tLN:i:%u\tKC:i:%u\n", nd->index[i], nd->seqlen[i], (unsigned)nd->abundance[i]);   // :1021
+    if (ed) for (u64 i = 0; i < ed->n; ++i) fprintf(f, "L\t%u\t%c\t%u\t%c\t%uM\n", ed->n1[i], ed->o1[i], ed->n2[i], ed->o2[i], ed->overlap[i]);   // :1095
+    return fclose(f) == 0 ? MDBG_OK : MDBG_E_PARAM;
+}
+
+mdbg_seqfile* mdbg_seqfile_open(const char* path, uint32_t k, uint32_t l, int* err) {
+    FILE* f = path ? fopen(path, "wb") : nullptr;
+    if (!f) { if (err) *err = MDBG_E_PARAM; return nullptr; }
+    mdbg_seqfile* s = new mdbg_seqfile(); s->f = f; s->k = k; s->l = l;
+    // LZ4 frame header: magic, FLG (version 01, independent blocks), BD (4 MiB blocks), header checksum
+    u8 hdr[7] = {0x04, 0x22, 0x4D, 0x18, 0x60, 0x70, 0};
+    hdr[6] = (u8)((xxh32(hdr + 4, 2, 0) >> 8) & 0xFF);
+    fwrite(hdr, 1, 7, f);
+    char b[256];
+    snprintf(b, sizeof b, "# k = %u\n# l = %u\n", k, l); s->buf += b;                               // main.rs:625-628
+    s->buf += "# Structure of remaining of the file:\n";
+    s->buf += "# [node name]\t[list of minimizers]\t[sequence of node]\t[abundance]\t[origin]\t[shift]\n";
+    if (err) *err = MDBG_OK;
+    return s;
+}
+
+int mdbg_seqfile_write_batch(mdbg_seqfile* s, const mdbg_nodes* nd, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t first) {
+    if (!s || !nd || !offsets || (n_reads && !bases && offsets[n_reads])) return MDBG_E_PARAM;
+    const u32 k = nd->k;
+    char num[64];
+    for (u64 i = 0; i < nd->n; ++i) {
+        const u64 r = nd->src_read[i];
+        if (r < first || r >= first + n_reads) continue;
+        const u64 ro = offsets[r - first], a = nd->src_start[i], b = nd->src_end[i];
+        if (ro + b > offsets[r - first + 1] || a > b) return MDBG_E_PARAM;
+        snprintf(num, sizeof num, "%u\t[", nd->index[i]); s->buf += num;                           // main.rs:702: {index}\t{node:?}\t{seq}\t*\t{origin}\t{shift:?}
+        for (u32 j = 0; j < k; ++j) { snprintf(num, sizeof num, j ? ", %llu" : "%llu", (unsigned long long)nd->keys[i * k + j]); s->buf += num; }
+        s->buf += "]\t";
+        if (nd->reversed[i]) for (u64 p = b; p > a; --p) s->buf += switch_base((char)bases[ro + p - 1]);   // utils::revcomp, main.rs:701
+        else s->buf.append((const char*)bases + ro + a, b - a);
+        snprintf(num, sizeof num, "\t*\t*\t(%llu, %llu)\n", (unsigned long long)nd->shift_full[2 * i], (unsigned long long)nd->shift_full[2 * i + 1]);
+        s->buf += num;
+        if (s->buf.size() >= (4u << 20) && !s->flush_block()) return MDBG_E_PARAM;
+    }
+    return MDBG_OK;
+}
+
+int mdbg_seqfile_close(mdbg_seqfile* s) {
+    if (!s) return MDBG_E_PARAM;
+    bool ok = s->flush_block();
+    const u32 endmark = 0;
+    ok = ok && fwrite(&endmark, 4, 1, s->f) == 1;
+    ok = (fclose(s->f) == 0) && ok;
+    delete s;
+    return ok ? MDBG_OK : MDBG_E_PARAM;
+}
+
+}  // extern "C"

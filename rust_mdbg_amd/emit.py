@@ -1,0 +1,111 @@
+"""ctypes binding of include/mdbg_emit.h — the host-side emitter rust-mdbg keeps after the hot path
+(edges + presimp, GFA S/L lines, .sequences in an LZ4 frame; src/main.rs:1006-1121, 614-630, 693-708)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .api import Nodes
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Edges(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n1", C.POINTER(C.c_uint32)), ("o1", C.POINTER(C.c_uint8)), ("n2", C.POINTER(C.c_uint32)),
+                ("o2", C.POINTER(C.c_uint8)), ("overlap", C.POINTER(C.c_uint32)), ("presimp_removed", C.c_uint64)]
+
+
+EXPORTS = ["mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
+           "mdbg_seqfile_write_batch", "mdbg_seqfile_close"]
+
+
+def load_library():
+    global _LIB
+    if _LIB is None:
+        p = os.path.join(_HERE, "libmdbg_emit.so")
+        if not os.path.exists(p):
+            raise ImportError("libmdbg_emit.so not built; run `make -C rust_mdbg_amd/csrc`")
+        L = C.CDLL(p)
+        vp = C.c_void_p
+        L.mdbg_emit_create.restype = vp
+        L.mdbg_emit_destroy.argtypes = [vp]
+        L.mdbg_emit_edges.argtypes = [vp, C.POINTER(Nodes), C.c_float, C.POINTER(Edges)]
+        L.mdbg_emit_write_gfa.argtypes = [C.c_char_p, C.POINTER(Nodes), C.POINTER(Edges)]
+        L.mdbg_seqfile_open.restype = vp
+        L.mdbg_seqfile_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
+        L.mdbg_seqfile_write_batch.argtypes = [vp, C.POINTER(Nodes), vp, vp, C.c_uint64, C.c_uint64]
+        L.mdbg_seqfile_close.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+class NodeTable:
+    """host node table (dict of numpy arrays as returned by Mdbg.finalize) viewed as a C `mdbg_nodes`"""
+
+    def __init__(self, nodes):
+        self.keep = {f: np.ascontiguousarray(nodes[f], dtype=t) for f, t in (
+            ("keys", np.uint64), ("index", np.uint32), ("abundance", np.uint16), ("seqlen", np.uint32), ("shift", np.uint16),
+            ("shift_full", np.uint64), ("src_read", np.uint64), ("src_start", np.uint64), ("src_end", np.uint64), ("reversed", np.uint8))}
+        k = self.keep["keys"].shape[1] if self.keep["keys"].ndim == 2 else int(nodes.get("k", 0))
+        n = len(self.keep["index"])
+        P = lambda f, t: self.keep[f].ctypes.data_as(C.POINTER(t))
+        self.c = Nodes(n=n, k=k, keys=P("keys", C.c_uint64), index=P("index", C.c_uint32), abundance=P("abundance", C.c_uint16),
+                       seqlen=P("seqlen", C.c_uint32), shift=P("shift", C.c_uint16), shift_full=P("shift_full", C.c_uint64),
+                       src_read=P("src_read", C.c_uint64), src_start=P("src_start", C.c_uint64), src_end=P("src_end", C.c_uint64),
+                       reversed=P("reversed", C.c_uint8), n_distinct=int(nodes.get("n_nodes_before", 0)), n_wrapped=int(nodes.get("n_wrapped", 0)))
+
+
+class Emitter:
+    def __init__(self):
+        self.L = load_library()
+        self.h = self.L.mdbg_emit_create()
+        self._edges = None
+
+    def edges(self, nodes, presimp=0.01):
+        """-> dict(n1, o1, n2, o2, overlap, presimp_removed) — the L-lines of the graph"""
+        self.nt = nodes if isinstance(nodes, NodeTable) else NodeTable(nodes)
+        e = Edges()
+        rc = self.L.mdbg_emit_edges(self.h, C.byref(self.nt.c), presimp, C.byref(e))
+        if rc:
+            raise RuntimeError("mdbg_emit_edges failed: %d" % rc)
+        self._edges = e
+        g = lambda p, t: np.ctypeslib.as_array(p, shape=(e.n,)).astype(t, copy=True) if e.n else np.zeros(0, t)
+        return dict(n1=g(e.n1, np.uint32), o1=g(e.o1, np.uint8), n2=g(e.n2, np.uint32), o2=g(e.o2, np.uint8), overlap=g(e.overlap, np.uint32),
+                    presimp_removed=int(e.presimp_removed))
+
+    def write_gfa(self, path, nodes=None):
+        nt = self.nt if nodes is None else (nodes if isinstance(nodes, NodeTable) else NodeTable(nodes))
+        rc = self.L.mdbg_emit_write_gfa(path.encode(), C.byref(nt.c), C.byref(self._edges) if self._edges is not None else None)
+        if rc:
+            raise RuntimeError("mdbg_emit_write_gfa failed: %d" % rc)
+
+    def write_sequences(self, path, nodes, l, batches):
+        """batches: iterable of (bases u8 array, offsets u64 array, first_read_ordinal) — what was ingested"""
+        nt = nodes if isinstance(nodes, NodeTable) else NodeTable(nodes)
+        err = C.c_int()
+        f = self.L.mdbg_seqfile_open(path.encode(), nt.c.k, l, C.byref(err))
+        if not f:
+            raise RuntimeError("mdbg_seqfile_open failed: %d" % err.value)
+        try:
+            for bases, offsets, first in batches:
+                bases = np.ascontiguousarray(bases, dtype=np.uint8)
+                offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+                rc = self.L.mdbg_seqfile_write_batch(f, C.byref(nt.c), bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, first)
+                if rc:
+                    raise RuntimeError("mdbg_seqfile_write_batch failed: %d" % rc)
+        finally:
+            rc = self.L.mdbg_seqfile_close(f)
+        if rc:
+            raise RuntimeError("mdbg_seqfile_close failed: %d" % rc)
+
+    def close(self):
+        if self.h:
+            self.L.mdbg_emit_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -24,6 +24,17 @@ def test_library_exports_every_declared_symbol():
     assert L.mdbg_strerror(0) == b"ok" and b"ACGTN" in L.mdbg_strerror(-2)
 
 
+def test_emit_library_exports_every_declared_symbol():
+    from rust_mdbg_amd import emit
+    h = open(os.path.join(ROOT, "include", "mdbg_emit.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mdbg_(?:emit|seqfile)_[a-z_0-9]+)\s*\(", h)))
+    L = emit.load_library()
+    assert syms == sorted(emit.EXPORTS)
+    for s in syms:
+        assert hasattr(L, s), s
+
+
 def test_struct_layouts_match_header():
     import ctypes as C
     from rust_mdbg_amd import api

@@ -35,6 +35,11 @@ def test_config2_100k_reads_bit_exact_nodes_and_edges():
     edges, removed = O.edges_from_nodes(got)
     exp_edges = sorted(zip(exp["edge_n1"].tolist(), exp["edge_o1"].tolist(), exp["edge_n2"].tolist(), exp["edge_o2"].tolist(), exp["edge_overlap"].tolist()))
     assert edges == exp_edges and len(edges) == exp["n_edges"] > 100000 and removed == exp["presimp_removed"]
+    # ... and the product's own host emitter (libmdbg_emit.so) gives the same L-lines
+    from rust_mdbg_amd import emit as E
+    pe = E.Emitter().edges(got)
+    assert sorted(zip(pe["n1"].tolist(), pe["o1"].tolist(), pe["n2"].tolist(), pe["o2"].tolist(), pe["overlap"].tolist())) == exp_edges
+    assert pe["presimp_removed"] == exp["presimp_removed"]
 
 
 def test_config3_size_properties():
