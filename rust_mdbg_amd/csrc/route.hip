@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void route_kernel(RouteArgs a) {
 
 // compact list of occupied slots: m1, A-th ordinal (~0 when the node fails the abundance filter), count, slot id.
 // One allocation atomic per 1024-thread block (same-address atomics serialise).
-__global__ __launch_bounds__(1024) void export_kernel(const Slot* __restrict__ tab, u64 cap, const u64* __restrict__ mx, u32 A, u64* __restrict__ counter,
+__global__ __launch_bounds__(1024) void export_kernel(FinArgs F, u64* __restrict__ counter,
                                                       u64* __restrict__ o_m1, u64* __restrict__ o_ma, u32* __restrict__ o_count, u64* __restrict__ o_slot) {
+    const Slot* tab = F.tab; const u64 cap = F.cap;
     __shared__ u32 wcnt[16];
     __shared__ u64 bbase;
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,9 +69,8 @@ __global__ __launch_bounds__(1024) void export_kernel(const Slot* __restrict__ t
     __syncthreads();
     if (occ) {
         const u64 idx = bbase + wcnt[wv] + __popcll(m & ((1ull << lane) - 1));
-        const bool solid = A == 1 || (u16)e.count >= (u16)A;
-        const u64 ma = A == 1 ? e.m1 : A == 2 ? e.m2 : mx[s * (A - 2) + (A - 3)];
-        o_m1[idx] = e.m1; o_ma[idx] = solid ? ma : EMPTY; o_count[idx] = e.count; o_slot[idx] = s;
+        const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word));
+        o_m1[idx] = v.first; o_ma[idx] = v.solid ? v.ath : EMPTY; o_count[idx] = v.count; o_slot[idx] = s;
     }
 }
 
@@ -121,8 +121,8 @@ void launch_route(const RouteArgs& a, bool write, hipStream_t s) {
     if (write) hipLaunchKernelGGL(route_kernel<true>, dim3(nb), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(route_kernel<false>, dim3(nb), dim3(256), 0, s, a);
 }
-void launch_export(const Slot* tab, u64 cap, const u64* mx, u32 A, u64* counter, u64* o_m1, u64* o_ma, u32* o_count, u64* o_slot, hipStream_t s) {
-    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((cap + 1023) / 1024)), dim3(1024), 0, s, tab, cap, mx, A, counter, o_m1, o_ma, o_count, o_slot);
+void launch_export(const FinArgs& F, u64* counter, u64* o_m1, u64* o_ma, u32* o_count, u64* o_slot, hipStream_t s) {
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((F.cap + 1023) / 1024)), dim3(1024), 0, s, F, counter, o_m1, o_ma, o_count, o_slot);
 }
 void launch_resolve_mark(const FinArgs& F, const u64* ord, const u8* solid, u64 n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(resolve_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, F, ord, solid, n);

@@ -9,9 +9,11 @@
 // where `rep` points at a representative occurrence of the key (an index into the resident minimizer
 // array, or into the routed-record arena when src=1) — the k*8-byte key itself is never copied.  A
 // fingerprint hit is confirmed by comparing the full canonical key with the representative's, so the
-// table is exact.  Per node the table keeps the count and the A smallest occurrence ordinals
-// (ordinal = read ordinal << 26 | window index): the smallest gives DbgEntry.index (order of first
-// sighting), the A-th gives the sighting whose seqlen/shift the reference stores.
+// table is exact.  The occurrence that CLAIMS a slot costs exactly one atomic (the CAS): its ordinal
+// (ordinal = read ordinal << 26 | window index) is recoverable from `rep`.  Every later occurrence of the key adds 1
+// to `count` and offers its ordinal to the A smallest kept in m1, m2, mx[]; at finalize the claimer is merged back in
+// (slot_view): the smallest ordinal gives DbgEntry.index (order of first sighting), the A-th gives the sighting whose
+// seqlen/shift the reference stores, abundance = count + 1.
 #include "mdbg_dev.h"
 
 struct __attribute__((aligned(32))) Slot {
@@ -85,7 +87,8 @@ __device__ inline void push_ordinal(const TableArgs& T, u64 s, u64 x) {
 
 // find-or-claim the slot of a key given by an accessor mine(j) = canonical element j
 template <class KeyFn>
-__device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyFn mine) {
+__device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyFn mine, bool& claimed) {
+    claimed = false;
     const u64 fp = (h >> 34) & 0x3FFFFFFFull;
     const u64 myword = (fp << 34) | myword_lo;
     u64 s = h & T.mask;
@@ -93,7 +96,7 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
         u64 w = load_relaxed(&T.tab[s].word);
         if (w == EMPTY) {
             const u64 old = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)myword);
-            if (old == EMPTY) { wave_agg_inc(T.n_distinct); return s; }
+            if (old == EMPTY) { wave_agg_inc(T.n_distinct); claimed = true; return s; }
             w = old;
         }
         if ((w >> 34) == fp) {
@@ -123,9 +126,11 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     const bool rev = window_reversed(w, k);
     const u64 h = key_hash_window(w, k, rev);
     if (T.dbg & 8) { if (h == 12345) *cap_err = 2; return; }
-    const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u32 j) { return rev ? w[k - 1 - j] : w[j]; });
-    if (!(T.dbg & 1)) atomicAdd(&T.tab[s].count, 1u);
-    if (!(T.dbg & 2)) push_ordinal(T, s, ord);
+    bool claimed;
+    const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u32 j) { return rev ? w[k - 1 - j] : w[j]; }, claimed);
+    if (claimed) return;                       // the claimer is accounted for through `rep` (slot_view)
+    atomicAdd(&T.tab[s].count, 1u);
+    push_ordinal(T, s, ord);
     (void)n_windows;
 }
 
@@ -136,7 +141,9 @@ __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0
     const u32 k = T.ks.k;
     const u64* key = T.ks.arena + r * (k + 1);
     const u64 h = key_hash_canon(key, k);
-    const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u32 j) { return key[j]; });
+    bool claimed;
+    const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u32 j) { return key[j]; }, claimed);
+    if (claimed) return;
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, key[k]);
     (void)n_windows;
@@ -175,11 +182,13 @@ __global__ void rehash_kernel(const Slot* __restrict__ old, u64 old_cap, const u
 // ---- finalize --------------------------------------------------------------------------------------
 struct BatchTab {                 // batches sorted by first_ordinal (device copy)
     const u64* first_ordinal; const u32* n_reads; const u32* slot0; const u64* rank_base; u32 n;
+    const u32* by_slot0; const u64* by_slot_first;   // the same batches sorted by slot0 (= call order): slot -> read ordinal
 };
 struct FinArgs {
     const Slot* tab; u64 cap; const u64* mx; u32 A; u32 k; u32 l;
-    const u64* mh; const u32* mpos; const u64* roff;
+    const u64* mh; const u32* mpos; const u64* roff; const u32* mread; const u64* arena;
     BatchTab bt;
+    u64* solid_list; u64* solid_count;       // compact list of solid slots (fin_mark -> fin_emit)
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
     const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
     u64* sh_solid; u64* sh_wrapped; u64* sh_distinct;   // sharded counters (CTR_SHARDS u64 each)
@@ -198,23 +207,60 @@ __device__ inline void decode_ordinal(const FinArgs& F, u64 ord, u64& i, u64& D)
     i = F.roff[slot] + win;
     D = F.bt.rank_base[lo] + (i - F.roff[s0]);
 }
-__device__ inline bool slot_solid(const FinArgs& F, const Slot& e) { return F.A == 1 || (u16)e.count >= (u16)F.A; }   // src/main.rs:922-929
+// ordinal of the occurrence that claimed the slot (it did no count / ordinal atomics)
+__device__ inline u64 rep_ordinal(const FinArgs& F, u64 word) {
+    const u32 rep = (u32)word;
+    if (word & (1ull << 33)) return F.arena[(u64)rep * (F.k + 1) + F.k];
+    const u32 slot = F.mread[rep];
+    u32 lo = 0, hi = F.bt.n - 1;
+    while (lo < hi) { const u32 mid = lo + ((hi - lo + 1) >> 1); if (F.bt.by_slot0[mid] <= slot) lo = mid; else hi = mid - 1; }
+    return ((F.bt.by_slot_first[lo] + (slot - F.bt.by_slot0[lo])) << WIN_BITS) | ((u64)rep - F.roff[slot]);
+}
+struct SlotView { u32 count; u64 first, ath; bool solid; };
+// merges the claimer back in: total count, smallest ordinal, A-th smallest ordinal (valid when count >= A)
+__device__ inline SlotView slot_view(const Slot& e, u64 s, const u64* mx, u32 A, u64 r) {
+    SlotView v;
+    v.count = e.count + 1u;
+    v.first = r < e.m1 ? r : e.m1;
+    if (A == 1) v.ath = v.first;
+    else {
+        const u64 prev = A == 2 ? e.m1 : A == 3 ? e.m2 : mx[s * (A - 2) + (A - 4)];      // (A-1)-th smallest of the others
+        const u64 last = A == 2 ? e.m2 : mx[s * (A - 2) + (A - 3)];                      // A-th smallest of the others
+        v.ath = r < prev ? prev : (r < last ? r : last);
+    }
+    v.solid = A == 1 || (u16)v.count >= (u16)A;                                           // src/main.rs:922-929 (u16 abundance)
+    return v;
+}
 
-__global__ void fin_mark_kernel(FinArgs F) {
+__global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
+    __shared__ u32 wcnt[16];
+    __shared__ u64 bbase;
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     bool occ = false, solid = false, wrapped = false;
     if (s < F.cap) {
         const Slot e = F.tab[s];
         if (e.word != EMPTY) {
-            occ = true; solid = slot_solid(F, e); wrapped = e.count >= 65536u;
-            u64 i, D; decode_ordinal(F, e.m1, i, D);
+            const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word));
+            occ = true; solid = v.solid; wrapped = v.count >= 65536u;
+            u64 i, D; decode_ordinal(F, v.first, i, D);
             atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
             if (solid) atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
         }
     }
     wave_count_add(occ, F.sh_distinct);
-    wave_count_add(solid, F.sh_solid);
     wave_count_add(wrapped, F.sh_wrapped);
+    // compact list of solid slots: one allocation atomic per block
+    const u64 m = __ballot(solid);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wv] = (u32)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = 0;
+        for (int i = 0; i < 16; ++i) { const u32 c = wcnt[i]; wcnt[i] = tot; tot += c; }
+        bbase = tot ? atomicAdd((unsigned long long*)F.solid_count, (unsigned long long)tot) : 0;
+    }
+    __syncthreads();
+    if (solid) F.solid_list[bbase + wcnt[wv] + __popcll(m & ((1ull << lane) - 1))] = s;
 }
 
 // number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
@@ -226,19 +272,20 @@ __global__ void count_windows_kernel(const u64* __restrict__ roff, u32 slot0, u3
     if ((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)out, (unsigned long long)w);
 }
 
-__global__ void fin_emit_kernel(FinArgs F) {
-    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= F.cap) return;
+__global__ void fin_emit_kernel(FinArgs F, u64 n_solid) {
+    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_solid) return;
+    const u64 s = F.solid_list[q];
     const Slot e = F.tab[s];
-    if (e.word == EMPTY || !slot_solid(F, e)) return;
+    const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word));
     const u32 k = F.k;
-    u64 i1, D; decode_ordinal(F, e.m1, i1, D);
+    u64 i1, D; decode_ordinal(F, v.first, i1, D);
     const u64 below = (1ull << (D & 63)) - 1;
     const u64 n = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);            // output row
     F.o_index[n] = F.pre_first[D >> 6] + __popcll(F.bm_first[D >> 6] & below);           // NODE_INDEX order (main.rs:661)
-    F.o_abund[n] = (u16)e.count;
+    F.o_abund[n] = (u16)v.count;
     // the A-th sighting (main.rs:680-684): seqlen, shift and the sequence's origin
-    const u64 oa = F.A == 1 ? e.m1 : F.A == 2 ? e.m2 : F.mx[s * (F.A - 2) + (F.A - 3)];
+    const u64 oa = v.ath;
     u64 i, Da; decode_ordinal(F, oa, i, Da);
     const u64* w = F.mh + i; const u32* p = F.mpos + i;
     const bool rev = window_reversed(w, k);
@@ -338,8 +385,8 @@ void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* o
     hipLaunchKernelGGL(count_windows_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, roff, slot0, n_reads, k, out);
 }
 void launch_fin_mark(const FinArgs& F, hipStream_t s) {
-    hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 255) / 256)), dim3(256), 0, s, F);
+    hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 1023) / 1024)), dim3(1024), 0, s, F);
 }
-void launch_fin_emit(const FinArgs& F, hipStream_t s) {
-    hipLaunchKernelGGL(fin_emit_kernel, dim3((unsigned)((F.cap + 255) / 256)), dim3(256), 0, s, F);
+void launch_fin_emit(const FinArgs& F, u64 n_solid, hipStream_t s) {
+    if (n_solid) hipLaunchKernelGGL(fin_emit_kernel, dim3((unsigned)((n_solid + 255) / 256)), dim3(256), 0, s, F, n_solid);
 }
