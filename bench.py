@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
+    ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
     return ap.parse_args()
 
 
@@ -116,7 +117,7 @@ def main():
         from rust_mdbg_amd import dist as D
         dev = torch.device("cuda", local_rank)
         engine = D.GpuEngine(m, torch, dev)
-        runner = D.DistributedMdbg(engine, D.TorchDistComm(dist, torch, dev), torch)
+        runner = D.DistributedMdbg(engine, D.TorchDistComm(dist, torch, dev), torch, profile=args.profile_dist)
 
     def step():
         if routed:
@@ -138,6 +139,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if routed:
+        runner.times = {}
     t0 = time.perf_counter()
     n_nodes = 0
     for _ in range(args.steps):
@@ -154,6 +157,9 @@ def main():
     else:
         total_bases = n_bases
     st = m.stats()          # stats of the last step only (reset clears the timers)
+    if routed and args.profile_dist and rank == 0:
+        n = args.steps
+        print("[dist profile, ms per step] " + ", ".join("%s=%.2f" % (k, v / n) for k, v in runner.times.items()), file=sys.stderr)
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = total_bases * args.steps / dt / 1e9

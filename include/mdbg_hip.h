@@ -137,19 +137,34 @@ int mdbg_insert_resident(mdbg_ctx* ctx);
  * (the exchanges themselves are done by the host driver over RCCL, see rust_mdbg_amd/dist.py)
  *
  * Key-range routing: packs every k-min-mer occurrence of the sketches not yet inserted into `world` (<= 64)
- * destination buckets, owner = mulhi64(keyhash, world).  One record is k+1 u64: canonical key, then the global
- * ordinal (read ordinal << 26 | window index).  *d_records receives a DEVICE pointer to the bucketed records
+ * destination buckets, owner = mulhi64(keyhash, world).  One record is k+2 u64: canonical key, the global ordinal
+ * (read ordinal << 26 | window index), the key hash.  *d_records receives a DEVICE pointer to the bucketed records
  * (library-owned, valid until the next route_pack/reset), counts[world] (HOST) the records per destination. */
 int mdbg_route_pack(mdbg_ctx* ctx, uint32_t world, const uint64_t** d_records, uint64_t* counts);
-/* Owner side: insert records received from peers (DEVICE memory, k+1 u64 each).  The records are copied into the
- * context's arena, so the caller's buffer may be released when the call returns.  After the first call the
+/* Owner side: room for n more records at the tail of the context's arena (DEVICE pointer, valid until the next
+ * arena_reserve / insert_records / reset): receive the all-to-all straight into it, then pass the same pointer to
+ * mdbg_insert_records and no copy is made. */
+int mdbg_arena_reserve(mdbg_ctx* ctx, uint64_t n_records, uint64_t** d_tail);
+/* Owner side: insert records received from peers (DEVICE memory, k+2 u64 each).  Unless they already sit in the arena
+ * tail (mdbg_arena_reserve) they are copied into it, so the caller's buffer may be released when the call returns.  After the first call the
  * context is in routed mode: mdbg_finalize is replaced by the four calls below. */
 int mdbg_insert_records(mdbg_ctx* ctx, const uint64_t* d_records, uint64_t n_records);
-/* Owner side: compact view of the table, one entry per distinct k-min-mer (DEVICE pointers, library-owned):
- * first[n] = smallest ordinal (first sighting), ath[n] = A-th smallest ordinal or ~0 when the node fails the abundance
- * filter (src/main.rs:922-929), count[n] = occurrences, slot[n] = handle for mdbg_routed_keys. */
-int mdbg_routed_export(mdbg_ctx* ctx, uint64_t* n, const uint64_t** d_first, const uint64_t** d_ath, const uint32_t** d_count,
-                       const uint64_t** d_slot);
+/* Owner side: the table's entries as two query lists, each bucketed by the rank that has to answer (DEVICE pointers,
+ * library-owned until the next export / finalize / reset).  Ranks are described by spans of read ordinals sorted by
+ * start: span i = [span_lo[i], span_lo[i+1]) belongs to rank span_rank[i].
+ *   list A, one entry per distinct k-min-mer, bucketed by the rank of its FIRST sighting: d_first[n_all] (ordinal),
+ *           d_solid[n_all] (1 = passes the abundance filter, src/main.rs:922-929); counts_all[r] entries for rank r.
+ *   list S, one entry per solid k-min-mer, bucketed by the rank of its A-th sighting: d_ath[n_solid] (ordinal),
+ *           d_count[n_solid] (occurrences), d_slot[n_solid] (handle for mdbg_routed_keys), d_idx_all[n_solid] (position of
+ *           the same k-min-mer in list A); counts_solid[r] entries for rank r. */
+typedef struct mdbg_routed_lists {
+    uint64_t n_all, n_solid;
+    const uint64_t* d_first; const uint8_t* d_solid;
+    const uint64_t* d_ath; const uint32_t* d_count; const uint64_t* d_slot; const uint64_t* d_idx_all;
+    uint64_t counts_all[64], counts_solid[64];
+} mdbg_routed_lists;
+int mdbg_routed_export(mdbg_ctx* ctx, uint32_t world, const uint64_t* span_lo, const uint32_t* span_rank, uint32_t n_spans,
+                       mdbg_routed_lists* out);
 /* Generator side (the rank whose reads the ordinals belong to): for n first-sighting ordinals (DEVICE) with their solid
  * flags, rank_first[i] = number of queried ordinals smaller than ord[i] (-> DbgEntry.index once the totals of the ranks
  * holding earlier reads are added), rank_solid[i] = the same among solid ones (-> row of the node in index order).

@@ -43,6 +43,12 @@ class Stats(C.Structure):
                 ("n_sketch_tile_launches", C.c_uint64), ("n_sketch_tile_bases", C.c_uint64), ("reserved", C.c_uint64 * 5)]
 
 
+class RoutedLists(C.Structure):
+    _fields_ = [("n_all", C.c_uint64), ("n_solid", C.c_uint64), ("d_first", C.c_void_p), ("d_solid", C.c_void_p), ("d_ath", C.c_void_p),
+                ("d_count", C.c_void_p), ("d_slot", C.c_void_p), ("d_idx_all", C.c_void_p), ("counts_all", C.c_uint64 * 64),
+                ("counts_solid", C.c_uint64 * 64)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_reads", C.c_uint64), ("mean_len", C.c_uint32),
                 ("sd_len", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("err_ppm", C.c_uint32),
@@ -52,7 +58,7 @@ class SynthParams(C.Structure):
 EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
-           "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys"]
+           "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve"]
 
 
 def lib_path():
@@ -96,10 +102,11 @@ def load_library():
     L.mdbg_last_error.restype = C.c_char_p
     L.mdbg_last_error.argtypes = [vp]
     L.mdbg_route_pack.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
-    L.mdbg_routed_export.argtypes = [vp, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.mdbg_routed_export.argtypes = [vp, u32, vp, vp, u32, C.POINTER(RoutedLists)]
     L.mdbg_resolve_first.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(u64), C.POINTER(u64)]
     L.mdbg_resolve_meta.argtypes = [vp, vp, u64, vp]
     L.mdbg_routed_keys.argtypes = [vp, vp, u64, vp]
+    L.mdbg_arena_reserve.argtypes = [vp, u64, C.POINTER(vp)]
     L.mdbg_insert_records.argtypes = [vp, vp, u64]
     L.mdbg_sync.argtypes = [vp]
     L.mdbg_copy_to_host.argtypes = [vp, vp, vp, u64]
@@ -108,7 +115,7 @@ def load_library():
     for f in ("mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_device", "mdbg_insert_resident", "mdbg_sketch_only",
               "mdbg_finalize", "mdbg_finalize_device", "mdbg_reset", "mdbg_get_stats", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync",
               "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device", "mdbg_routed_export", "mdbg_resolve_first",
-              "mdbg_resolve_meta", "mdbg_routed_keys"):
+              "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve"):
         getattr(L, f).restype = C.c_int
     _LIB = L
     return L
@@ -200,21 +207,28 @@ class Mdbg:
 
     # --- multi-GPU stage calls (raw device pointers; see rust_mdbg_amd/dist.py for the driver) ---
     def route_pack(self, world):
-        """-> (device pointer to bucketed records of k+1 u64, [records per destination])"""
+        """-> (device pointer to bucketed records of k+2 u64, [records per destination])"""
         ptr = C.c_void_p()
         counts = (C.c_uint64 * 64)()
         self._chk(self.L.mdbg_route_pack(self.h, world, C.byref(ptr), counts))
         return ptr.value or 0, [int(counts[i]) for i in range(world)]
 
+    def arena_reserve(self, n):
+        """-> device pointer where n more routed records (k+2 u64 each) may be received in place"""
+        ptr = C.c_void_p()
+        self._chk(self.L.mdbg_arena_reserve(self.h, n, C.byref(ptr)))
+        return ptr.value or 0
+
     def insert_records(self, d_records, n):
         self._chk(self.L.mdbg_insert_records(self.h, d_records, n))
 
-    def routed_export(self):
-        """-> (n, d_first, d_ath, d_count, d_slot) device pointers"""
-        n = C.c_uint64()
-        a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self._chk(self.L.mdbg_routed_export(self.h, C.byref(n), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return n.value, a.value or 0, b.value or 0, c.value or 0, d.value or 0
+    def routed_export(self, world, span_lo, span_rank):
+        """owner side: the two query lists bucketed by answering rank -> RoutedLists (device pointers + host counts)"""
+        lo = np.ascontiguousarray(span_lo, dtype=np.uint64)
+        rk = np.ascontiguousarray(span_rank, dtype=np.uint32)
+        out = RoutedLists()
+        self._chk(self.L.mdbg_routed_export(self.h, world, lo.ctypes.data, rk.ctypes.data, len(lo), C.byref(out)))
+        return out
 
     def resolve_first(self, d_ord, d_solid, n, d_rank_first, d_rank_solid):
         tf, ts = C.c_uint64(), C.c_uint64()

@@ -28,7 +28,7 @@ constexpr u64 HMUL = 0x9E3779B97F4A7C15ull;
 
 struct KeySrc {                   // where representative keys live
     const u64* mh;                // resident minimizer hashes (src = 0): key = mh[rep .. rep+k), orientation in the slot word
-    const u64* arena;             // routed records (src = 1): key = arena[rep*(k+1) .. +k), already canonical
+    const u64* arena;             // routed records (src = 1), k+2 u64 each: key = arena[rep*(k+2) .. +k), already canonical
     u32 k;
 };
 
@@ -37,7 +37,7 @@ __device__ inline u64 load_relaxed(const u64* p) { return __hip_atomic_load(p, _
 // canonical element j of the key a slot word stands for
 __device__ inline u64 rep_elem(const KeySrc& ks, u64 word, u32 j) {
     const u32 rep = (u32)word;
-    if (word & (1ull << 33)) return ks.arena[(u64)rep * (ks.k + 1) + j];
+    if (word & (1ull << 33)) return ks.arena[(u64)rep * (ks.k + 2) + j];
     return (word & (1ull << 32)) ? ks.mh[(u64)rep + ks.k - 1 - j] : ks.mh[(u64)rep + j];
 }
 
@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     (void)n_windows;
 }
 
-// routed records (k canonical u64 + ordinal), already copied into the arena at record index r0..
+// routed records (k canonical u64, ordinal, key hash) sitting in the arena at record index r0..
 __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0, u64 r1, u64* __restrict__ n_windows) {
     const u64 r = r0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= r1) return;
     const u32 k = T.ks.k;
-    const u64* key = T.ks.arena + r * (k + 1);
-    const u64 h = key_hash_canon(key, k);
+    const u64* key = T.ks.arena + r * (k + 2);
+    const u64 h = key[k + 1];                  // computed by the sender (route_count_kernel)
     bool claimed;
     const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u32 j) { return key[j]; }, claimed);
     if (claimed) return;
@@ -210,7 +210,7 @@ __device__ inline void decode_ordinal(const FinArgs& F, u64 ord, u64& i, u64& D)
 // ordinal of the occurrence that claimed the slot (it did no count / ordinal atomics)
 __device__ inline u64 rep_ordinal(const FinArgs& F, u64 word) {
     const u32 rep = (u32)word;
-    if (word & (1ull << 33)) return F.arena[(u64)rep * (F.k + 1) + F.k];
+    if (word & (1ull << 33)) return F.arena[(u64)rep * (F.k + 2) + F.k];
     const u32 slot = F.mread[rep];
     u32 lo = 0, hi = F.bt.n - 1;
     while (lo < hi) { const u32 mid = lo + ((hi - lo + 1) >> 1); if (F.bt.by_slot0[mid] <= slot) lo = mid; else hi = mid - 1; }

@@ -8,7 +8,7 @@ that generated the read in question (two more, small, all-to-alls at finalize).
 
 The driver only moves tensors; all compute is in the engine (GpuEngine = libmdbg_hip.so through its C ABI).
 Communicators: TorchDistComm (RCCL on GPUs, gloo on CPU) and ThreadComm (several ranks inside one process, for tests).
-All tensors are int64 (u64 values bit-cast); ~0 appears as -1.
+All tensors are int64 (u64 values bit-cast); ~0 appears as -1.  A routed record is k+2 values: key[k], ordinal, key hash.
 """
 import threading
 
@@ -27,8 +27,9 @@ class TorchDistComm:
         self.dist, self.torch, self.device, self.max_bytes = dist, torch, device, max_bytes
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def alltoallv(self, send, counts):
-        """send: [n, ...] rows grouped by destination; counts[d] rows go to rank d -> (recv rows, recv counts)"""
+    def alltoallv(self, send, counts, alloc=None):
+        """send: [n, ...] rows grouped by destination; counts[d] rows go to rank d -> (recv rows, recv counts).
+        alloc(n_rows), if given, provides the receive tensor (e.g. a view of the engine's record arena: no copy later)"""
         t, dist = self.torch, self.dist
         counts = [int(c) for c in counts]
         sc = t.tensor(counts, dtype=t.int64, device=self.device)
@@ -36,7 +37,7 @@ class TorchDistComm:
         dist.all_to_all_single(rc, sc)
         rcl = [int(x) for x in rc.tolist()]
         send = send.contiguous()
-        recv = t.empty((sum(rcl),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.device)
+        recv = alloc(sum(rcl)) if alloc is not None else t.empty((sum(rcl),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.device)
         row_bytes = max(1, send.element_size() * (send.numel() // max(1, send.shape[0]) if send.shape[0] else 1))
         max_rows = max(1, self.max_bytes // row_bytes)
         biggest = t.tensor([max(counts + rcl + [0])], dtype=t.int64, device=self.device)
@@ -91,7 +92,7 @@ class ThreadComm:
         self.tw.barrier.wait()
         return allv
 
-    def alltoallv(self, send, counts):
+    def alltoallv(self, send, counts, alloc=None):
         t = self.torch
         offs = [0]
         for c in counts:
@@ -154,18 +155,32 @@ class GpuEngine:
 
     def route_pack(self, world):
         ptr, counts = self.m.route_pack(world)
-        return self._view(ptr, (sum(counts), self.k + 1)), counts
+        return self._view(ptr, (sum(counts), self.k + 2)), counts
+
+    def alloc_records(self, n):
+        """receive buffer for n routed records inside the library's arena (zero-copy insert)"""
+        return self._view(self.m.arena_reserve(n), (n, self.k + 2))
 
     def insert_records(self, recs):
         recs = recs.contiguous()
         self.t.cuda.synchronize()
         self.m.insert_records(recs.data_ptr() if recs.numel() else 0, recs.shape[0])
 
-    def export(self):
-        n, a, b, c, d = self.m.routed_export()
-        first, ath, slot = self._view(a, (n,)), self._view(b, (n,)), self._view(d, (n,))
-        cnt = self.t.as_tensor(_DevArray(c, ((n + 1) // 2,)), device=self.device).view(self.t.int32)[:n].to(self.t.int64) if n else self.t.empty(0, dtype=self.t.int64, device=self.device)
-        return first, ath, cnt, slot
+    def _view_as(self, ptr, n, dtype, itemsize):
+        """n elements of a narrower integer type at ptr, as an int64 tensor (copy)"""
+        t = self.t
+        if n == 0 or not ptr:
+            return t.empty(0, dtype=t.int64, device=self.device)
+        words = (n * itemsize + 7) // 8
+        return self._view(ptr, (words,)).view(dtype)[:n].to(t.int64)
+
+    def export(self, world, span_lo, span_rank):
+        r = self.m.routed_export(world, span_lo, span_rank)
+        na, ns = int(r.n_all), int(r.n_solid)
+        return dict(first=self._view(r.d_first, (na,)), solid=self._view_as(r.d_solid, na, self.t.uint8, 1),
+                    counts_all=[int(r.counts_all[i]) for i in range(world)],
+                    ath=self._view(r.d_ath, (ns,)), count=self._view_as(r.d_count, ns, self.t.int32, 4), slot=self._view(r.d_slot, (ns,)),
+                    idx_all=self._view(r.d_idx_all, (ns,)), counts_solid=[int(r.counts_solid[i]) for i in range(world)])
 
     def resolve_first(self, ords, solid):
         t = self.t
@@ -201,12 +216,27 @@ class GpuEngine:
 
 # ------------------------------------------------------------------------------------------- driver
 class DistributedMdbg:
-    def __init__(self, engine, comm, torch):
+    def __init__(self, engine, comm, torch, profile=False):
         self.e, self.c, self.t = engine, comm, torch
+        self.profile, self.times = profile, {}
+
+    def _tick(self, name, t0):
+        """accumulates wall time per stage when profiling (forces a device sync, so only for diagnosis)"""
+        if not self.profile:
+            return 0.0
+        import time
+        if self.t.cuda.is_available():
+            self.t.cuda.synchronize()
+        now = time.perf_counter()
+        self.times[name] = self.times.get(name, 0.0) + (now - t0) * 1e3
+        return now
 
     # process_read_aux over this rank's shard of a batch (src/main.rs:730-785), distributed
     def ingest_device(self, d_bases, d_offsets, n_reads, n_bases, first_ordinal):
+        import time
+        t0 = time.perf_counter()
         self.e.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
+        self._tick("sketch", t0)
         self.exchange()
 
     def ingest_host(self, bases, offsets, first_ordinal):
@@ -214,48 +244,33 @@ class DistributedMdbg:
         self.exchange()
 
     def exchange(self):
+        import time
+        t0 = time.perf_counter()
         recs, counts = self.e.route_pack(self.c.world)
-        recv, _ = self.c.alltoallv(recs, counts)
+        t0 = self._tick("route_pack", t0) or t0
+        recv, _ = self.c.alltoallv(recs, counts, getattr(self.e, "alloc_records", None))
+        t0 = self._tick("alltoall_records", t0) or t0
         self.e.insert_records(recv)
-
-    def _generator_of(self, ords, all_ranges):
-        """rank that sketched the read an ordinal belongs to"""
-        t = self.t
-        flat = sorted((fo, n, r) for r, rl in enumerate(all_ranges) for (fo, n) in rl)
-        starts = t.tensor([f[0] for f in flat], dtype=t.int64, device=ords.device)
-        owner = t.tensor([f[2] for f in flat], dtype=t.int64, device=ords.device)
-        idx = t.searchsorted(starts, ords >> WIN_BITS, right=True) - 1
-        return owner[idx.clamp(min=0)]
-
-    def _query(self, payload, dest):
-        """send rows of payload to dest ranks, return (recv rows, recv counts, order) — replies go back with _reply"""
-        t = self.t
-        order = t.argsort(dest, stable=True)
-        counts = t.bincount(dest, minlength=self.c.world).tolist()
-        recv, rc = self.c.alltoallv(payload[order], counts)
-        return recv, rc, order, counts
-
-    def _reply(self, answer, rc, order, counts):
-        back, _ = self.c.alltoallv(answer, rc)
-        out = self.t.empty_like(back)
-        out[order] = back
-        return out
+        self._tick("insert_records", t0)
 
     def finalize(self):
         """-> this rank's partition of the node table (dict of tensors) plus global counters; rows carry their global
         `row` (= position in index order), so concatenating all partitions and sorting by row gives the reference's table"""
+        import time
         t, e, c = self.t, self.e, self.c
-        first, ath, count, slot = e.export()
+        t0 = time.perf_counter()
         all_ranges = c.allgather_obj(e.ranges)
         spans = [(min(fo for fo, _ in rl), max(fo + n for fo, n in rl)) if rl else None for rl in all_ranges]
         live = sorted((s[0], r) for r, s in enumerate(spans) if s)
         for (a, ra), (b, rb) in zip(live, live[1:]):
             assert spans[ra][1] <= b, "each rank must hold one contiguous range of read ordinals"
-        solid = ath != -1
-        # 1. first sightings -> index and row
-        q = t.stack([first, solid.to(t.int64)], 1)
-        recv, rc, order, counts = self._query(q, self._generator_of(first, all_ranges))
+        ex = e.export(c.world, [lo for lo, _ in live], [r for _, r in live])       # both query lists, bucketed by answering rank
+        t0 = self._tick("fin_export", t0) or t0
+        # 1. first sightings -> DbgEntry.index and row, answered by the rank that sketched that read
+        recv, rc = c.alltoallv(t.stack([ex["first"], ex["solid"]], 1), ex["counts_all"])
+        t0 = self._tick("fin_query_first", t0) or t0
         rf, rs, tf, ts = e.resolve_first(recv[:, 0].contiguous(), recv[:, 1].contiguous())
+        t0 = self._tick("fin_resolve_first", t0) or t0
         totals = c.allgather_obj((tf, ts))
         base_f = base_s = 0
         for _, r in live:
@@ -263,17 +278,20 @@ class DistributedMdbg:
                 break
             base_f += totals[r][0]
             base_s += totals[r][1]
-        ans = self._reply(t.stack([rf + base_f, rs + base_s], 1), rc, order, counts)
-        index_all, row_all = ans[:, 0], ans[:, 1]
+        ans, _ = c.alltoallv(t.stack([rf + base_f, rs + base_s], 1), rc)          # comes back in list-A order
+        t0 = self._tick("fin_reply_first", t0) or t0
         # 2. metadata of the A-th sighting, solid nodes only
-        sel = solid.nonzero().flatten()
-        a_sel = ath[sel]
-        recv2, rc2, order2, counts2 = self._query(a_sel, self._generator_of(a_sel, all_ranges))
-        meta = self._reply(e.resolve_meta(recv2.contiguous()), rc2, order2, counts2)
-        keys = e.keys(slot[sel])
+        recv2, rc2 = c.alltoallv(ex["ath"], ex["counts_solid"])
+        meta_local = e.resolve_meta(recv2.contiguous())
+        t0 = self._tick("fin_query+resolve_meta", t0) or t0
+        meta, _ = c.alltoallv(meta_local, rc2)                                     # list-S order
+        t0 = self._tick("fin_reply_meta", t0) or t0
+        keys = e.keys(ex["slot"])
+        sel = ex["idx_all"]
+        self._tick("fin_keys", t0)
         n_nodes = sum(x[1] for x in totals)
         n_before = sum(x[0] for x in totals)
-        return dict(keys=keys, index=index_all[sel], row=row_all[sel], abundance=count[sel] & 0xFFFF, seqlen=meta[:, 0] & 0xFFFFFFFF,
+        return dict(keys=keys, index=ans[sel, 0], row=ans[sel, 1], abundance=ex["count"] & 0xFFFF, seqlen=meta[:, 0] & 0xFFFFFFFF,
                     reversed=(meta[:, 0] >> 32) & 1, shift_full=meta[:, 1:3], src_read=meta[:, 3], src_start=meta[:, 4], src_end=meta[:, 5],
                     n_nodes=n_nodes, n_nodes_before=n_before, n_local=int(sel.shape[0]))
 

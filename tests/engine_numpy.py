@@ -49,11 +49,11 @@ class NumpyEngine:
         for b in self.pending:
             for key, ordn in self._windows(b):
                 h = int.from_bytes(hashlib.blake2b(np.asarray(key, dtype=np.uint64).tobytes(), digest_size=8).digest(), "little")
-                buckets[(h * world) >> 64].append(list(key) + [ordn])
+                buckets[(h * world) >> 64].append(list(key) + [ordn, h])
         self.pending = []
         counts = [len(x) for x in buckets]
         rows = [r for bk in buckets for r in bk]
-        arr = _i64(np.asarray(rows, dtype=np.uint64).reshape(len(rows), self.k + 1))
+        arr = _i64(np.asarray(rows, dtype=np.uint64).reshape(len(rows), self.k + 2))
         return torch.from_numpy(arr.copy()), counts
 
     def insert_records(self, recs):
@@ -67,18 +67,32 @@ class NumpyEngine:
             e[0] += 1
             e[1].append(int(row[self.k]))
 
-    def export(self):
-        first, ath, cnt = [], [], []
-        for key in self.keys_list:
+    def export(self, world, span_lo, span_rank):
+        """the two query lists of GpuEngine.export, bucketed by the rank whose read span holds the ordinal"""
+        import bisect
+
+        def owner(ordn):
+            return span_rank[bisect.bisect_right(span_lo, ordn >> WIN_BITS) - 1]
+        ents = []
+        for slot, key in enumerate(self.keys_list):
             c, ords = self.table[key]
             ords = sorted(ords)
-            first.append(ords[0])
             solid = self.A == 1 or (c & 0xFFFF) >= self.A
-            ath.append(ords[self.A - 1] if solid else (1 << 64) - 1)
-            cnt.append(c)
-        n = len(first)
-        return (torch.from_numpy(_i64(first).copy()), torch.from_numpy(_i64(ath).copy()), torch.tensor(cnt, dtype=torch.int64),
-                torch.arange(n, dtype=torch.int64))
+            ents.append((ords[0], solid, ords[self.A - 1] if solid else None, c, slot))
+        order_a = sorted(range(len(ents)), key=lambda i: owner(ents[i][0]))
+        pos_a = {i: p for p, i in enumerate(order_a)}
+        sol = [i for i in range(len(ents)) if ents[i][1]]
+        order_s = sorted(sol, key=lambda i: owner(ents[i][2]))
+        cnt_a, cnt_s = [0] * world, [0] * world
+        for i in order_a:
+            cnt_a[owner(ents[i][0])] += 1
+        for i in order_s:
+            cnt_s[owner(ents[i][2])] += 1
+        T = lambda v: torch.from_numpy(_i64(v).copy()) if len(v) else torch.empty(0, dtype=torch.int64)
+        return dict(first=T([ents[i][0] for i in order_a]), solid=torch.tensor([int(ents[i][1]) for i in order_a], dtype=torch.int64),
+                    counts_all=cnt_a, ath=T([ents[i][2] for i in order_s]), count=torch.tensor([ents[i][3] for i in order_s], dtype=torch.int64),
+                    slot=torch.tensor([ents[i][4] for i in order_s], dtype=torch.int64),
+                    idx_all=torch.tensor([pos_a[i] for i in order_s], dtype=torch.int64), counts_solid=cnt_s)
 
     def resolve_first(self, ords, solid):
         o = ords.numpy().view(np.uint64)
