@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
+    ap.add_argument("--chunks", type=int, default=4, help="routed path: chunks per step pipelined over two contexts (1 = no overlap)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
     return ap.parse_args()
 
@@ -116,8 +117,14 @@ def main():
     if routed:
         from rust_mdbg_amd import dist as D
         dev = torch.device("cuda", local_rank)
-        engine = D.GpuEngine(m, torch, dev)
+        chunked = args.chunks > 1 and not args.profile_dist
+        mt = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank) if chunked else None     # owner-side context
+        engine = D.GpuEngine(m, torch, dev, table=mt)
         runner = D.DistributedMdbg(engine, D.TorchDistComm(dist, torch, dev), torch, profile=args.profile_dist)
+        if chunked:
+            import numpy as np
+            plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), args.chunks)
+            offs_t = engine._view(d_off, (reads_per_gpu + 1,))
 
     def step():
         if routed:
@@ -127,7 +134,10 @@ def main():
         if not routed:
             m.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
             return m.finalize_device().n
-        runner.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
+        if chunked:
+            runner.ingest_device_chunked(d_bases, offs_t, plan, first_ordinal)
+        else:
+            runner.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
         return runner.finalize_device_count()
 
     def fence():
@@ -157,6 +167,11 @@ def main():
     else:
         total_bases = n_bases
     st = m.stats()          # stats of the last step only (reset clears the timers)
+    if routed and engine.tm is not m:
+        st2 = engine.tm.stats()
+        st["n_distinct"], st["table_capacity"] = st2["n_distinct"], st2["table_capacity"]
+        st["ms_insert"] += st2["ms_insert"]
+        st["ms_finalize"] += st2["ms_finalize"]
     if routed and args.profile_dist and rank == 0:
         n = args.steps
         print("[dist profile, ms per step] " + ", ".join("%s=%.2f" % (k, v / n) for k, v in runner.times.items()), file=sys.stderr)
@@ -190,6 +205,8 @@ def main():
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"]}}
         print(json.dumps(out))
     m.close()
+    if routed and engine.tm is not m:
+        engine.tm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -104,7 +104,9 @@ void mdbg_destroy(mdbg_ctx* ctx);
  * copied to the device and processed there; the sketch of every read stays resident for mdbg_reset. */
 int mdbg_ingest_batch(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
                       uint64_t first_read_ordinal);
-/* Same, with both buffers already in DEVICE memory (d_bases 16-byte aligned).  n_bases = offsets[n_reads]. */
+/* Same, with both buffers already in DEVICE memory (d_bases 16-byte aligned).  n_bases = offsets[n_reads].
+ * offsets[0] may be > 0: bytes in front of the first read are ignored (lets a caller pass an aligned pointer into the
+ * middle of a larger buffer). */
 int mdbg_ingest_batch_device(mdbg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
                              uint64_t n_bases, uint64_t first_read_ordinal);
 

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void slow_tile_kernel(TileArgs a, const u64* _
         if (p < tile_end) {
             r = find_read(a.offsets, rl, rh_, p);
             rlo = a.offsets[r];
-            if (kept_ascii<HPC>(a.bases, rlo, p) && walk_lmer_ascii<HPC>(a.bases, rlo, p, a.c.l, start, hash) && hash <= a.c.bound) sel = 1;
+            if (p >= rlo && kept_ascii<HPC>(a.bases, rlo, p) && walk_lmer_ascii<HPC>(a.bases, rlo, p, a.c.l, start, hash) && hash <= a.c.bound) sel = 1;
         }
         u32 total;
         u32 rank = block_excl_scan_256(sel, tmp, total);
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
             u64 fh = 0, rh = 0; int64_t q = p;
             if (ok) {
                 r = find_read(a.offsets, rl, rhi, (u64)p); rlo = (int64_t)a.offsets[r];
+                if (p < rlo) ok = false;                     // lead-in bytes in front of the batch's first read belong to no read
                 for (int jj = (int)l - 1;; --jj) {
                     const u32 c = code_at(q);
                     const ulonglong2 e = *(const ulonglong2*)(rt + (jj * 4 + c) * 2);

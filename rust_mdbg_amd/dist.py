@@ -120,8 +120,12 @@ class _DevArray:
 class GpuEngine:
     """libmdbg_hip.so behind the stage interface the driver needs"""
 
-    def __init__(self, mdbg, torch, device):
+    def __init__(self, mdbg, torch, device, table=None):
+        """mdbg: context holding the sketch store (sketch / route / resolve); table: optional SECOND context for the
+        owner side (arena / insert / export / keys).  In routed mode the two sides share no state, so giving them their own
+        contexts (own HIP streams) lets DistributedMdbg overlap one chunk's sketch with the previous chunk's exchange."""
         self.m, self.t, self.device, self.ranges = mdbg, torch, device, []
+        self.tm = table if table is not None else mdbg
 
     @property
     def k(self):
@@ -137,6 +141,8 @@ class GpuEngine:
 
     def reset(self):
         self.m.reset(0)
+        if self.tm is not self.m:
+            self.tm.reset(0)
         self.ranges = []
 
     def sketch_device(self, d_bases, d_offsets, n_reads, n_bases, first_ordinal):
@@ -159,12 +165,12 @@ class GpuEngine:
 
     def alloc_records(self, n):
         """receive buffer for n routed records inside the library's arena (zero-copy insert)"""
-        return self._view(self.m.arena_reserve(n), (n, self.k + 2))
+        return self._view(self.tm.arena_reserve(n), (n, self.k + 2))
 
     def insert_records(self, recs):
         recs = recs.contiguous()
         self.t.cuda.synchronize()
-        self.m.insert_records(recs.data_ptr() if recs.numel() else 0, recs.shape[0])
+        self.tm.insert_records(recs.data_ptr() if recs.numel() else 0, recs.shape[0])
 
     def _view_as(self, ptr, n, dtype, itemsize):
         """n elements of a narrower integer type at ptr, as an int64 tensor (copy)"""
@@ -175,7 +181,7 @@ class GpuEngine:
         return self._view(ptr, (words,)).view(dtype)[:n].to(t.int64)
 
     def export(self, world, span_lo, span_rank):
-        r = self.m.routed_export(world, span_lo, span_rank)
+        r = self.tm.routed_export(world, span_lo, span_rank)
         na, ns = int(r.n_all), int(r.n_solid)
         return dict(first=self._view(r.d_first, (na,)), solid=self._view_as(r.d_solid, na, self.t.uint8, 1),
                     counts_all=[int(r.counts_all[i]) for i in range(world)],
@@ -210,7 +216,7 @@ class GpuEngine:
         slots = slots.contiguous()
         t.cuda.synchronize()
         if n:
-            self.m.routed_keys(slots.data_ptr(), n, out.data_ptr())
+            self.tm.routed_keys(slots.data_ptr(), n, out.data_ptr())
         return out
 
 
@@ -238,6 +244,44 @@ class DistributedMdbg:
         self.e.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
         self._tick("sketch", t0)
         self.exchange()
+
+    def ingest_device_chunked(self, d_bases, offsets_dev, plan, first_ordinal):
+        """Same as ingest_device for a batch cut into chunks of whole reads (plan from plan_chunks): a producer thread
+        sketches chunk c+1 and packs its records while this thread exchanges and inserts chunk c.  Needs an engine with
+        a separate table context; offsets_dev is the device offsets array as an int64 tensor."""
+        import queue
+        import threading
+        t, e = self.t, self.e
+        q = queue.Queue()
+        sent = threading.Semaphore(1)          # route_out of the engine is reused: pack chunk c+1 only after chunk c was sent
+        err = []
+
+        def producer():
+            try:
+                for (r0, r1, a, nb) in plan:
+                    offs_c = (offsets_dev[r0:r1 + 1] - a).contiguous()
+                    t.cuda.synchronize()
+                    e.sketch_device(d_bases + a, offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0)
+                    sent.acquire()
+                    q.put(e.route_pack(self.c.world))
+            except BaseException as ex:        # noqa: BLE001
+                err.append(ex)
+                q.put(None)
+
+        th = threading.Thread(target=producer)
+        th.start()
+        for _ in plan:
+            item = q.get()
+            if item is None:
+                break
+            recs, counts = item
+            recv, _ = self.c.alltoallv(recs, counts, getattr(e, "alloc_records", None))
+            t.cuda.synchronize()
+            sent.release()
+            e.insert_records(recv)
+        th.join()
+        if err:
+            raise err[0]
 
     def ingest_host(self, bases, offsets, first_ordinal):
         self.e.sketch_host(bases, offsets, first_ordinal)
@@ -297,6 +341,26 @@ class DistributedMdbg:
 
     def finalize_device_count(self):
         return self.finalize()["n_nodes"]
+
+
+def plan_chunks(offsets_host, n_chunks):
+    """cut a batch (host copy of its offsets) into n_chunks runs of whole reads with roughly equal bases:
+    -> [(r0, r1, aligned_byte, n_bytes)]: the chunk is reads [r0, r1), passed with base pointer + aligned_byte (a multiple
+    of 16 <= offsets[r0]) and offsets rebased by it; n_bytes = offsets[r1] - aligned_byte"""
+    import numpy as np
+    o = np.asarray(offsets_host, dtype=np.uint64)
+    n = len(o) - 1
+    cuts = [0]
+    for c in range(1, n_chunks):
+        r = int(np.searchsorted(o, o[-1] * c // n_chunks))
+        cuts.append(min(max(r, cuts[-1]), n))
+    cuts.append(n)
+    plan = []
+    for r0, r1 in zip(cuts, cuts[1:]):
+        if r1 > r0:
+            a = int(o[r0]) // 16 * 16
+            plan.append((r0, r1, a, int(o[r1]) - a))
+    return plan
 
 
 def gather_node_table(parts):

@@ -91,3 +91,33 @@ def test_rccl_communicator_world1_chunked():
         assert rc == [100003] and torch.equal(x, y)
     finally:
         dist.destroy_process_group()
+
+
+def test_chunked_two_context_pipeline_matches_oracle():
+    """sketch store and table in two contexts, batch cut into chunks (unaligned read starts -> lead-in bytes), producer
+    thread sketching ahead of the exchange: same node table"""
+    import torch
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import dist as D, synth
+    reads = synth.synth_reads(21, 250000, 320, mean_len=11000, sd_len=2500, min_len=100, max_len=20000, err_ppm=1500)
+    k, l, d, a = 7, 12, 0.004, 2
+    dev = torch.device("cuda", 0)
+    b, o = O.concat_reads(reads)
+    with R.Mdbg(k, l, d, a, device=0) as ms, R.Mdbg(k, l, d, a, device=0) as mt:
+        eng = D.GpuEngine(ms, torch, dev, table=mt)
+        drv = D.DistributedMdbg(eng, D.ThreadComm(D.ThreadWorld(1), 0, torch), torch)
+        tb = torch.from_numpy(b).to(dev)
+        to = torch.from_numpy(o.view(np.int64)).to(dev)
+        plan = D.plan_chunks(o, 5)
+        assert len(plan) == 5 and any(int(o[r0]) % 16 for r0, _, _, _ in plan)
+        drv.ingest_device_chunked(tb.data_ptr(), to, plan, 1000)
+        part = drv.finalize()
+        part = {f: (v.cpu() if hasattr(v, "cpu") else v) for f, v in part.items()}
+    g = O.Graph(k, l, d, a)
+    g.ingest(b, o, 1000)
+    exp = g.finalize(with_edges=False)
+    tab = D.gather_node_table([{f: (v.numpy().view(np.uint64) if hasattr(v, "numpy") else v) for f, v in part.items()}])
+    assert tab["n_nodes"] == exp["n_nodes"] and tab["n_nodes_before"] == exp["n_nodes_before"]
+    assert np.array_equal(tab["keys"], exp["keys"])
+    for f in ("index", "abundance", "seqlen", "reversed", "src_read", "src_start", "src_end"):
+        assert np.array_equal(tab[f].astype(np.uint64), exp[f].astype(np.uint64)), f
