@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
-    ap.add_argument("--chunks", type=int, default=4, help="routed path: chunks per step pipelined over two contexts (1 = no overlap)")
+    ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
+                    help="multi-GPU mode: all-gather of sketches + partitioned table (intra-node default), or all-to-all of k-min-mer records")
+    ap.add_argument("--chunks", type=int, default=1, help="routed path: chunks per step pipelined over two contexts (1 = no overlap)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
     return ap.parse_args()
 
@@ -117,10 +119,12 @@ def main():
     if routed:
         from rust_mdbg_amd import dist as D
         dev = torch.device("cuda", local_rank)
-        chunked = args.chunks > 1 and not args.profile_dist
+        replicate = args.dist_mode == "replicate"
+        chunked = args.chunks > 1 and not args.profile_dist and not replicate
         mt = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank) if chunked else None     # owner-side context
         engine = D.GpuEngine(m, torch, dev, table=mt)
-        runner = D.DistributedMdbg(engine, D.TorchDistComm(dist, torch, dev), torch, profile=args.profile_dist)
+        comm = D.TorchDistComm(dist, torch, dev)
+        runner = D.ReplicatedMdbg(engine, comm, torch) if replicate else D.DistributedMdbg(engine, comm, torch, profile=args.profile_dist)
         if chunked:
             import numpy as np
             plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), args.chunks)
@@ -128,7 +132,7 @@ def main():
 
     def step():
         if routed:
-            engine.reset()
+            runner.reset() if replicate else engine.reset()
         else:
             m.reset(0)
         if not routed:
@@ -149,7 +153,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if routed:
+    if routed and not replicate:
         runner.times = {}
     t0 = time.perf_counter()
     n_nodes = 0
@@ -172,7 +176,7 @@ def main():
         st["n_distinct"], st["table_capacity"] = st2["n_distinct"], st2["table_capacity"]
         st["ms_insert"] += st2["ms_insert"]
         st["ms_finalize"] += st2["ms_finalize"]
-    if routed and args.profile_dist and rank == 0:
+    if routed and not replicate and args.profile_dist and rank == 0:
         n = args.steps
         print("[dist profile, ms per step] " + ", ".join("%s=%.2f" % (k, v / n) for k, v in runner.times.items()), file=sys.stderr)
     if rank == 0:
@@ -198,7 +202,7 @@ def main():
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "synthetic D. melanogaster 140 Mb @50x per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1% errors",
                           "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
-                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": "reads sharded by record x%d, key-range all-to-all over RCCL" % world if routed else "single GPU"},
+                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, "all-gather of sketches" if args.dist_mode == "replicate" else "all-to-all of k-min-mer records")) if routed else "single GPU"},
                "roofline": roof, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_tile_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),

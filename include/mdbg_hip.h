@@ -179,6 +179,30 @@ int mdbg_resolve_first(mdbg_ctx* ctx, const uint64_t* d_ord, const uint8_t* d_so
 int mdbg_resolve_meta(mdbg_ctx* ctx, const uint64_t* d_ord, uint64_t n, uint64_t* d_meta);
 /* Owner side: canonical keys (k u64 each) of the given slot handles into the caller-owned DEVICE buffer d_keys. */
 int mdbg_routed_keys(mdbg_ctx* ctx, const uint64_t* d_slot, uint64_t n, uint64_t* d_keys);
+/* ---- multi-GPU, second mode: replicated sketches, partitioned table ----------------------------------------
+ * Within one node the sketch is much more compact than the k-min-mers cut from it (every minimizer sits in k windows),
+ * so the ranks may exchange SKETCHES instead (one all-gather), each rank then windows the global sketch but inserts only
+ * the k-min-mers it owns.  Ownership is an O(1) function of the canonical key (its two ends and its middle), the table,
+ * insertion and finalize are the single-GPU ones, and nothing is approximate.  DbgEntry.index needs the first sightings
+ * of all ranks: mdbg_finalize_begin exposes this rank's first-sighting / solid bitmaps over the (identical on every
+ * rank) global sketch; the driver sums them across ranks (bits are disjoint) and mdbg_finalize_end emits the rows. */
+int mdbg_set_partition(mdbg_ctx* ctx, uint32_t world, uint32_t rank);   /* before the first insertion */
+typedef struct mdbg_sketch_store {
+    uint64_t n_minimizers, n_reads;
+    const uint64_t* d_hashes;        /* [n_minimizers] DEVICE */
+    const uint32_t* d_positions;     /* [n_minimizers] raw position relative to the read */
+    const uint64_t* d_read_offsets;  /* [n_reads + 1] first minimizer of every read */
+} mdbg_sketch_store;
+int mdbg_sketch_view(mdbg_ctx* ctx, mdbg_sketch_store* out);  /* the resident store (valid until the next sketch/ingest/reset) */
+/* Append an already computed sketch (DEVICE arrays, e.g. another rank's mdbg_sketch_view): n_reads reads whose minimizers
+ * are hashes/positions[read_offsets[r] .. read_offsets[r+1]).  Counterpart of mdbg_sketch_device without the kernel. */
+int mdbg_ingest_sketch(mdbg_ctx* ctx, const uint64_t* d_hashes, const uint32_t* d_positions, const uint64_t* d_read_offsets,
+                       uint64_t n_reads, uint64_t first_read_ordinal);
+int mdbg_finalize_begin(mdbg_ctx* ctx, uint64_t** d_bm_first, uint64_t** d_bm_solid, uint64_t* n_words);
+/* out: DEVICE pointers, this rank's nodes in table order; d_row[i] = global row (position in index order);
+ * out->n_distinct and *n_nodes_global are the totals over all ranks (from the merged bitmaps). */
+int mdbg_finalize_end(mdbg_ctx* ctx, mdbg_nodes* out, const uint64_t** d_row, uint64_t* n_nodes_global);
+
 /* Wait for all device work queued by ctx. */
 int mdbg_sync(mdbg_ctx* ctx);
 /* Plain copies between host memory and device buffers handed out by / given to this library. */

@@ -49,6 +49,11 @@ class RoutedLists(C.Structure):
                 ("counts_solid", C.c_uint64 * 64)]
 
 
+class SketchStore(C.Structure):
+    _fields_ = [("n_minimizers", C.c_uint64), ("n_reads", C.c_uint64), ("d_hashes", C.c_void_p), ("d_positions", C.c_void_p),
+                ("d_read_offsets", C.c_void_p)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_reads", C.c_uint64), ("mean_len", C.c_uint32),
                 ("sd_len", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("err_ppm", C.c_uint32),
@@ -58,7 +63,8 @@ class SynthParams(C.Structure):
 EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
-           "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve"]
+           "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
+           "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end"]
 
 
 def lib_path():
@@ -107,6 +113,11 @@ def load_library():
     L.mdbg_resolve_meta.argtypes = [vp, vp, u64, vp]
     L.mdbg_routed_keys.argtypes = [vp, vp, u64, vp]
     L.mdbg_arena_reserve.argtypes = [vp, u64, C.POINTER(vp)]
+    L.mdbg_set_partition.argtypes = [vp, u32, u32]
+    L.mdbg_sketch_view.argtypes = [vp, C.POINTER(SketchStore)]
+    L.mdbg_ingest_sketch.argtypes = [vp, vp, vp, vp, u64, u64]
+    L.mdbg_finalize_begin.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.mdbg_finalize_end.argtypes = [vp, C.POINTER(Nodes), C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_insert_records.argtypes = [vp, vp, u64]
     L.mdbg_sync.argtypes = [vp]
     L.mdbg_copy_to_host.argtypes = [vp, vp, vp, u64]
@@ -115,7 +126,8 @@ def load_library():
     for f in ("mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_device", "mdbg_insert_resident", "mdbg_sketch_only",
               "mdbg_finalize", "mdbg_finalize_device", "mdbg_reset", "mdbg_get_stats", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync",
               "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device", "mdbg_routed_export", "mdbg_resolve_first",
-              "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve"):
+              "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve", "mdbg_set_partition", "mdbg_sketch_view",
+              "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end"):
         getattr(L, f).restype = C.c_int
     _LIB = L
     return L
@@ -240,6 +252,30 @@ class Mdbg:
 
     def routed_keys(self, d_slot, n, d_keys):
         self._chk(self.L.mdbg_routed_keys(self.h, d_slot, n, d_keys))
+
+    # --- replicated-sketch multi-GPU mode ---
+    def set_partition(self, world, rank):
+        self._chk(self.L.mdbg_set_partition(self.h, world, rank))
+
+    def sketch_view(self):
+        s = SketchStore()
+        self._chk(self.L.mdbg_sketch_view(self.h, C.byref(s)))
+        return s
+
+    def ingest_sketch(self, d_hashes, d_positions, d_read_offsets, n_reads, first_read_ordinal):
+        self._chk(self.L.mdbg_ingest_sketch(self.h, d_hashes, d_positions, d_read_offsets, n_reads, first_read_ordinal))
+
+    def finalize_begin(self):
+        """-> (d_bm_first, d_bm_solid, n_words): this rank's bitmaps over the global sketch, to be summed over ranks"""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._chk(self.L.mdbg_finalize_begin(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value or 0, b.value or 0, n.value
+
+    def finalize_end(self):
+        """-> (Nodes with device pointers, d_row, n_nodes_global)"""
+        nd, row, ng = Nodes(), C.c_void_p(), C.c_uint64()
+        self._chk(self.L.mdbg_finalize_end(self.h, C.byref(nd), C.byref(row), C.byref(ng)))
+        return nd, row.value or 0, ng.value
 
     def to_host(self, d_ptr, nbytes, dtype=np.uint8):
         """copy nbytes of device memory into a fresh numpy array"""

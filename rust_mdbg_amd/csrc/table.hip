@@ -68,6 +68,7 @@ struct TableArgs {
     u64* n_distinct;              // device counter
     KeySrc ks;
     u32 dbg;                      // experiment switches (MDBG_DBG), 0 in production
+    u32 own_world, own_rank;      // replicated-sketch mode: insert only windows owned by own_rank (own_world <= 1: all)
 };
 
 // insert ordinal x into the slot's A smallest
@@ -108,6 +109,13 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
     }
 }
 
+// Owner of a k-min-mer in the replicated-sketch multi-GPU mode: an O(1) function of the canonical key (both ends and the
+// middle are invariant under reversal as unordered sets), so every rank can decide ownership of every window cheaply.
+__device__ inline u32 window_owner(const u64* __restrict__ w, u32 k, u32 world) {
+    const u64 x = w[0] + w[k - 1] + w[(k - 1) >> 1] + w[k >> 1];
+    return (u32)__umul64hi(fmix64(x), (u64)world);
+}
+
 // one thread per minimizer index i in [i0, i1): if a window of k starts at i inside its read, upsert it.
 // src/main.rs:756 — only reads with MORE than k minimizers contribute.
 __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     if (win > WIN_MASK) { *cap_err = 1; return; }
     const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
     const u64* w = mh + i;
+    if (T.own_world > 1 && window_owner(w, k, T.own_world) != T.own_rank) return;
     const bool rev = window_reversed(w, k);
     const u64 h = key_hash_window(w, k, rev);
     if (T.dbg & 8) { if (h == 12345) *cap_err = 2; return; }
@@ -189,6 +198,7 @@ struct FinArgs {
     const u64* mh; const u32* mpos; const u64* roff; const u32* mread; const u64* arena;
     BatchTab bt;
     u64* solid_list; u64* solid_count;       // compact list of solid slots (fin_mark -> fin_emit)
+    u64* o_row;                              // non-null: write node q at position q and its global row here (partitioned table)
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
     const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
     u64* sh_solid; u64* sh_wrapped; u64* sh_distinct;   // sharded counters (CTR_SHARDS u64 each)
@@ -264,6 +274,19 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
 }
 
 // number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
+// the same, counting only the windows owned by `rank` (replicated-sketch mode); one thread per minimizer index
+__global__ void count_owned_windows_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
+                                           u32 k, u32 world, u32 rank, u64* __restrict__ out) {
+    const u64 i = i0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool mine = false;
+    if (i < i1) {
+        const u32 slot = mread[i];
+        const u64 rs = roff[slot], re = roff[slot + 1];
+        mine = re - rs > k && i + k <= re && window_owner(mh + i, k, world) == rank;
+    }
+    const u64 m = __ballot(mine);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd((unsigned long long*)ctr_shard(out), (unsigned long long)__popcll(m));
+}
 __global__ void count_windows_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32 k, u64* __restrict__ out) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     u64 w = 0;
@@ -281,7 +304,9 @@ __global__ void fin_emit_kernel(FinArgs F, u64 n_solid) {
     const u32 k = F.k;
     u64 i1, D; decode_ordinal(F, v.first, i1, D);
     const u64 below = (1ull << (D & 63)) - 1;
-    const u64 n = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);            // output row
+    const u64 row = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);          // row of the node in index order
+    const u64 n = F.o_row ? q : row;
+    if (F.o_row) F.o_row[q] = row;
     F.o_index[n] = F.pre_first[D >> 6] + __popcll(F.bm_first[D >> 6] & below);           // NODE_INDEX order (main.rs:661)
     F.o_abund[n] = (u16)v.count;
     // the A-th sighting (main.rs:680-684): seqlen, shift and the sequence's origin
@@ -341,6 +366,19 @@ __global__ __launch_bounds__(1024) void popc_prefix_kernel(const u64* __restrict
     if (w < n_words) pre[w] = b + inc - v;
 }
 
+// imported sketches: mread[i] = slot of the read minimizer i belongs to (one wave per read)
+__global__ __launch_bounds__(256) void fill_mread_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32* __restrict__ mread) {
+    const u32 r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const u64 a = roff[slot0 + r], b = roff[slot0 + r + 1];
+    for (u64 i = a + (threadIdx.x & 63); i < b; i += 64) mread[i] = slot0 + r;
+}
+// roff[slot0 + r] = m0 + rel[r] for r in [0, n_reads]
+__global__ void rebase_offsets_kernel(const u64* __restrict__ rel, u32 n_reads, u64 m0, u64* __restrict__ roff_out) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_reads) roff_out[r] = m0 + rel[r];
+}
+
 // out[j] = sum of shard array j (CTR_SHARDS u64 each); one block per array
 __global__ __launch_bounds__(256) void sum_shards_kernel(const u64* __restrict__ shards, u64* __restrict__ out) {
     __shared__ u64 ws[4];
@@ -379,6 +417,15 @@ void launch_popc_prefix(const u64* bm, u64 n_words, u32* block_tmp, u32* pre, hi
     hipLaunchKernelGGL(popc_block_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp);
     hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_tmp, nb);
     hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp, pre);
+}
+void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32 rank, u64* out_shards, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, rank, out_shards);
+}
+void launch_fill_mread(const u64* roff, u32 slot0, u32 n_reads, u32* mread, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(fill_mread_kernel, dim3((n_reads + 3) / 4), dim3(256), 0, s, roff, slot0, n_reads, mread);
+}
+void launch_rebase_offsets(const u64* rel, u32 n_reads, u64 m0, u64* roff_out, hipStream_t s) {
+    hipLaunchKernelGGL(rebase_offsets_kernel, dim3((n_reads + 256) / 256), dim3(256), 0, s, rel, n_reads, m0, roff_out);
 }
 void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* out, hipStream_t s) {
     if (!n_reads) return;

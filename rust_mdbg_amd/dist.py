@@ -10,6 +10,7 @@ The driver only moves tensors; all compute is in the engine (GpuEngine = libmdbg
 Communicators: TorchDistComm (RCCL on GPUs, gloo on CPU) and ThreadComm (several ranks inside one process, for tests).
 All tensors are int64 (u64 values bit-cast); ~0 appears as -1.  A routed record is k+2 values: key[k], ordinal, key hash.
 """
+import ctypes as C
 import threading
 
 WIN_BITS = 26
@@ -71,6 +72,31 @@ class TorchDistComm:
         self.dist.all_gather_object(out, obj)
         return out
 
+    def allgatherv(self, x, sizes):
+        """x: this rank's 1-D tensor, sizes[r] = length on rank r -> list of tensors (rank r's data), padded collectives
+        cut into rounds of <= max_bytes per rank"""
+        t, dist = self.torch, self.dist
+        mx = max(sizes) if sizes else 0
+        outs = [t.empty(n, dtype=x.dtype, device=self.device) for n in sizes]
+        step = max(1, self.max_bytes // max(1, x.element_size()))
+        for a in range(0, mx, step):
+            n = min(step, mx - a)
+            mine = t.zeros(n, dtype=x.dtype, device=self.device)
+            k = max(0, min(n, x.shape[0] - a))
+            if k:
+                mine[:k] = x[a:a + k]
+            buf = t.empty(n * self.world, dtype=x.dtype, device=self.device)
+            dist.all_gather_into_tensor(buf, mine)
+            for r in range(self.world):
+                kr = max(0, min(n, sizes[r] - a))
+                if kr:
+                    outs[r][a:a + kr] = buf[r * n:r * n + kr]
+        return outs
+
+    def allreduce_sum_(self, x):
+        self.dist.all_reduce(x)
+        return x
+
 
 class ThreadWorld:
     """shared state of `world` in-process ranks (one thread each)"""
@@ -107,6 +133,14 @@ class ThreadComm:
 
     def allgather_obj(self, obj):
         return self._exchange(obj)
+
+    def allgatherv(self, x, sizes):
+        return [v.clone() for v in self._exchange(x)]
+
+    def allreduce_sum_(self, x):
+        allv = self._exchange(x.clone())
+        x.copy_(sum(allv[1:], allv[0]))
+        return x
 
 
 # ------------------------------------------------------------------------------------------- GPU engine
@@ -158,6 +192,42 @@ class GpuEngine:
         to = self.t.from_numpy(offsets.view(np.int64)).to(self.device)
         self.t.cuda.synchronize()
         self.sketch_device(tb.data_ptr(), to.data_ptr(), len(offsets) - 1, int(offsets[-1]), first_ordinal)
+
+    # replicated-sketch mode ------------------------------------------------------------------------------
+    def set_partition(self, world, rank):
+        self.m.set_partition(world, rank)
+
+    def sketch_arrays(self):
+        """this rank's resident sketch as int64 / int32 / int64 tensors (views)"""
+        s = self.m.sketch_view()
+        m, n = int(s.n_minimizers), int(s.n_reads)
+        pos = self._view(s.d_positions, ((m + 1) // 2,)).view(self.t.int32)[:m] if m else self.t.empty(0, dtype=self.t.int32, device=self.device)
+        return self._view(s.d_hashes, (m,)), pos, self._view(s.d_read_offsets, (n + 1,))
+
+    def ingest_sketch(self, hashes, pos, read_off, first_ordinal):
+        hashes, pos, read_off = hashes.contiguous(), pos.contiguous(), read_off.contiguous()
+        self.t.cuda.synchronize()
+        self.m.ingest_sketch(hashes.data_ptr() if hashes.numel() else 0, pos.data_ptr() if pos.numel() else 0, read_off.data_ptr(),
+                             read_off.shape[0] - 1, first_ordinal)
+
+    def insert_owned(self):
+        self.m.insert_resident()
+
+    def finalize_begin(self):
+        a, b, n = self.m.finalize_begin()
+        return self._view(a, (n,)), self._view(b, (n,))
+
+    def finalize_end(self):
+        t = self.t
+        nd, row, ng = self.m.finalize_end()
+        n, k = int(nd.n), self.k
+        addr = lambda p: C.cast(p, C.c_void_p).value or 0
+        v16 = lambda p, cnt: self._view_as(addr(p), cnt, t.int16, 2) & 0xFFFF
+        return dict(keys=self._view(addr(nd.keys), (n, k)), index=self._view_as(addr(nd.index), n, t.int32, 4) & 0xFFFFFFFF, row=self._view(row, (n,)),
+                    abundance=v16(nd.abundance, n), seqlen=self._view_as(addr(nd.seqlen), n, t.int32, 4) & 0xFFFFFFFF,
+                    reversed=self._view_as(addr(nd.reversed), n, t.uint8, 1), shift_full=self._view(addr(nd.shift_full), (n, 2)),
+                    src_read=self._view(addr(nd.src_read), (n,)), src_start=self._view(addr(nd.src_start), (n,)), src_end=self._view(addr(nd.src_end), (n,)),
+                    n_nodes=int(ng), n_nodes_before=int(nd.n_distinct), n_local=n)
 
     def route_pack(self, world):
         ptr, counts = self.m.route_pack(world)
@@ -338,6 +408,58 @@ class DistributedMdbg:
         return dict(keys=keys, index=ans[sel, 0], row=ans[sel, 1], abundance=ex["count"] & 0xFFFF, seqlen=meta[:, 0] & 0xFFFFFFFF,
                     reversed=(meta[:, 0] >> 32) & 1, shift_full=meta[:, 1:3], src_read=meta[:, 3], src_start=meta[:, 4], src_end=meta[:, 5],
                     n_nodes=n_nodes, n_nodes_before=n_before, n_local=int(sel.shape[0]))
+
+    def finalize_device_count(self):
+        return self.finalize()["n_nodes"]
+
+
+class ReplicatedMdbg:
+    """Second multi-GPU mode (include/mdbg_hip.h "replicated sketches, partitioned table"): all-gather of the sketches,
+    every rank windows the global sketch and inserts the k-min-mers it owns, one sum-all-reduce of two bitmaps at finalize.
+    Communication per rank grows with the number of ranks (all-gather), so this is the intra-node mode; DistributedMdbg
+    (all-to-all of k-min-mer records, volume per rank independent of the world size) is the one that scales out."""
+
+    def __init__(self, engine, comm, torch):
+        self.e, self.c, self.t = engine, comm, torch
+        self.imported_local = 0        # reads (own + imported) already in this rank's store
+        engine.set_partition(comm.world, comm.rank)
+
+    def reset(self):
+        self.e.reset()
+        self.imported_local = 0
+
+    def ingest_device(self, d_bases, d_offsets, n_reads, n_bases, first_ordinal):
+        self.e.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
+        self.share(first_ordinal, n_reads)
+
+    def ingest_host(self, bases, offsets, first_ordinal):
+        self.e.sketch_host(bases, offsets, first_ordinal)
+        self.share(first_ordinal, len(offsets) - 1)
+
+    def share(self, first_ordinal, n_reads):
+        """all-gather the sketch of the batch just sketched; peers' batches are appended to the resident store"""
+        t, e, c = self.t, self.e, self.c
+        hashes, pos, roff = e.sketch_arrays()
+        r0 = self.imported_local
+        m0 = int(roff[r0].item()) if roff.shape[0] else 0
+        my_off = (roff[r0:r0 + n_reads + 1] - m0).clone()
+        my_h, my_p = hashes[m0:m0 + int(my_off[-1].item())].clone(), pos[m0:m0 + int(my_off[-1].item())].clone()
+        meta = c.allgather_obj((int(my_h.shape[0]), int(n_reads), int(first_ordinal)))
+        hs = c.allgatherv(my_h, [x[0] for x in meta])
+        ps = c.allgatherv(my_p, [x[0] for x in meta])
+        os_ = c.allgatherv(my_off, [x[1] + 1 for x in meta])
+        self.imported_local = r0 + n_reads
+        for r in range(c.world):
+            if r != c.rank and meta[r][1]:
+                e.ingest_sketch(hs[r], ps[r], os_[r], meta[r][2])
+                self.imported_local += meta[r][1]
+        e.insert_owned()
+
+    def finalize(self):
+        bf, bs = self.e.finalize_begin()
+        self.c.allreduce_sum_(bf)      # every bit is set by exactly one rank (distinct keys have distinct first sightings)
+        self.c.allreduce_sum_(bs)
+        return self.e.finalize_end()
 
     def finalize_device_count(self):
         return self.finalize()["n_nodes"]

@@ -94,6 +94,94 @@ class NumpyEngine:
                     slot=torch.tensor([ents[i][4] for i in order_s], dtype=torch.int64),
                     idx_all=torch.tensor([pos_a[i] for i in order_s], dtype=torch.int64), counts_solid=cnt_s)
 
+    # ---- replicated-sketch mode -------------------------------------------------------------------------
+    def set_partition(self, world, rank):
+        self.world, self.rank = world, rank
+
+    def sketch_arrays(self):
+        hs = np.concatenate([b["sk"]["hashes"] for b in self.batches]) if self.batches else np.zeros(0, np.uint64)
+        ps = np.concatenate([b["sk"]["pos"] for b in self.batches]).astype(np.int32) if self.batches else np.zeros(0, np.int32)
+        off, base = [0], 0
+        for b in self.batches:
+            off += [base + int(x) for x in b["sk"]["off"][1:]]
+            base += len(b["sk"]["hashes"])
+        return torch.from_numpy(_i64(hs).copy()), torch.from_numpy(ps.copy()), torch.tensor(off, dtype=torch.int64)
+
+    def ingest_sketch(self, hashes, pos, read_off, first_ordinal):
+        sk = dict(hashes=hashes.numpy().view(np.uint64).copy(), pos=pos.numpy().astype(np.uint64), off=read_off.numpy().view(np.uint64).copy())
+        b = dict(first=int(first_ordinal), n=len(sk["off"]) - 1, sk=sk)
+        self.batches.append(b)
+        self.pending.append(b)
+
+    @staticmethod
+    def _fmix(x):
+        M = (1 << 64) - 1
+        x ^= x >> 33; x = x * 0xff51afd7ed558ccd & M; x ^= x >> 33; x = x * 0xc4ceb9fe1a85ec53 & M; x ^= x >> 33
+        return x
+
+    def insert_owned(self):
+        k, M = self.k, (1 << 64) - 1
+        for b in self.pending:
+            sk = b["sk"]
+            for r in range(b["n"]):
+                lo, hi = int(sk["off"][r]), int(sk["off"][r + 1])
+                if hi - lo > k:
+                    for i in range(hi - lo - k + 1):
+                        w = [int(x) for x in sk["hashes"][lo + i:lo + i + k]]
+                        x = (w[0] + w[k - 1] + w[(k - 1) >> 1] + w[k >> 1]) & M
+                        if (self._fmix(x) * self.world) >> 64 != self.rank:
+                            continue
+                        rev = not (w < w[::-1])
+                        key = tuple(w[::-1] if rev else w)
+                        ent = self.table.get(key)
+                        if ent is None:
+                            ent = self.table[key] = [0, []]
+                            self.keys_list.append(key)
+                        ent[0] += 1
+                        ent[1].append(((b["first"] + r) << WIN_BITS) | i)
+        self.pending = []
+
+    def _dense(self, ordn):
+        ro, win = ordn >> WIN_BITS, ordn & ((1 << WIN_BITS) - 1)
+        base = 0
+        for b in sorted(self.batches, key=lambda q: q["first"]):
+            if b["first"] <= ro < b["first"] + b["n"]:
+                return base + int(b["sk"]["off"][ro - b["first"]]) + win
+            base += len(b["sk"]["hashes"])
+        raise KeyError(ordn)
+
+    def finalize_begin(self):
+        total = sum(len(b["sk"]["hashes"]) for b in self.batches)
+        bf = np.zeros((total + 63) // 64, dtype=np.uint64)
+        bs = np.zeros_like(bf)
+        self._fin = []
+        for key in self.keys_list:
+            c, ords = self.table[key]
+            ords = sorted(ords)
+            solid = self.A == 1 or (c & 0xFFFF) >= self.A
+            D = self._dense(ords[0])
+            bf[D >> 6] |= np.uint64(1 << (D & 63))
+            if solid:
+                bs[D >> 6] |= np.uint64(1 << (D & 63))
+                self._fin.append((key, c, D, ords[self.A - 1]))
+        self._bf, self._bs = torch.from_numpy(bf.view(np.int64)), torch.from_numpy(bs.view(np.int64))
+        return self._bf, self._bs
+
+    def finalize_end(self):
+        bf, bs = self._bf.numpy().view(np.uint64), self._bs.numpy().view(np.uint64)
+        bits_f = np.unpackbits(bf.view(np.uint8), bitorder="little")
+        bits_s = np.unpackbits(bs.view(np.uint8), bitorder="little")
+        cf, cs = np.concatenate([[0], np.cumsum(bits_f)]), np.concatenate([[0], np.cumsum(bits_s)])
+        keys, rows, idx, ab, metas = [], [], [], [], []
+        for key, c, D, oa in self._fin:
+            keys.append(key); rows.append(int(cs[D])); idx.append(int(cf[D])); ab.append(c & 0xFFFF); metas.append(oa)
+        meta = self.resolve_meta(torch.from_numpy(_i64(metas).copy()) if metas else torch.empty(0, dtype=torch.int64))
+        n = len(keys)
+        T = lambda v: torch.tensor(v, dtype=torch.int64)
+        return dict(keys=torch.from_numpy(_i64(np.asarray(keys, dtype=np.uint64).reshape(n, self.k)).copy()), index=T(idx), row=T(rows), abundance=T(ab),
+                    seqlen=meta[:, 0] & 0xFFFFFFFF, reversed=(meta[:, 0] >> 32) & 1, shift_full=meta[:, 1:3], src_read=meta[:, 3], src_start=meta[:, 4],
+                    src_end=meta[:, 5], n_nodes=int(bits_s.sum()), n_nodes_before=int(bits_f.sum()), n_local=n)
+
     def resolve_first(self, ords, solid):
         o = ords.numpy().view(np.uint64)
         s = solid.numpy().astype(bool)

@@ -38,10 +38,10 @@ def check_against_oracle(parts, reads, k=K, l=L, d=DENS, a=A):
     assert np.array_equal(tab["shift_full"], exp["shift_full"])
 
 
-def run_rank(rank, world, comm, reads, out, batches_per_rank=2):
+def run_rank(rank, world, comm, reads, out, batches_per_rank=2, mode="route"):
     from engine_numpy import NumpyEngine
     eng = NumpyEngine(K, L, DENS, A)
-    drv = D.DistributedMdbg(eng, comm, torch)
+    drv = D.DistributedMdbg(eng, comm, torch) if mode == "route" else D.ReplicatedMdbg(eng, comm, torch)
     per = len(reads) // world
     lo, hi = rank * per, (len(reads) if rank == world - 1 else (rank + 1) * per)
     step = (hi - lo + batches_per_rank - 1) // batches_per_rank
@@ -51,8 +51,9 @@ def run_rank(rank, world, comm, reads, out, batches_per_rank=2):
     out[rank] = drv.finalize()
 
 
+@pytest.mark.parametrize("mode", ["route", "replicate"])
 @pytest.mark.parametrize("world", [1, 2, 3])
-def test_thread_ranks_numpy_engine(world):
+def test_thread_ranks_numpy_engine(world, mode):
     reads = workload()
     tw = D.ThreadWorld(world)
     out = [None] * world
@@ -60,7 +61,7 @@ def test_thread_ranks_numpy_engine(world):
 
     def body(r):
         try:
-            run_rank(r, world, D.ThreadComm(tw, r, torch), reads, out)
+            run_rank(r, world, D.ThreadComm(tw, r, torch), reads, out, mode=mode)
         except BaseException as e:           # noqa: BLE001
             errs.append(e)
             tw.barrier.abort()
@@ -72,7 +73,7 @@ def test_thread_ranks_numpy_engine(world):
     check_against_oracle(out, reads)
 
 
-def _gloo_worker(rank, world, port, tmpdir):
+def _gloo_worker(rank, world, port, tmpdir, mode):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     import torch.distributed as dist
@@ -80,19 +81,20 @@ def _gloo_worker(rank, world, port, tmpdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = [None] * world
-    run_rank(rank, world, D.TorchDistComm(dist, torch, torch.device("cpu")), workload(), out)
+    run_rank(rank, world, D.TorchDistComm(dist, torch, torch.device("cpu"), max_bytes=1 << 16), workload(), out, mode=mode)
     np.savez(os.path.join(tmpdir, "part%d.npz" % rank), **{f: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for f, v in out[rank].items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gloo_world2(tmp_path):
+@pytest.mark.parametrize("mode", ["route", "replicate"])
+def test_gloo_world2(tmp_path, mode):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     parts = []
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), "part%d.npz" % r))

@@ -12,7 +12,7 @@ from test_distributed_cpu import check_against_oracle
 pytestmark = pytest.mark.gpu
 
 
-def run(world, reads, k, l, d, a, batches_per_rank=2):
+def run(world, reads, k, l, d, a, batches_per_rank=2, mode="route"):
     import torch
     import rust_mdbg_amd as R
     from rust_mdbg_amd import dist as D
@@ -24,7 +24,8 @@ def run(world, reads, k, l, d, a, batches_per_rank=2):
         try:
             with R.Mdbg(k, l, d, a, device=0) as m:
                 eng = D.GpuEngine(m, torch, dev)
-                drv = D.DistributedMdbg(eng, D.ThreadComm(tw, rank, torch), torch)
+                comm = D.ThreadComm(tw, rank, torch)
+                drv = D.DistributedMdbg(eng, comm, torch) if mode == "route" else D.ReplicatedMdbg(eng, comm, torch)
                 per = len(reads) // world
                 lo, hi = rank * per, (len(reads) if rank == world - 1 else (rank + 1) * per)
                 step = (hi - lo + batches_per_rank - 1) // batches_per_rank
@@ -44,19 +45,21 @@ def run(world, reads, k, l, d, a, batches_per_rank=2):
     return out
 
 
+@pytest.mark.parametrize("mode", ["route", "replicate"])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-def test_routed_path_matches_oracle(world):
+def test_routed_path_matches_oracle(world, mode):
     from rust_mdbg_amd import synth
     reads = synth.synth_reads(3, 120000, 160, mean_len=9000, sd_len=2000, min_len=2000, max_len=15000, err_ppm=1500)
-    parts = run(world, reads, 6, 12, 0.004, 2)
+    parts = run(world, reads, 6, 12, 0.004, 2, mode=mode)
     check_against_oracle(parts, reads, 6, 12, 0.004, 2)
 
 
+@pytest.mark.parametrize("mode", ["route", "replicate"])
 @pytest.mark.parametrize("k,l,d,a", [(21, 12, 0.003, 2), (35, 12, 0.002, 2), (4, 10, 0.01, 1), (5, 12, 0.01, 3)])
-def test_routed_path_configs(k, l, d, a):
+def test_routed_path_configs(k, l, d, a, mode):
     from rust_mdbg_amd import synth
     reads = synth.synth_reads(k, 300000, 500, mean_len=15000, sd_len=1500, min_len=8000, max_len=25000, err_ppm=1000)
-    parts = run(2, reads, k, l, d, a)
+    parts = run(2, reads, k, l, d, a, mode=mode)
     check_against_oracle(parts, reads, k, l, d, a)
     assert sum(p["n_local"] for p in parts) == parts[0]["n_nodes"] > 50
 
