@@ -433,22 +433,27 @@ __global__ __launch_bounds__(256) void gather_kernel(u32 n_tiles, const Rec* __r
     }
 }
 
-// exclusive scan of n_valid over the tiles of one launch, single workgroup; carry[0] in/out = running total
+// exclusive scan of n_valid over the tiles of one launch, single workgroup, 16 tiles per lane and round;
+// carry[0] in/out = running total
 __global__ __launch_bounds__(1024) void tile_scan_kernel(u32 n, const u32* __restrict__ n_valid, u64* __restrict__ tile_base, u64* __restrict__ carry) {
     __shared__ u64 wsum[16];
     __shared__ u64 run;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) run = carry[0];
     __syncthreads();
-    for (u32 i0 = 0; i0 < n; i0 += 1024) {
-        const u32 i = i0 + tid;
-        const u32 v = i < n ? n_valid[i] : 0;
-        u32 inc = wave_incl_scan(v);
+    for (u32 i0 = 0; i0 < n; i0 += 1024 * 16) {
+        const u32 first = i0 + tid * 16;
+        u32 v[16]; u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v[j] = first + j < n ? n_valid[first + j] : 0; mine += v[j]; }
+        const u32 inc = wave_incl_scan(mine);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
-        u64 b = run; u64 tot = 0;
+        u64 b = run, tot = 0;
         for (int k = 0; k < 16; ++k) { if (k < w) b += wsum[k]; tot += wsum[k]; }
-        if (i < n) tile_base[i] = b + inc - v;
+        b += inc - mine;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { if (first + j < n) tile_base[first + j] = b; b += v[j]; }
         __syncthreads();
         if (tid == 0) run += tot;
         __syncthreads();

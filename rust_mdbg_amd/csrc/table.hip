@@ -101,9 +101,15 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
             w = old;
         }
         if ((w >> 34) == fp) {
-            bool eq = true;
-            if (!(T.dbg & 4)) for (u32 j = 0; j < T.ks.k; ++j) if (rep_elem(T.ks, w, j) != mine(j)) { eq = false; break; }
-            if (eq) return s;
+            // full-key confirmation, four elements per round so that eight loads are in flight per round trip
+            const u32 k = T.ks.k;
+            u64 diff = 0;
+            u32 j = 0;
+            for (; j + 4 <= k && !diff; j += 4)
+                diff = (rep_elem(T.ks, w, j) ^ mine(j)) | (rep_elem(T.ks, w, j + 1) ^ mine(j + 1)) |
+                       (rep_elem(T.ks, w, j + 2) ^ mine(j + 2)) | (rep_elem(T.ks, w, j + 3) ^ mine(j + 3));
+            for (; j < k && !diff; ++j) diff = rep_elem(T.ks, w, j) ^ mine(j);
+            if (!diff) return s;
         }
         s = (s + 1) & T.mask;
     }
