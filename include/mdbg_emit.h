@@ -44,6 +44,21 @@ int mdbg_seqfile_write_batch(mdbg_seqfile* f, const mdbg_nodes* nodes, const uin
                              uint64_t n_reads, uint64_t first_read_ordinal);
 int mdbg_seqfile_close(mdbg_seqfile* f);
 
+/* ---- host ingest: FASTA / FASTQ, optionally gzip-compressed, into the batch layout of
+ * mdbg_ingest_batch.  Mirrors get_reader + the seq_io readers of the reference (src/main.rs:163-178,461-467,830-839):
+ * the format is decided by the FILE NAME (".fa"/".fasta" suffix or ".fa."/".fasta." inside -> FASTA, anything else ->
+ * FASTQ), ".gz" is read through zlib, ".lz4" input is not supported.  Like seq_io's RefRecord::seq(), a multi-line
+ * FASTA record keeps its interior line terminators unless strip_newlines is set (the reference strips them only with
+ * --reference, src/main.rs:737; otherwise such a read trips the ACGTN check, as it does in the reference). */
+typedef struct mdbg_reader mdbg_reader;
+mdbg_reader* mdbg_reader_open(const char* path, int strip_newlines, int* err);
+/* Next batch of whole records, at most max_bases bases unless a single record is longer (then that record alone).
+ * *n_reads == 0 at end of file.  bases/offsets (n_reads + 1 entries, offsets[0] = 0) belong to the reader and stay valid
+ * until the next call on it. */
+int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, const uint64_t** offsets, uint64_t* n_reads);
+int mdbg_reader_is_fasta(const mdbg_reader* r);
+void mdbg_reader_close(mdbg_reader* r);
+
 #ifdef __cplusplus
 }
 #endif

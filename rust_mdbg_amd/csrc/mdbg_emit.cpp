@@ -11,6 +11,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include <zlib.h>
+
 #include "../../include/mdbg_emit.h"
 
 namespace {
@@ -198,5 +200,104 @@ int mdbg_seqfile_close(mdbg_seqfile* s) {
     delete s;
     return ok ? MDBG_OK : MDBG_E_PARAM;
 }
+
+}  // extern "C"
+
+// ---- host ingest -------------------------------------------------------------------------------------
+struct mdbg_reader {
+    gzFile f = nullptr; bool fasta = false, strip = false, eof = false;
+    std::vector<u8> buf; size_t pos = 0, len = 0;            // input window
+    std::vector<u8> bases; std::vector<u64> offs;            // current batch
+    std::vector<u8> pending; bool have_pending = false;      // a parsed record that did not fit the previous batch
+    bool fill() {                                             // more input; false at EOF
+        if (eof) return false;
+        if (pos > 0) { memmove(buf.data(), buf.data() + pos, len - pos); len -= pos; pos = 0; }
+        if (buf.size() - len < (1u << 20)) buf.resize(buf.size() * 2);
+        const int n = gzread(f, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, 1u << 30));
+        if (n <= 0) { eof = true; return false; }
+        len += (size_t)n;
+        return true;
+    }
+    // next line [start, end) without its terminator; false at EOF with nothing left
+    bool line(size_t& s, size_t& e, bool& had_nl) {
+        for (size_t scan = pos;;) {
+            const u8* nl = (const u8*)memchr(buf.data() + scan, '\n', len - scan);
+            if (nl) { s = pos; e = (size_t)(nl - buf.data()); pos = e + 1; had_nl = true; return true; }
+            scan = len;
+            const size_t before = pos;
+            if (!fill()) { if (pos == len) return false; s = pos; e = len; pos = len; had_nl = false; return true; }
+            scan -= before - pos;                             // window was shifted
+        }
+    }
+    // parses one record's sequence into `out`; false at EOF
+    bool record(std::vector<u8>& out) {
+        out.clear();
+        size_t s, e; bool nl;
+        if (fasta) {
+            do { if (!line(s, e, nl)) return false; } while (e == s || buf[s] != '>');      // header line
+            // seq_io 0.3 RefRecord::seq(): everything between the header's line end and the record's last line end, interior
+            // line terminators included, one trailing '\r' trimmed
+            bool first = true;
+            for (;;) {
+                if (pos == len && !fill()) break;
+                if (pos < len && buf[pos] == '>') break;
+                if (!line(s, e, nl)) break;
+                if (!first) out.push_back('\n');
+                out.insert(out.end(), buf.begin() + s, buf.begin() + e);
+                first = false;
+            }
+            if (strip) { size_t w = 0; for (u8 ch : out) if (ch != '\n' && ch != '\r') out[w++] = ch; out.resize(w); }   // --reference, main.rs:737
+            else if (!out.empty() && out.back() == '\r') out.pop_back();
+            return true;
+        }
+        do { if (!line(s, e, nl)) return false; } while (e == s);                            // '@' header
+        if (!line(s, e, nl)) return false;                                                   // sequence
+        size_t ee = e; if (ee > s && buf[ee - 1] == '\r') --ee;
+        out.assign(buf.begin() + s, buf.begin() + ee);
+        if (!line(s, e, nl)) return true;                                                    // '+'
+        line(s, e, nl);                                                                      // qualities
+        return true;
+    }
+};
+
+extern "C" {
+
+mdbg_reader* mdbg_reader_open(const char* path, int strip_newlines, int* err) {
+    if (err) *err = MDBG_E_PARAM;
+    if (!path) return nullptr;
+    const std::string p(path);
+    auto ends = [&](const char* suf) { const size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
+    if (ends(".lz4")) return nullptr;                        // src/main.rs:172: lz4 input — not supported here
+    gzFile f = gzopen(path, "rb");                           // transparent for uncompressed files
+    if (!f) return nullptr;
+    gzbuffer(f, 1u << 20);
+    mdbg_reader* r = new mdbg_reader();
+    r->f = f; r->strip = strip_newlines != 0;
+    r->fasta = p.find(".fasta.") != std::string::npos || p.find(".fa.") != std::string::npos || ends(".fa") || ends(".fasta");   // main.rs:463
+    r->buf.resize(4u << 20);
+    r->offs.push_back(0);
+    if (err) *err = MDBG_OK;
+    return r;
+}
+
+int mdbg_reader_is_fasta(const mdbg_reader* r) { return r && r->fasta ? 1 : 0; }
+
+int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, const uint64_t** offsets, uint64_t* n_reads) {
+    if (!r || !bases || !offsets || !n_reads) return MDBG_E_PARAM;
+    r->bases.clear(); r->offs.assign(1, 0);
+    std::vector<u8> rec;
+    for (;;) {
+        if (r->have_pending) { rec.swap(r->pending); r->have_pending = false; }
+        else if (!r->record(rec)) break;
+        if (r->offs.size() > 1 && r->bases.size() + rec.size() > max_bases) { r->pending.swap(rec); r->have_pending = true; break; }
+        r->bases.insert(r->bases.end(), rec.begin(), rec.end());
+        r->offs.push_back(r->bases.size());
+        if (r->bases.size() >= max_bases) break;
+    }
+    *bases = r->bases.data(); *offsets = r->offs.data(); *n_reads = r->offs.size() - 1;
+    return MDBG_OK;
+}
+
+void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->f) gzclose(r->f); delete r; } }
 
 }  // extern "C"

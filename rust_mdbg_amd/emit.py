@@ -109,3 +109,51 @@ class Emitter:
             self.close()
         except Exception:
             pass
+
+
+# ---- host ingest (include/mdbg_emit.h: mdbg_reader_*) -----------------------------------------------------
+READER_EXPORTS = ["mdbg_reader_open", "mdbg_reader_next", "mdbg_reader_is_fasta", "mdbg_reader_close"]
+
+
+class Reader:
+    """FASTA/FASTQ(.gz) -> batches in the layout of Mdbg.ingest; format by file name like src/main.rs:461-467"""
+
+    def __init__(self, path, strip_newlines=False):
+        L = load_library()
+        L.mdbg_reader_open.restype = C.c_void_p
+        L.mdbg_reader_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+        L.mdbg_reader_next.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.mdbg_reader_is_fasta.argtypes = [C.c_void_p]
+        L.mdbg_reader_close.argtypes = [C.c_void_p]
+        L.mdbg_reader_close.restype = None
+        self.L = L
+        err = C.c_int()
+        self.h = L.mdbg_reader_open(path.encode(), int(strip_newlines), C.byref(err))
+        if not self.h:
+            raise OSError("cannot open %s (err %d; .lz4 input is not supported)" % (path, err.value))
+        self.is_fasta = bool(L.mdbg_reader_is_fasta(self.h))
+
+    def batches(self, max_bases=256 << 20):
+        """yields (bases uint8[:], offsets uint64[n+1]) copies, whole records, <= max_bases each"""
+        while True:
+            b, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+            rc = self.L.mdbg_reader_next(self.h, max_bases, C.byref(b), C.byref(o), C.byref(n))
+            if rc:
+                raise RuntimeError("mdbg_reader_next failed: %d" % rc)
+            if n.value == 0:
+                return
+            offs = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+            nb = int(offs[-1])
+            bases = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), shape=(max(nb, 1),))[:nb].copy()
+            yield bases, offs
+
+    def close(self):
+        if self.h:
+            self.L.mdbg_reader_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

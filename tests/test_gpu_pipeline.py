@@ -1,0 +1,38 @@
+"""End to end on the GPU box: reads-0.00.fa.gz -> host reader -> GPU hot path -> emitter -> .gfa / .sequences, compared with
+what the oracle's restatement of the reference produces for BASELINE configs[0] (k=7 l=10 d=0.0008 minabund=2)."""
+import os
+
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+from test_emit_cpu import oracle_edges, read_lz4_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def test_example_file_to_gfa(example_reads, tmp_path):
+    from rust_mdbg_amd import pipeline
+    prefix = str(tmp_path / "example")
+    k, l, d, a = 7, 10, 0.0008, 2
+    c = pipeline.run_file(os.path.join(GOLDEN, "reads-0.00.fa.gz"), prefix, k, l, d, a, batch_bases=3_000_000)    # 5 batches
+    assert (c["n_reads"], c["n_bases"], c["n_minimizers"], c["n_windows"]) == (657, 14744805, 16069, 12127)
+    assert (c["n_nodes_before"], c["n_nodes"], c["n_edges"], c["presimp_removed"]) == (104, 104, 206, 0)
+    g = O.Graph(k, l, d, a)
+    b, o = O.concat_reads(example_reads)
+    g.ingest(b, o)
+    r = g.finalize(with_edges=True)
+    lines = open(prefix + ".gfa").read().split("\n")
+    assert lines[0] == "H\tVN:Z:1.0"
+    assert [x for x in lines if x.startswith("S")] == ["S\t%d\t*\tLN:i:%d\tKC:i:%d" % (r["index"][i], r["seqlen"][i], r["abundance"][i]) for i in range(104)]
+    assert sorted(x for x in lines if x.startswith("L")) == sorted("L\t%d\t%s\t%d\t%s\t%dM" % (x, chr(p), y, chr(q), ov) for x, p, y, q, ov in oracle_edges(r))
+    body = [x for x in read_lz4_frame(prefix + ".0.sequences").decode().split("\n")[4:] if x]
+    assert len(body) == 104
+    by_id = {int(line.split("\t")[0]): line for line in body}
+    assert sorted(by_id) == [int(x) for x in r["index"]]
+    for i in range(104):
+        f = by_id[int(r["index"][i])].split("\t")
+        seq = example_reads[int(r["src_read"][i])][int(r["src_start"][i]):int(r["src_end"][i])]
+        if r["reversed"][i]:
+            seq = O.revcomp(seq)
+        assert f[0] == str(r["index"][i]) and f[2] == seq.decode() and f[5] == "(%d, %d)" % tuple(int(v) for v in r["shift_full"][i])
