@@ -170,6 +170,11 @@ def main():
         total_bases = int(nb.item())
     else:
         total_bases = n_bases
+    consistent = None
+    if routed:               # outside the timed region: the ranks' partitions must add up to the global node count
+        loc = torch.tensor([runner.last_local], device="cuda", dtype=torch.int64)
+        dist.all_reduce(loc)
+        consistent = bool(int(loc.item()) == int(n_nodes))
     st = m.stats()          # stats of the last step only (reset clears the timers)
     if routed and engine.tm is not m:
         st2 = engine.tm.stats()
@@ -206,7 +211,8 @@ def main():
                "roofline": roof, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_tile_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
-                         "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"]}}
+                         "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
+                         "partitions_add_up": consistent}}
         print(json.dumps(out))
     m.close()
     if routed and engine.tm is not m:

@@ -23,7 +23,6 @@ struct TileArgs {
     const u32* tbl;              // device copy of SketchConsts::tbl
     u32 read_base;               // slot index of the batch's first read in the resident store
     u64* dbg;                    // diagnostic: per-tile phase timestamps [n_tiles][8] (null in production)
-    u32 dbgflags;                // diagnostic ablation switches (MDBG_TILE_DBG), 0 in production
     SketchConsts c;
 };
 
@@ -85,6 +84,7 @@ __global__ __launch_bounds__(256) void slow_tile_kernel(TileArgs a, const u64* _
         if (p < tile_end) {
             r = find_read(a.offsets, rl, rh_, p);
             rlo = a.offsets[r];
+            if (!WRITE) { const u8 c = a.bases[p]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') *a.err_flag = 1; }   // host decides (read length rule)
             if (p >= rlo && kept_ascii<HPC>(a.bases, rlo, p) && walk_lmer_ascii<HPC>(a.bases, rlo, p, a.c.l, start, hash) && hash <= a.c.bound) sel = 1;
         }
         u32 total;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
 #pragma unroll
     for (int i = 0; i < 8; ++i) cb[i] = 0;
     bool force = false;                       // first l-1 pushes of my segment must all be candidates
-    const bool active = tile_start + (int64_t)tid * SEG < nb && !(a.dbgflags & 2);
+    const bool active = tile_start + (int64_t)tid * SEG < nb;
     if (active) {
         RollState st;
         // warm-up: the same loop, silently, over the 32 bases before my segment (then the whole 128-base halo).  The
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
     auto code_at = [&](int64_t q) -> u32 { const int rel = (int)(q - tile_start); return (codes[rel >> 4] >> (2 * (rel & 15))) & 3u; };
     u32 nval = 0;
     Rec* slab = a.slab + (size_t)t * QCAP;
-    for (u32 j = tid; j < ((a.dbgflags & 4) ? 0u : n_cand); j += TILE_THREADS) {
+    for (u32 j = tid; j < n_cand; j += TILE_THREADS) {
         const int64_t p = tile_start + list[j];
         Rec rec; rec.hash = 0; rec.pos = 0; rec.read = 0xFFFFFFFFu;
         if (p < nb) {
@@ -478,7 +478,7 @@ struct SketchLaunch {
     u32* bread; u64 n_tiles_total;
     Rec* slab; u32* n_cand; u32* n_valid; u64* tile_base; u32* slow_list; u32* slow_count; u32* err_flag; u64* carry;
     u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
-    SketchConsts c; const u32* tbl; bool force_slow; u64* slow_total; u32 read_base; u64* dbg; u32 dbgflags;
+    SketchConsts c; const u32* tbl; bool force_slow; u64* slow_total; u32 read_base; u64* dbg;
 };
 
 void launch_bread(const SketchLaunch& L, hipStream_t s) {
@@ -491,7 +491,7 @@ void launch_sketch_chunk(const SketchLaunch& L, u64 tile0, u32 n, hipStream_t s,
     TileArgs a;
     a.bases = L.bases; a.n_bases = L.n_bases; a.offsets = L.offsets; a.n_reads = L.n_reads; a.bread = L.bread;
     a.tile0 = tile0; a.n_tiles = n; a.slab = L.slab; a.n_cand = L.n_cand; a.n_valid = L.n_valid;
-    a.slow_list = L.slow_list; a.slow_count = L.slow_count; a.err_flag = L.err_flag; a.c = L.c; a.tbl = L.tbl; a.read_base = L.read_base; a.dbg = L.dbg; a.dbgflags = L.dbgflags;
+    a.slow_list = L.slow_list; a.slow_count = L.slow_count; a.err_flag = L.err_flag; a.c = L.c; a.tbl = L.tbl; a.read_base = L.read_base; a.dbg = L.dbg;
     (void)hipMemsetAsync(L.slow_count, 0, sizeof(u32), s);
     const bool hpc = L.c.hpc != 0;
     if (L.force_slow || L.c.l > (u32)FAST_MAX_L) {

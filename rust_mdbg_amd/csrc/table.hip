@@ -67,7 +67,6 @@ struct TableArgs {
     u32 A;
     u64* n_distinct;              // device counter
     KeySrc ks;
-    u32 dbg;                      // experiment switches (MDBG_DBG), 0 in production
     u32 own_world, own_rank;      // replicated-sketch mode: insert only windows owned by own_rank (own_world <= 1: all)
 };
 
@@ -140,7 +139,6 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     if (T.own_world > 1 && window_owner(w, k, T.own_world) != T.own_rank) return;
     const bool rev = window_reversed(w, k);
     const u64 h = key_hash_window(w, k, rev);
-    if (T.dbg & 8) { if (h == 12345) *cap_err = 2; return; }
     bool claimed;
     const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u32 j) { return rev ? w[k - 1 - j] : w[j]; }, claimed);
     if (claimed) return;                       // the claimer is accounted for through `rep` (slot_view)

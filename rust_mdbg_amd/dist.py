@@ -78,7 +78,7 @@ class TorchDistComm:
         t, dist = self.torch, self.dist
         mx = max(sizes) if sizes else 0
         outs = [t.empty(n, dtype=x.dtype, device=self.device) for n in sizes]
-        step = max(1, self.max_bytes // max(1, x.element_size()))
+        step = max(1, min(self.max_bytes, 64 << 20) // max(1, x.element_size()))      # <= 64 MB per rank and round
         for a in range(0, mx, step):
             n = min(step, mx - a)
             mine = t.zeros(n, dtype=x.dtype, device=self.device)
@@ -410,7 +410,9 @@ class DistributedMdbg:
                     n_nodes=n_nodes, n_nodes_before=n_before, n_local=int(sel.shape[0]))
 
     def finalize_device_count(self):
-        return self.finalize()["n_nodes"]
+        part = self.finalize()
+        self.last_local = part["n_local"]
+        return part["n_nodes"]
 
 
 class ReplicatedMdbg:
@@ -462,7 +464,9 @@ class ReplicatedMdbg:
         return self.e.finalize_end()
 
     def finalize_device_count(self):
-        return self.finalize()["n_nodes"]
+        part = self.finalize()
+        self.last_local = part["n_local"]
+        return part["n_nodes"]
 
 
 def plan_chunks(offsets_host, n_chunks):
