@@ -54,7 +54,7 @@ def pmc_traffic(bases_per_launch, args):
         try:
             j = json.load(open(p))
             ref = json.load(open(p.replace("_pmc_traffic.json", "_bench.json")))
-            k = j["kernels"]["sketch_tile_kernel<true>" if True else ""]
+            k = j["kernels"]["sketch_tile_kernel<true>"]       # <true> = homopolymer compression on (the bench never passes --reads-already-hpc)
             c = ref["config"]
             same = (c["k"], c["l"], c["density"], c["minabund"]) == (args.k, args.l, args.density, args.minabund) and \
                 abs(c["bases_per_gpu"] / ref["roofline"]["launches_per_step"] - bases_per_launch) < 1e-6 * bases_per_launch
