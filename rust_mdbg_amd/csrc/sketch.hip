@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void slow_tile_kernel(TileArgs a, const u64* _
                                                         u64* __restrict__ out_hash, u32* __restrict__ out_pos,
                                                         u32* __restrict__ out_read, u64 out_cap) {
     __shared__ u32 tmp[8];
-    const u32 s = blockIdx.x;
-    if (s >= *a.slow_count) return;
+    const u32 n_slow = *a.slow_count;
+    for (u32 s = blockIdx.x; s < n_slow; s += gridDim.x) {
     const u32 t = a.slow_list[s];
     const u64 gt = a.tile0 + t;
     const u64 tile_start = gt * (u64)TILE;
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256) void slow_tile_kernel(TileArgs a, const u64* _
         running += total;
     }
     if (!WRITE && threadIdx.x == 0) a.n_valid[t] = running;
+    __syncthreads();
+    }
 }
 
 // marks every tile of the launch slow (l > FAST_MAX_L or forced)
@@ -414,51 +416,70 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
 __global__ __launch_bounds__(256) void gather_kernel(u32 n_tiles, const Rec* __restrict__ slab, const u32* __restrict__ n_cand,
                                                      const u64* __restrict__ tile_base, u64* __restrict__ out_hash,
                                                      u32* __restrict__ out_pos, u32* __restrict__ out_read, u64 out_cap) {
-    __shared__ u32 tmp[8];
-    const u32 t = blockIdx.x;
+    const u32 t = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per tile
     if (t >= n_tiles) return;
+    const u32 lane = threadIdx.x & 63;
     const u32 nc = n_cand[t];
     if (nc == SLOW_MARK || nc == 0) return;
     const Rec* s = slab + (size_t)t * QCAP;
     u64 base = tile_base[t];
-    for (u32 j0 = 0; j0 < nc; j0 += 256) {
-        const u32 j = j0 + threadIdx.x;
+    for (u32 j0 = 0; j0 < nc; j0 += 64) {
+        const u32 j = j0 + lane;
         Rec r; r.read = 0xFFFFFFFFu;
         if (j < nc) r = s[j];
-        const u32 v = r.read != 0xFFFFFFFFu;
-        u32 total;
-        const u32 rank = block_excl_scan_256(v, tmp, total);
-        if (v) { const u64 idx = base + rank; if (idx < out_cap) { out_hash[idx] = r.hash; out_pos[idx] = r.pos; out_read[idx] = r.read; } }
-        base += total;
+        const bool v = r.read != 0xFFFFFFFFu;
+        const u64 m = __ballot(v);
+        if (v) {
+            const u64 idx = base + __popcll(m & ((1ull << lane) - 1));
+            if (idx < out_cap) { out_hash[idx] = r.hash; out_pos[idx] = r.pos; out_read[idx] = r.read; }
+        }
+        base += __popcll(m);
     }
 }
 
-// exclusive scan of n_valid over the tiles of one launch, single workgroup, 16 tiles per lane and round;
-// carry[0] in/out = running total
-__global__ __launch_bounds__(1024) void tile_scan_kernel(u32 n, const u32* __restrict__ n_valid, u64* __restrict__ tile_base, u64* __restrict__ carry) {
-    __shared__ u64 wsum[16];
-    __shared__ u64 run;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// exclusive scan of n_valid over the tiles of one launch (carry[0] in/out = running total), three small kernels:
+// sums of 1024-tile blocks, scan of the block sums by one workgroup, per-block scan + base.
+__global__ __launch_bounds__(1024) void tile_scan_sums_kernel(u32 n, const u32* __restrict__ n_valid, u64* __restrict__ block_sum) {
+    __shared__ u32 ws[16];
+    const u32 i = blockIdx.x * 1024 + threadIdx.x;
+    u32 v = i < n ? n_valid[i] : 0;
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 t = 0; for (int q = 0; q < 16; ++q) t += ws[q]; block_sum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void tile_scan_top_kernel(u32 n_blocks, u64* __restrict__ block_sum, u64* __restrict__ carry) {
+    __shared__ u64 ws[16]; __shared__ u64 run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) run = carry[0];
     __syncthreads();
-    for (u32 i0 = 0; i0 < n; i0 += 1024 * 16) {
-        const u32 first = i0 + tid * 16;
-        u32 v[16]; u32 mine = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { v[j] = first + j < n ? n_valid[first + j] : 0; mine += v[j]; }
-        const u32 inc = wave_incl_scan(mine);
-        if (lane == 63) wsum[w] = inc;
+    for (u32 i0 = 0; i0 < n_blocks; i0 += 1024) {
+        const u32 i = i0 + tid;
+        const u64 v = i < n_blocks ? block_sum[i] : 0;
+        u64 inc = v;
+        for (int d = 1; d < 64; d <<= 1) { const u64 o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) ws[wv] = inc;
         __syncthreads();
         u64 b = run, tot = 0;
-        for (int k = 0; k < 16; ++k) { if (k < w) b += wsum[k]; tot += wsum[k]; }
-        b += inc - mine;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { if (first + j < n) tile_base[first + j] = b; b += v[j]; }
+        for (int q = 0; q < 16; ++q) { if (q < wv) b += ws[q]; tot += ws[q]; }
+        if (i < n_blocks) block_sum[i] = b + inc - v;
         __syncthreads();
         if (tid == 0) run += tot;
         __syncthreads();
     }
     if (tid == 0) carry[0] = run;
+}
+__global__ __launch_bounds__(1024) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base) {
+    __shared__ u32 ws[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 i = blockIdx.x * 1024 + tid;
+    const u32 v = i < n ? n_valid[i] : 0;
+    const u32 inc = wave_incl_scan(v);
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    u64 b = block_base[blockIdx.x];
+    for (int q = 0; q < wv; ++q) b += ws[q];
+    if (i < n) tile_base[i] = b + inc - v;
 }
 
 // per-read offsets into the ordered minimizer arrays: off[slot] = first i with mread[i] >= slot, for the batch's
@@ -476,7 +497,7 @@ __global__ void acc_slow_kernel(const u32* __restrict__ slow_count, u64* __restr
 struct SketchLaunch {
     const u8* bases; u64 n_bases; const u64* offsets; u32 n_reads;
     u32* bread; u64 n_tiles_total;
-    Rec* slab; u32* n_cand; u32* n_valid; u64* tile_base; u32* slow_list; u32* slow_count; u32* err_flag; u64* carry;
+    Rec* slab; u32* n_cand; u32* n_valid; u64* tile_base; u64* scan_tmp; u32* slow_list; u32* slow_count; u32* err_flag; u64* carry;
     u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
     SketchConsts c; const u32* tbl; bool force_slow; u64* slow_total; u32 read_base; u64* dbg;
 };
@@ -502,12 +523,15 @@ void launch_sketch_chunk(const SketchLaunch& L, u64 tile0, u32 n, hipStream_t s,
         else     hipLaunchKernelGGL(sketch_tile_kernel<false>, dim3(n), dim3(TILE_THREADS), 0, s, a);
         if (ev_end) (void)hipEventRecord(ev_end, s);
     }
-    if (hpc) hipLaunchKernelGGL((slow_tile_kernel<true, false>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
-    else     hipLaunchKernelGGL((slow_tile_kernel<false, false>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n, L.n_valid, L.tile_base, L.carry);
-    hipLaunchKernelGGL(gather_kernel, dim3(n), dim3(256), 0, s, n, L.slab, L.n_cand, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
-    if (hpc) hipLaunchKernelGGL((slow_tile_kernel<true, true>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
-    else     hipLaunchKernelGGL((slow_tile_kernel<false, true>), dim3(n), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    if (hpc) hipLaunchKernelGGL((slow_tile_kernel<true, false>), dim3(n < 4096 ? n : 4096), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    else     hipLaunchKernelGGL((slow_tile_kernel<false, false>), dim3(n < 4096 ? n : 4096), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    const u32 nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(1024), 0, s, n, L.n_valid, L.scan_tmp);
+    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(1024), 0, s, nb, L.scan_tmp, L.carry);
+    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(1024), 0, s, n, L.n_valid, L.scan_tmp, L.tile_base);
+    hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, L.slab, L.n_cand, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    if (hpc) hipLaunchKernelGGL((slow_tile_kernel<true, true>), dim3(n < 4096 ? n : 4096), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
+    else     hipLaunchKernelGGL((slow_tile_kernel<false, true>), dim3(n < 4096 ? n : 4096), dim3(256), 0, s, a, L.tile_base, L.out_hash, L.out_pos, L.out_read, L.out_cap);
     hipLaunchKernelGGL(acc_slow_kernel, dim3(1), dim3(1), 0, s, L.slow_count, L.slow_total);
 }
 

@@ -62,13 +62,18 @@ __device__ inline u64 key_hash_canon(const u64* __restrict__ key, u32 k) {
 }
 
 struct TableArgs {
-    Slot* tab; u64 mask;          // capacity - 1 (power of two)
+    Slot* tab; u64 cap;           // number of slots (any value >= 1024)
     u64* mx;                      // [capacity][A-2] further minima when A > 2, else null
     u32 A;
     u64* n_distinct;              // device counter
     KeySrc ks;
     u32 own_world, own_rank;      // replicated-sketch mode: insert only windows owned by own_rank (own_world <= 1: all)
 };
+
+// Home slot of a key hash: range reduction by multiplication, so the capacity need not be a power of two.  It is fed
+// from the LOW 40 bits of the hash: the high bits choose the owning rank in the routed mode (route.hip) and the
+// fingerprint, and must stay independent of the position inside one rank's table.
+__device__ inline u64 home_slot(u64 h, u64 cap) { return __umul64hi(h << 24, cap); }
 
 // insert ordinal x into the slot's A smallest
 __device__ inline void push_ordinal(const TableArgs& T, u64 s, u64 x) {
@@ -91,7 +96,7 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
     claimed = false;
     const u64 fp = (h >> 34) & 0x3FFFFFFFull;
     const u64 myword = (fp << 34) | myword_lo;
-    u64 s = h & T.mask;
+    u64 s = home_slot(h, T.cap);
     for (;;) {
         u64 w = load_relaxed(&T.tab[s].word);
         if (w == EMPTY) {
@@ -110,7 +115,7 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
             for (; j < k && !diff; ++j) diff = rep_elem(T.ks, w, j) ^ mine(j);
             if (!diff) return s;
         }
-        s = (s + 1) & T.mask;
+        s = s + 1 == T.cap ? 0 : s + 1;
     }
 }
 
@@ -182,11 +187,11 @@ __global__ void rehash_kernel(const Slot* __restrict__ old, u64 old_cap, const u
     u64 h = 0x243F6A8885A308D3ull;
     for (u32 j = 0; j < k; ++j) { h = (h ^ rep_elem(T.ks, e.word, j)) * HMUL; h ^= h >> 29; }
     h = fmix64(h);
-    u64 s = h & T.mask;
+    u64 s = home_slot(h, T.cap);
     for (;;) {
         const u64 oldw = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)e.word);
         if (oldw == EMPTY) break;
-        s = (s + 1) & T.mask;
+        s = s + 1 == T.cap ? 0 : s + 1;
     }
     T.tab[s].m1 = e.m1; T.tab[s].m2 = e.m2; T.tab[s].count = e.count;
     for (u32 j = 0; j + 2 < T.A; ++j) T.mx[s * (T.A - 2) + j] = old_mx[i * (T.A - 2) + j];
@@ -291,41 +296,62 @@ __global__ void count_owned_windows_kernel(const u64* __restrict__ mh, const u32
     const u64 m = __ballot(mine);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd((unsigned long long*)ctr_shard(out), (unsigned long long)__popcll(m));
 }
-__global__ void count_windows_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32 k, u64* __restrict__ out) {
+__global__ __launch_bounds__(1024) void count_windows_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32 k, u64* __restrict__ out) {
+    __shared__ u64 ws[16];
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     u64 w = 0;
     if (r < n_reads) { const u64 n = roff[slot0 + r + 1] - roff[slot0 + r]; if (n > k) w = n - k + 1; }
     for (int d = 32; d; d >>= 1) w += __shfl_down(w, d, 64);
-    if ((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)out, (unsigned long long)w);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {                  // one atomic per workgroup: same-address atomics serialise (~12 ns each)
+        u64 t = 0;
+        for (int i = 0; i < 16; ++i) t += ws[i];
+        if (t) atomicAdd((unsigned long long*)out, (unsigned long long)t);
+    }
 }
 
-__global__ void fin_emit_kernel(FinArgs F, u64 n_solid) {
-    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_solid) return;
-    const u64 s = F.solid_list[q];
-    const Slot e = F.tab[s];
-    const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word));
+// One thread per solid node for the scalar fields; the k key values of a workgroup's 256 nodes are then copied by
+// the whole workgroup, consecutive lanes on consecutive values, so that every row of o_keys is written as one run.
+__global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
+    __shared__ u64 sh_src[256];              // minimizer index of the A-th sighting | reversed << 63
+    __shared__ u64 sh_row[256];
+    const u64 q0 = (u64)blockIdx.x * 256, q = q0 + threadIdx.x;
     const u32 k = F.k;
-    u64 i1, D; decode_ordinal(F, v.first, i1, D);
-    const u64 below = (1ull << (D & 63)) - 1;
-    const u64 row = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);          // row of the node in index order
-    const u64 n = F.o_row ? q : row;
-    if (F.o_row) F.o_row[q] = row;
-    F.o_index[n] = F.pre_first[D >> 6] + __popcll(F.bm_first[D >> 6] & below);           // NODE_INDEX order (main.rs:661)
-    F.o_abund[n] = (u16)v.count;
-    // the A-th sighting (main.rs:680-684): seqlen, shift and the sequence's origin
-    const u64 oa = v.ath;
-    u64 i, Da; decode_ordinal(F, oa, i, Da);
-    const u64* w = F.mh + i; const u32* p = F.mpos + i;
-    const bool rev = window_reversed(w, k);
-    for (u32 j = 0; j < k; ++j) F.o_keys[n * k + j] = rev ? w[k - 1 - j] : w[j];
-    const u64 first = p[1] - p[0], last = p[k - 1] - p[k - 2];                             // main.rs:769-776
-    const u64 s0 = rev ? last : first, s1 = rev ? first : last;
-    F.o_seqlen[n] = (u32)((u64)p[k - 1] + 1 - p[0] + 1);                                   // main.rs:778 (read_offsets.2)
-    F.o_shift[2 * n] = (u16)s0; F.o_shift[2 * n + 1] = (u16)s1;                            // main.rs:675
-    F.o_shift_full[2 * n] = s0; F.o_shift_full[2 * n + 1] = s1;
-    F.o_src_read[n] = oa >> WIN_BITS; F.o_src_start[n] = p[0]; F.o_src_end[n] = (u64)p[k - 1] + F.l;
-    F.o_rev[n] = rev ? 1 : 0;
+    if (q < n_solid) {
+        const u64 s = F.solid_list[q];
+        const Slot e = F.tab[s];
+        const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word));
+        u64 i1, D; decode_ordinal(F, v.first, i1, D);
+        const u64 below = (1ull << (D & 63)) - 1;
+        const u64 row = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);          // row of the node in index order
+        const u64 n = F.o_row ? q : row;
+        if (F.o_row) F.o_row[q] = row;
+        F.o_index[n] = F.pre_first[D >> 6] + __popcll(F.bm_first[D >> 6] & below);           // NODE_INDEX order (main.rs:661)
+        F.o_abund[n] = (u16)v.count;
+        // the A-th sighting (main.rs:680-684): seqlen, shift and the sequence's origin
+        const u64 oa = v.ath;
+        u64 i, Da; decode_ordinal(F, oa, i, Da);
+        const u64* w = F.mh + i; const u32* p = F.mpos + i;
+        const bool rev = window_reversed(w, k);
+        sh_src[threadIdx.x] = i | ((u64)rev << 63); sh_row[threadIdx.x] = n;
+        const u64 first = p[1] - p[0], last = p[k - 1] - p[k - 2];                             // main.rs:769-776
+        const u64 s0 = rev ? last : first, s1 = rev ? first : last;
+        F.o_seqlen[n] = (u32)((u64)p[k - 1] + 1 - p[0] + 1);                                   // main.rs:778 (read_offsets.2)
+        F.o_shift[2 * n] = (u16)s0; F.o_shift[2 * n + 1] = (u16)s1;                            // main.rs:675
+        F.o_shift_full[2 * n] = s0; F.o_shift_full[2 * n + 1] = s1;
+        F.o_src_read[n] = oa >> WIN_BITS; F.o_src_start[n] = p[0]; F.o_src_end[n] = (u64)p[k - 1] + F.l;
+        F.o_rev[n] = rev ? 1 : 0;
+    }
+    __syncthreads();
+    const u32 nodes = (u32)(n_solid - q0 < 256 ? n_solid - q0 : 256);
+    const u32 total = nodes * k;
+    for (u32 e = threadIdx.x; e < total; e += 256) {
+        const u32 g = e / k, j = e - g * k;
+        const u64 src = sh_src[g];
+        const u64 i = src & ~(1ull << 63);
+        F.o_keys[sh_row[g] * k + j] = F.mh[i + ((src >> 63) ? k - 1 - j : j)];
+    }
 }
 
 // exclusive prefix of popcounts over 64-bit words: pre[w] = sum_{v<w} popc(bm[v]); three kernels
@@ -433,7 +459,7 @@ void launch_rebase_offsets(const u64* rel, u32 n_reads, u64 m0, u64* roff_out, h
 }
 void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* out, hipStream_t s) {
     if (!n_reads) return;
-    hipLaunchKernelGGL(count_windows_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, roff, slot0, n_reads, k, out);
+    hipLaunchKernelGGL(count_windows_kernel, dim3((n_reads + 1023) / 1024), dim3(1024), 0, s, roff, slot0, n_reads, k, out);
 }
 void launch_fin_mark(const FinArgs& F, hipStream_t s) {
     hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 1023) / 1024)), dim3(1024), 0, s, F);
