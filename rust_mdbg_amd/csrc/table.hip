@@ -50,15 +50,28 @@ __device__ inline bool window_reversed(const u64* __restrict__ w, u32 k) {
     }
     return true;
 }
+// Hash of a canonical key given by an accessor elem(j): four independent multiply-xorshift chains over j mod 4 (the
+// chain of one lane would otherwise be k dependent 64-bit multiplies), folded and finished with fmix64.
+template <class ElemFn>
+__device__ inline u64 key_hash_fn(ElemFn elem, u32 k) {
+    u64 h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull, h2 = 0xA4093822299F31D0ull, h3 = 0x082EFA98EC4E6C89ull;
+    u32 j = 0;
+    for (; j + 4 <= k; j += 4) {
+        h0 = (h0 ^ elem(j)) * HMUL;     h0 ^= h0 >> 29;
+        h1 = (h1 ^ elem(j + 1)) * HMUL; h1 ^= h1 >> 29;
+        h2 = (h2 ^ elem(j + 2)) * HMUL; h2 ^= h2 >> 29;
+        h3 = (h3 ^ elem(j + 3)) * HMUL; h3 ^= h3 >> 29;
+    }
+    if (j < k) { h0 = (h0 ^ elem(j)) * HMUL; h0 ^= h0 >> 29; }
+    if (j + 1 < k) { h1 = (h1 ^ elem(j + 1)) * HMUL; h1 ^= h1 >> 29; }
+    if (j + 2 < k) { h2 = (h2 ^ elem(j + 2)) * HMUL; h2 ^= h2 >> 29; }
+    return fmix64(h0 ^ rol64(h1, 17) ^ rol64(h2, 31) ^ rol64(h3, 47));
+}
 __device__ inline u64 key_hash_window(const u64* __restrict__ w, u32 k, bool rev) {
-    u64 h = 0x243F6A8885A308D3ull;
-    for (u32 j = 0; j < k; ++j) { const u64 x = rev ? w[k - 1 - j] : w[j]; h = (h ^ x) * HMUL; h ^= h >> 29; }
-    return fmix64(h);
+    return key_hash_fn([&](u32 j) { return rev ? w[k - 1 - j] : w[j]; }, k);
 }
 __device__ inline u64 key_hash_canon(const u64* __restrict__ key, u32 k) {
-    u64 h = 0x243F6A8885A308D3ull;
-    for (u32 j = 0; j < k; ++j) { h = (h ^ key[j]) * HMUL; h ^= h >> 29; }
-    return fmix64(h);
+    return key_hash_fn([&](u32 j) { return key[j]; }, k);
 }
 
 struct TableArgs {
@@ -90,9 +103,9 @@ __device__ inline void push_ordinal(const TableArgs& T, u64 s, u64 x) {
     }
 }
 
-// find-or-claim the slot of a key given by an accessor mine(j) = canonical element j
-template <class KeyFn>
-__device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyFn mine, bool& claimed) {
+// find-or-claim the slot of a key; same_key(word) = full comparison of my key with the representative a slot word names
+template <class EqFn>
+__device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, EqFn same_key, bool& claimed) {
     claimed = false;
     const u64 fp = (h >> 34) & 0x3FFFFFFFull;
     const u64 myword = (fp << 34) | myword_lo;
@@ -104,18 +117,49 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, KeyF
             if (old == EMPTY) { wave_agg_inc(T.n_distinct); claimed = true; return s; }
             w = old;
         }
-        if ((w >> 34) == fp) {
-            // full-key confirmation, four elements per round so that eight loads are in flight per round trip
-            const u32 k = T.ks.k;
-            u64 diff = 0;
-            u32 j = 0;
-            for (; j + 4 <= k && !diff; j += 4)
-                diff = (rep_elem(T.ks, w, j) ^ mine(j)) | (rep_elem(T.ks, w, j + 1) ^ mine(j + 1)) |
-                       (rep_elem(T.ks, w, j + 2) ^ mine(j + 2)) | (rep_elem(T.ks, w, j + 3) ^ mine(j + 3));
-            for (; j < k && !diff; ++j) diff = rep_elem(T.ks, w, j) ^ mine(j);
-            if (!diff) return s;
-        }
+        if ((w >> 34) == fp && same_key(w)) return s;
         s = s + 1 == T.cap ? 0 : s + 1;
+    }
+}
+// scalar comparison through the accessors (routed records, any key source)
+template <class KeyFn>
+__device__ inline bool same_key_scalar(const KeySrc& ks, u64 w, KeyFn mine) {
+    const u32 k = ks.k;
+    u64 diff = 0;
+    u32 j = 0;
+    for (; j + 4 <= k && !diff; j += 4)       // four elements per round so that eight loads are in flight per round trip
+        diff = (rep_elem(ks, w, j) ^ mine(j)) | (rep_elem(ks, w, j + 1) ^ mine(j + 1)) |
+               (rep_elem(ks, w, j + 2) ^ mine(j + 2)) | (rep_elem(ks, w, j + 3) ^ mine(j + 3));
+    for (; j < k && !diff; ++j) diff = rep_elem(ks, w, j) ^ mine(j);
+    return !diff;
+}
+// comparison of a window staged in LDS (wl[0..k), orientation rev_mine) with the representative in HBM: both are
+// contiguous, so the representative is read 16 bytes per load, eight values per round trip; the last round overlaps.
+typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, bool rev_mine) {
+    const u32 k = ks.k, rep = (u32)w;
+    const u64* rp; bool cross;                // cross: rp[j] pairs with wl[k-1-j]
+    if (w & (1ull << 33)) { rp = ks.arena + (u64)rep * (k + 2); cross = rev_mine; }
+    else { rp = ks.mh + rep; cross = rev_mine != ((w & (1ull << 32)) != 0); }
+    if (k < 8) {
+        u64 diff = 0;
+        for (u32 j = 0; j < k; ++j) diff |= rp[j] ^ wl[cross ? k - 1 - j : j];
+        return !diff;
+    }
+    for (u32 j = 0;; j += 8) {
+        if (j + 8 > k) j = k - 8;
+        const u64x2_a8 a0 = *(const u64x2_a8*)(rp + j), a1 = *(const u64x2_a8*)(rp + j + 2),
+                       a2 = *(const u64x2_a8*)(rp + j + 4), a3 = *(const u64x2_a8*)(rp + j + 6);
+        u64 diff;
+        if (!cross) {
+            const u64* m = wl + j;
+            diff = (a0.x ^ m[0]) | (a0.y ^ m[1]) | (a1.x ^ m[2]) | (a1.y ^ m[3]) | (a2.x ^ m[4]) | (a2.y ^ m[5]) | (a3.x ^ m[6]) | (a3.y ^ m[7]);
+        } else {
+            const u64* m = wl + (k - 8 - j);   // m[7-t] pairs with rp[j+t]
+            diff = (a0.x ^ m[7]) | (a0.y ^ m[6]) | (a1.x ^ m[5]) | (a1.y ^ m[4]) | (a2.x ^ m[3]) | (a2.y ^ m[2]) | (a3.x ^ m[1]) | (a3.y ^ m[0]);
+        }
+        if (diff) return false;
+        if (j + 8 >= k) return true;
     }
 }
 
@@ -127,29 +171,39 @@ __device__ inline u32 window_owner(const u64* __restrict__ w, u32 k, u32 world) 
 }
 
 // one thread per minimizer index i in [i0, i1): if a window of k starts at i inside its read, upsert it.
-// src/main.rs:756 — only reads with MORE than k minimizers contribute.
+// src/main.rs:756 — only reads with MORE than k minimizers contribute.  The 256 + k - 1 values a workgroup's windows
+// cover are staged in LDS once (dynamic LDS: (256 + k) * 8 bytes); orientation, hash and the own side of the key
+// comparison read them from there.
 __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
                                                              const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
-                                                             u64* __restrict__ n_windows, u32* __restrict__ cap_err) {
-    const u64 i = i0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= i1) return;
+                                                             u32* __restrict__ cap_err) {
+    extern __shared__ u64 sh_keys[];
     const u32 k = T.ks.k;
-    const u32 slot = mread[i];
-    const u64 rs = roff[slot], re = roff[slot + 1];
-    if (re - rs <= k || i + k > re) return;
-    const u64 win = i - rs;
-    if (win > WIN_MASK) { *cap_err = 1; return; }
-    const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
-    const u64* w = mh + i;
+    const u64 b0 = i0 + (u64)blockIdx.x * 256;
+    const u64 lim = b0 + 256 + k - 1 < i1 ? b0 + 256 + k - 1 : i1;     // windows never extend past their batch
+    for (u64 t = b0 + threadIdx.x; t < lim; t += 256) sh_keys[t - b0] = mh[t];
+    const u64 i = b0 + threadIdx.x;
+    bool active = i < i1;
+    u64 ord = 0;
+    if (active) {
+        const u32 slot = mread[i];
+        const u64 rs = roff[slot], re = roff[slot + 1];
+        active = re - rs > k && i + k <= re;
+        const u64 win = i - rs;
+        if (active && win > WIN_MASK) { *cap_err = 1; active = false; }
+        ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
+    }
+    __syncthreads();
+    if (!active) return;
+    const u64* w = sh_keys + threadIdx.x;
     if (T.own_world > 1 && window_owner(w, k, T.own_world) != T.own_rank) return;
     const bool rev = window_reversed(w, k);
     const u64 h = key_hash_window(w, k, rev);
     bool claimed;
-    const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u32 j) { return rev ? w[k - 1 - j] : w[j]; }, claimed);
+    const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
     if (claimed) return;                       // the claimer is accounted for through `rep` (slot_view)
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
-    (void)n_windows;
 }
 
 // routed records (k canonical u64, ordinal, key hash) sitting in the arena at record index r0..
@@ -160,7 +214,7 @@ __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0
     const u64* key = T.ks.arena + r * (k + 2);
     const u64 h = key[k + 1];                  // computed by the sender (route_count_kernel)
     bool claimed;
-    const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u32 j) { return key[j]; }, claimed);
+    const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u64 word) { return same_key_scalar(T.ks, word, [&](u32 j) { return key[j]; }); }, claimed);
     if (claimed) return;
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, key[k]);
@@ -183,10 +237,7 @@ __global__ void rehash_kernel(const Slot* __restrict__ old, u64 old_cap, const u
     if (i >= old_cap) return;
     const Slot e = old[i];
     if (e.word == EMPTY) return;
-    const u32 k = T.ks.k;
-    u64 h = 0x243F6A8885A308D3ull;
-    for (u32 j = 0; j < k; ++j) { h = (h ^ rep_elem(T.ks, e.word, j)) * HMUL; h ^= h >> 29; }
-    h = fmix64(h);
+    const u64 h = key_hash_fn([&](u32 j) { return rep_elem(T.ks, e.word, j); }, T.ks.k);
     u64 s = home_slot(h, T.cap);
     for (;;) {
         const u64 oldw = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)e.word);
@@ -431,8 +482,9 @@ void launch_clear_table(Slot* tab, u64 cap, u64* mx, u64 n_mx, hipStream_t s) {
 void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 slot0,
                            u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s) {
     if (i1 <= i0) return;
-    hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, i0, i1, slot0,
-                       first_ordinal, n_windows, cap_err);
+    (void)n_windows;
+    hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), (256 + T.ks.k) * sizeof(u64), s, T, mh, mread, roff,
+                       i0, i1, slot0, first_ordinal, cap_err);
 }
 void launch_insert_records(const TableArgs& T, u64 r0, u64 r1, u64* n_windows, hipStream_t s) {
     if (r1 <= r0) return;
