@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
                                                              const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
                                                              u32* __restrict__ cap_err) {
     extern __shared__ u64 sh_keys[];
+    if (cap_err[1]) return;                    // reserve_check_kernel: the table must grow first (uniform over the launch)
     const u32 k = T.ks.k;
     const u64 b0 = i0 + (u64)blockIdx.x * 256;
     const u64 lim = b0 + 256 + k - 1 < i1 ? b0 + 256 + k - 1 : i1;     // windows never extend past their batch
@@ -204,6 +205,13 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     if (claimed) return;                       // the claimer is accounted for through `rep` (slot_view)
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
+}
+
+// Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch
+// the insert speculatively and needs one round trip per batch instead of two.  Same rule as slots_for() in api.inc.
+__global__ void reserve_check_kernel(const u64* __restrict__ n_distinct, const u64* __restrict__ batch_windows, u64 cap, u32* __restrict__ too_small) {
+    const u64 n = *n_distinct + *batch_windows;
+    *too_small = n + n / 2 + 1024 > cap ? 1u : 0u;
 }
 
 // routed records (k canonical u64, ordinal, key hash) sitting in the arena at record index r0..
@@ -485,6 +493,9 @@ void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, 
     (void)n_windows;
     hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), (256 + T.ks.k) * sizeof(u64), s, T, mh, mread, roff,
                        i0, i1, slot0, first_ordinal, cap_err);
+}
+void launch_reserve_check(const u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s) {
+    hipLaunchKernelGGL(reserve_check_kernel, dim3(1), dim3(1), 0, s, n_distinct, batch_windows, cap, too_small);
 }
 void launch_insert_records(const TableArgs& T, u64 r0, u64 r1, u64* n_windows, hipStream_t s) {
     if (r1 <= r0) return;
