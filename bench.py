@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
                     help="multi-GPU mode: all-gather of sketches + partitioned table (intra-node default), or all-to-all of k-min-mer records")
-    ap.add_argument("--chunks", type=int, default=1, help="routed path: chunks per step pipelined over two contexts (1 = no overlap)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="multi-GPU: chunks per step; the exchange of chunk c overlaps the sketch of chunk c+1 (0 = 4 in replicate mode, 1 in route mode)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
     return ap.parse_args()
 
@@ -93,6 +94,11 @@ def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: native libraries (RCCL prints a version banner) write to file descriptor 1
+    # directly, so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,14 +126,15 @@ def main():
         from rust_mdbg_amd import dist as D
         dev = torch.device("cuda", local_rank)
         replicate = args.dist_mode == "replicate"
-        chunked = args.chunks > 1 and not args.profile_dist and not replicate
-        mt = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank) if chunked else None     # owner-side context
+        n_chunks = args.chunks if args.chunks > 0 else (4 if replicate else 1)
+        chunked = n_chunks > 1 and not args.profile_dist
+        mt = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank) if chunked and not replicate else None     # owner-side context
         engine = D.GpuEngine(m, torch, dev, table=mt)
         comm = D.TorchDistComm(dist, torch, dev)
         runner = D.ReplicatedMdbg(engine, comm, torch) if replicate else D.DistributedMdbg(engine, comm, torch, profile=args.profile_dist)
         if chunked:
             import numpy as np
-            plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), args.chunks)
+            plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), n_chunks)
             offs_t = engine._view(d_off, (reads_per_gpu + 1,))
 
     def step():
@@ -207,13 +214,13 @@ def main():
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "synthetic D. melanogaster 140 Mb @50x per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1% errors",
                           "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
-                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, "all-gather of sketches" if args.dist_mode == "replicate" else "all-to-all of k-min-mer records")) if routed else "single GPU"},
+                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records")) if routed else "single GPU"},
                "roofline": roof, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_tile_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent}}
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     if routed and engine.tm is not m:
         engine.tm.close()

@@ -198,6 +198,28 @@ int mdbg_sketch_view(mdbg_ctx* ctx, mdbg_sketch_store* out);  /* the resident st
  * are hashes/positions[read_offsets[r] .. read_offsets[r+1]).  Counterpart of mdbg_sketch_device without the kernel. */
 int mdbg_ingest_sketch(mdbg_ctx* ctx, const uint64_t* d_hashes, const uint32_t* d_positions, const uint64_t* d_read_offsets,
                        uint64_t n_reads, uint64_t first_read_ordinal);
+/* Zero-copy variant for receives that can write straight into the resident store (RCCL recv, peer copies):
+ *   mdbg_store_reserve   sizes the store up front (total minimizers / reads it will hold), so that it never has to move;
+ *   mdbg_sketch_reserve  appends an UNCOMMITTED region of n_minimizers entries and returns where to write its hashes and
+ *                        positions (DEVICE pointers; they stay valid because the store refuses to grow, MDBG_E_STATE, while
+ *                        regions are pending); *region identifies it;
+ *   mdbg_sketch_commit   registers [region, region + n_minimizers) - or any part of a reserved region - as the sketch of
+ *                        n_reads reads; d_read_offsets are relative to `region` ([0] = 0, [n_reads] = n_minimizers, checked
+ *                        on the device: a violation is reported as MDBG_E_PARAM by the next mdbg_insert_resident).  The
+ *                        call is stream-ordered: the offsets buffer must stay alive until the next synchronising call.
+ *   mdbg_last_batch      describes the batch registered last (e.g. the one mdbg_sketch_device just produced), with DEVICE
+ *                        pointers to its part of the store: what a rank sends to its peers. */
+int mdbg_store_reserve(mdbg_ctx* ctx, uint64_t n_minimizers_total, uint64_t n_reads_total);
+int mdbg_sketch_reserve(mdbg_ctx* ctx, uint64_t n_minimizers, uint64_t** d_hashes, uint32_t** d_positions, uint64_t* region);
+int mdbg_sketch_commit(mdbg_ctx* ctx, uint64_t region, uint64_t n_minimizers, const uint64_t* d_read_offsets, uint64_t n_reads,
+                       uint64_t first_read_ordinal);
+typedef struct mdbg_batch_info {
+    uint64_t store_offset, n_minimizers, first_slot, n_reads, first_read_ordinal;
+    const uint64_t* d_hashes;        /* [n_minimizers] */
+    const uint32_t* d_positions;     /* [n_minimizers] */
+    const uint64_t* d_read_offsets;  /* [n_reads + 1], absolute: subtract store_offset for offsets relative to the batch */
+} mdbg_batch_info;
+int mdbg_last_batch(mdbg_ctx* ctx, mdbg_batch_info* out);
 int mdbg_finalize_begin(mdbg_ctx* ctx, uint64_t** d_bm_first, uint64_t** d_bm_solid, uint64_t* n_words);
 /* out: DEVICE pointers, this rank's nodes in table order; d_row[i] = global row (position in index order);
  * out->n_distinct and *n_nodes_global are the totals over all ranks (from the merged bitmaps). */

@@ -54,6 +54,11 @@ class SketchStore(C.Structure):
                 ("d_read_offsets", C.c_void_p)]
 
 
+class BatchInfo(C.Structure):
+    _fields_ = [("store_offset", C.c_uint64), ("n_minimizers", C.c_uint64), ("first_slot", C.c_uint64), ("n_reads", C.c_uint64),
+                ("first_read_ordinal", C.c_uint64), ("d_hashes", C.c_void_p), ("d_positions", C.c_void_p), ("d_read_offsets", C.c_void_p)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_reads", C.c_uint64), ("mean_len", C.c_uint32),
                 ("sd_len", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("err_ppm", C.c_uint32),
@@ -64,7 +69,8 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
-           "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end"]
+           "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
+           "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch"]
 
 
 def lib_path():
@@ -116,6 +122,10 @@ def load_library():
     L.mdbg_set_partition.argtypes = [vp, u32, u32]
     L.mdbg_sketch_view.argtypes = [vp, C.POINTER(SketchStore)]
     L.mdbg_ingest_sketch.argtypes = [vp, vp, vp, vp, u64, u64]
+    L.mdbg_store_reserve.argtypes = [vp, u64, u64]
+    L.mdbg_sketch_reserve.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.mdbg_sketch_commit.argtypes = [vp, u64, u64, vp, u64, u64]
+    L.mdbg_last_batch.argtypes = [vp, C.POINTER(BatchInfo)]
     L.mdbg_finalize_begin.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_finalize_end.argtypes = [vp, C.POINTER(Nodes), C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_insert_records.argtypes = [vp, vp, u64]
@@ -264,6 +274,23 @@ class Mdbg:
 
     def ingest_sketch(self, d_hashes, d_positions, d_read_offsets, n_reads, first_read_ordinal):
         self._chk(self.L.mdbg_ingest_sketch(self.h, d_hashes, d_positions, d_read_offsets, n_reads, first_read_ordinal))
+
+    def store_reserve(self, n_minimizers_total, n_reads_total):
+        self._chk(self.L.mdbg_store_reserve(self.h, n_minimizers_total, n_reads_total))
+
+    def sketch_reserve(self, n_minimizers):
+        """-> (d_hashes, d_positions, region): an uncommitted region at the end of the resident store to receive into"""
+        h, p, r = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._chk(self.L.mdbg_sketch_reserve(self.h, n_minimizers, C.byref(h), C.byref(p), C.byref(r)))
+        return h.value or 0, p.value or 0, r.value
+
+    def sketch_commit(self, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal):
+        self._chk(self.L.mdbg_sketch_commit(self.h, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal))
+
+    def last_batch(self):
+        b = BatchInfo()
+        self._chk(self.L.mdbg_last_batch(self.h, C.byref(b)))
+        return b
 
     def finalize_begin(self):
         """-> (d_bm_first, d_bm_solid, n_words): this rank's bitmaps over the global sketch, to be summed over ranks"""

@@ -468,6 +468,15 @@ __global__ void rebase_offsets_kernel(const u64* __restrict__ rel, u32 n_reads, 
     if (r <= n_reads) roff_out[r] = m0 + rel[r];
 }
 
+// same for an imported region, with the caller's offsets checked on the device: [0] = 0, non-decreasing, [n_reads] = n_min
+__global__ void rebase_offsets_checked_kernel(const u64* __restrict__ rel, u32 n_reads, u64 m0, u64 n_min, u64* __restrict__ roff_out, u64* __restrict__ bad) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    const u64 v = rel[r];
+    if (v > n_min || (r == 0 && v != 0) || (r == n_reads && v != n_min) || (r < n_reads && rel[r + 1] < v)) *bad = 1;
+    roff_out[r] = m0 + (v > n_min ? n_min : v);
+}
+
 // out[j] = sum of shard array j (CTR_SHARDS u64 each); one block per array
 __global__ __launch_bounds__(256) void sum_shards_kernel(const u64* __restrict__ shards, u64* __restrict__ out) {
     __shared__ u64 ws[4];
@@ -519,6 +528,9 @@ void launch_fill_mread(const u64* roff, u32 slot0, u32 n_reads, u32* mread, hipS
 }
 void launch_rebase_offsets(const u64* rel, u32 n_reads, u64 m0, u64* roff_out, hipStream_t s) {
     hipLaunchKernelGGL(rebase_offsets_kernel, dim3((n_reads + 256) / 256), dim3(256), 0, s, rel, n_reads, m0, roff_out);
+}
+void launch_rebase_offsets_checked(const u64* rel, u32 n_reads, u64 m0, u64 n_min, u64* roff_out, u64* bad, hipStream_t s) {
+    hipLaunchKernelGGL(rebase_offsets_checked_kernel, dim3((n_reads + 256) / 256), dim3(256), 0, s, rel, n_reads, m0, n_min, roff_out, bad);
 }
 void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* out, hipStream_t s) {
     if (!n_reads) return;

@@ -97,6 +97,38 @@ class TorchDistComm:
         self.dist.all_reduce(x)
         return x
 
+    def allgather_i64(self, vals):
+        """small fixed-size all-gather of integers -> [world][len(vals)]"""
+        t = self.torch
+        x = t.tensor([int(v) for v in vals], dtype=t.int64, device=self.device)
+        out = t.empty(self.world * x.shape[0], dtype=t.int64, device=self.device)
+        self.dist.all_gather_into_tensor(out, x)
+        return out.view(self.world, -1).tolist()
+
+    def exchange(self, sends, recvs):
+        """Point-to-point exchange in one group (RCCL send/recv pairs use the direct xGMI link of every pair of GPUs):
+        sends / recvs = [(peer, [tensors])], the tensors of a (source, destination) pair are matched in order; empty
+        tensors are skipped on both sides.  Returns a handle; wait() blocks the host until every receive has landed."""
+        dist, ops = self.dist, []
+        for peer, ts in recvs:
+            ops += [dist.P2POp(dist.irecv, x, peer) for x in ts if x.numel()]
+        for peer, ts in sends:
+            ops += [dist.P2POp(dist.isend, x, peer) for x in ts if x.numel()]
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        return _Pending(reqs, self.torch if self.device is not None and getattr(self.device, "type", "cpu") == "cuda" else None, (sends, recvs))
+
+
+class _Pending:
+    def __init__(self, reqs, torch_cuda, keep):
+        self.reqs, self.t, self.keep = reqs, torch_cuda, keep      # keep: the tensors stay referenced until wait()
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        if self.t is not None and self.reqs:
+            self.t.cuda.current_stream().synchronize()           # Work.wait() only orders the current stream; the engine has its own
+        self.reqs, self.keep = [], None
+
 
 class ThreadWorld:
     """shared state of `world` in-process ranks (one thread each)"""
@@ -143,12 +175,33 @@ class ThreadComm:
         return x
 
 
+    def allgather_i64(self, vals):
+        return [list(v) for v in self._exchange([int(v) for v in vals])]
+
+    def exchange(self, sends, recvs):
+        allv = self._exchange_keep(dict((peer, ts) for peer, ts in sends))
+        for peer, ts in recvs:
+            for dst, src in zip(ts, allv[peer][self.rank]):
+                if dst.numel():
+                    dst.copy_(src)
+                    if dst.is_cuda:
+                        self.torch.cuda.current_stream().synchronize()
+        self.tw.barrier.wait()
+        return _Pending([], None, None)
+
+    def _exchange_keep(self, obj):
+        """like _exchange but the senders' objects stay valid until the caller's closing barrier"""
+        self.tw.box[self.rank] = obj
+        self.tw.barrier.wait()
+        return list(self.tw.box)
+
+
 # ------------------------------------------------------------------------------------------- GPU engine
 class _DevArray:
     """zero-copy view of library-owned device memory for torch.as_tensor (CUDA array interface v2)"""
 
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+    def __init__(self, ptr, shape, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 class GpuEngine:
@@ -165,13 +218,13 @@ class GpuEngine:
     def k(self):
         return self.m.k
 
-    def _view(self, ptr, shape):
+    def _view(self, ptr, shape, i32=False):
         n = 1
         for s in shape:
             n *= s
         if n == 0 or not ptr:
-            return self.t.empty(shape, dtype=self.t.int64, device=self.device)
-        return self.t.as_tensor(_DevArray(ptr, shape), device=self.device)
+            return self.t.empty(shape, dtype=self.t.int32 if i32 else self.t.int64, device=self.device)
+        return self.t.as_tensor(_DevArray(ptr, shape, "<i4" if i32 else "<i8"), device=self.device)
 
     def reset(self):
         self.m.reset(0)
@@ -210,8 +263,35 @@ class GpuEngine:
         self.m.ingest_sketch(hashes.data_ptr() if hashes.numel() else 0, pos.data_ptr() if pos.numel() else 0, read_off.data_ptr(),
                              read_off.shape[0] - 1, first_ordinal)
 
+    def store_reserve(self, n_minimizers, n_reads):
+        self.m.store_reserve(n_minimizers, n_reads)
+
+    def last_sketch(self):
+        """the batch sketched last -> (hashes view, positions view (int32), offsets relative to the batch, first ordinal, n_reads)"""
+        b = self.m.last_batch()
+        m, n = int(b.n_minimizers), int(b.n_reads)
+        off = self._view(b.d_read_offsets, (n + 1,)) - int(b.store_offset)
+        return self._view(b.d_hashes, (m,)), self._view(b.d_positions, (m,), i32=True), off, int(b.first_read_ordinal), n
+
+    def reserve_import(self, sizes):
+        """room for peers' sketches of sizes[i] minimizers at the end of the resident store (no copy after the receive)
+        -> [(hashes view, positions view, token)]"""
+        dh, dp, region = self.m.sketch_reserve(sum(sizes))
+        out, o = [], 0
+        for m in sizes:
+            out.append((self._view(dh + 8 * o, (m,)), self._view(dp + 4 * o, (m,), i32=True), (region + o, m)))
+            o += m
+        return out
+
+    def commit_import(self, token, rel_off, first_ordinal):
+        rel_off = rel_off.contiguous()
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append(rel_off)             # the call is stream-ordered: keep the offsets alive until insert_owned()
+        self.m.sketch_commit(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal)
+
     def insert_owned(self):
         self.m.insert_resident()
+        self._keep = []
 
     def finalize_begin(self):
         a, b, n = self.m.finalize_begin()
@@ -423,39 +503,82 @@ class ReplicatedMdbg:
 
     def __init__(self, engine, comm, torch):
         self.e, self.c, self.t = engine, comm, torch
-        self.imported_local = 0        # reads (own + imported) already in this rank's store
+        self.sized = False             # sketch store sized for the whole exchange (zero-copy receives must not move it)
         engine.set_partition(comm.world, comm.rank)
 
     def reset(self):
         self.e.reset()
-        self.imported_local = 0
 
     def ingest_device(self, d_bases, d_offsets, n_reads, n_bases, first_ordinal):
         self.e.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
-        self.share(first_ordinal, n_reads)
+        self._finish([self._share_begin(1, [])])
 
     def ingest_host(self, bases, offsets, first_ordinal):
         self.e.sketch_host(bases, offsets, first_ordinal)
-        self.share(first_ordinal, len(offsets) - 1)
+        self._finish([self._share_begin(1, [])])
 
-    def share(self, first_ordinal, n_reads):
-        """all-gather the sketch of the batch just sketched; peers' batches are appended to the resident store"""
+    def ingest_device_chunked(self, d_bases, offsets_dev, plan, first_ordinal):
+        """One batch cut into chunks of whole reads (plan_chunks): while chunk c travels to the peers (RCCL send/recv
+        pairs straight into their sketch stores) the tile kernel already works on chunk c+1; windows are inserted once
+        everything has arrived.  offsets_dev: the device offsets array as an int64 tensor."""
+        t, e = self.t, self.e
+        pend = []
+        for (r0, r1, a, nb) in plan:
+            offs_c = (offsets_dev[r0:r1 + 1] - a).contiguous()
+            if offs_c.is_cuda:
+                t.cuda.current_stream().synchronize()
+            self._with_room(pend, lambda: e.sketch_device(d_bases + a, offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0))
+            pend.append(self._share_begin(len(plan), pend))
+        self._finish(pend)
+
+    def ingest_host_chunks(self, chunks):
+        """[(bases, offsets, first_ordinal)] host batches, pipelined like ingest_device_chunked"""
+        pend = []
+        for bases, offsets, first in chunks:
+            self._with_room(pend, lambda: self.e.sketch_host(bases, offsets, first))
+            pend.append(self._share_begin(len(chunks), pend))
+        self._finish(pend)
+
+    def _with_room(self, pend, fn):
+        """run fn; if the sketch store would have to move while receives are in flight (MDBG_E_STATE), complete them first"""
+        try:
+            return fn()
+        except Exception as ex:                # noqa: BLE001
+            if getattr(ex, "code", None) != -6 or not pend:
+                raise
+        self._drain(pend)
+        return fn()
+
+    def _share_begin(self, n_chunks, pend):
+        """start sending the batch sketched last to every peer and receiving theirs -> pending item"""
         t, e, c = self.t, self.e, self.c
-        hashes, pos, roff = e.sketch_arrays()
-        r0 = self.imported_local
-        m0 = int(roff[r0].item()) if roff.shape[0] else 0
-        my_off = (roff[r0:r0 + n_reads + 1] - m0).clone()
-        my_h, my_p = hashes[m0:m0 + int(my_off[-1].item())].clone(), pos[m0:m0 + int(my_off[-1].item())].clone()
-        meta = c.allgather_obj((int(my_h.shape[0]), int(n_reads), int(first_ordinal)))
-        hs = c.allgatherv(my_h, [x[0] for x in meta])
-        ps = c.allgatherv(my_p, [x[0] for x in meta])
-        os_ = c.allgatherv(my_off, [x[1] + 1 for x in meta])
-        self.imported_local = r0 + n_reads
-        for r in range(c.world):
-            if r != c.rank and meta[r][1]:
-                e.ingest_sketch(hs[r], ps[r], os_[r], meta[r][2])
-                self.imported_local += meta[r][1]
-        e.insert_owned()
+        h, p, off, first, n = e.last_sketch()
+        meta = c.allgather_i64([h.shape[0], n, first])
+        peers = [r for r in range(c.world) if r != c.rank]
+        if not peers:
+            return None
+        if not self.sized and hasattr(e, "store_reserve"):
+            # size the store once, before anything is in flight: all chunks of all ranks, from the first chunk's counts
+            self._drain(pend)
+            e.store_reserve(int(sum(x[0] for x in meta) * n_chunks * 1.2) + (1 << 20), int(sum(x[1] for x in meta) * n_chunks * 1.2) + 4096 * n_chunks * c.world)
+            self.sized = True
+            h, p, off, first, n = e.last_sketch()          # the store may have moved
+        bufs = self._with_room(pend, lambda: e.reserve_import([int(meta[r][0]) for r in peers]))
+        offs = [t.empty(int(meta[r][1]) + 1, dtype=t.int64, device=off.device) for r in peers]
+        handle = c.exchange([(r, [h, p, off]) for r in peers], [(r, [bufs[i][0], bufs[i][1], offs[i]]) for i, r in enumerate(peers)])
+        return handle, [(bufs[i][2], offs[i], int(meta[r][2])) for i, r in enumerate(peers)]
+
+    def _drain(self, pend):
+        for item in pend:
+            if item is not None and item[0] is not None:
+                item[0].wait()
+                for token, off, first in item[1]:
+                    self.e.commit_import(token, off, first)
+        pend[:] = []
+
+    def _finish(self, pend):
+        self._drain(pend)
+        self.e.insert_owned()
 
     def finalize(self):
         bf, bs = self.e.finalize_begin()

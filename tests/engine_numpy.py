@@ -113,6 +113,22 @@ class NumpyEngine:
         self.batches.append(b)
         self.pending.append(b)
 
+    def last_sketch(self):
+        b = self.batches[-1]
+        sk = b["sk"]
+        return (torch.from_numpy(_i64(sk["hashes"]).copy()), torch.from_numpy(np.asarray(sk["pos"]).astype(np.int32)),
+                torch.from_numpy(_i64(sk["off"]).copy()), b["first"], b["n"])
+
+    def reserve_import(self, sizes):
+        out = []
+        for m in sizes:
+            h, p = torch.empty(m, dtype=torch.int64), torch.empty(m, dtype=torch.int32)
+            out.append((h, p, (h, p)))           # the token of this engine is simply the pair of receive buffers
+        return out
+
+    def commit_import(self, token, rel_off, first_ordinal):
+        self.ingest_sketch(token[0], token[1], rel_off, first_ordinal)
+
     @staticmethod
     def _fmix(x):
         M = (1 << 64) - 1

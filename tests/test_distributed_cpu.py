@@ -45,13 +45,16 @@ def run_rank(rank, world, comm, reads, out, batches_per_rank=2, mode="route"):
     per = len(reads) // world
     lo, hi = rank * per, (len(reads) if rank == world - 1 else (rank + 1) * per)
     step = (hi - lo + batches_per_rank - 1) // batches_per_rank
-    for s in range(lo, hi, step):
-        bb, oo = O.concat_reads(reads[s:min(hi, s + step)])
-        drv.ingest_host(bb, oo, s)
+    chunks = [O.concat_reads(reads[s:min(hi, s + step)]) + (s,) for s in range(lo, hi, step)]
+    if mode == "replicate-pipelined":          # all chunks in flight, windows inserted once everything has arrived
+        drv.ingest_host_chunks(chunks)
+    else:
+        for bb, oo, s in chunks:
+            drv.ingest_host(bb, oo, s)
     out[rank] = drv.finalize()
 
 
-@pytest.mark.parametrize("mode", ["route", "replicate"])
+@pytest.mark.parametrize("mode", ["route", "replicate", "replicate-pipelined"])
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_thread_ranks_numpy_engine(world, mode):
     reads = workload()
@@ -87,7 +90,7 @@ def _gloo_worker(rank, world, port, tmpdir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["route", "replicate"])
+@pytest.mark.parametrize("mode", ["route", "replicate", "replicate-pipelined"])
 def test_gloo_world2(tmp_path, mode):
     import torch.multiprocessing as mp
     s = socket.socket()

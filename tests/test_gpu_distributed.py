@@ -29,9 +29,15 @@ def run(world, reads, k, l, d, a, batches_per_rank=2, mode="route"):
                 per = len(reads) // world
                 lo, hi = rank * per, (len(reads) if rank == world - 1 else (rank + 1) * per)
                 step = (hi - lo + batches_per_rank - 1) // batches_per_rank
-                for s in range(lo, hi, step):
-                    bb, oo = O.concat_reads(reads[s:min(hi, s + step)])
-                    drv.ingest_host(bb, oo, s)
+                chunks = [O.concat_reads(reads[s:min(hi, s + step)]) + (s,) for s in range(lo, hi, step)]
+                if mode.startswith("replicate-pipelined"):
+                    # all chunks in flight into reserved regions of the peers' sketch stores (mdbg_sketch_reserve / _commit);
+                    # "-nosize": the store is NOT sized up front, so it has to grow mid-flight -> drain-and-retry path
+                    drv.sized = mode.endswith("nosize")
+                    drv.ingest_host_chunks(chunks)
+                else:
+                    for bb, oo, s in chunks:
+                        drv.ingest_host(bb, oo, s)
                 part = drv.finalize()
                 out[rank] = {f: (v.cpu() if hasattr(v, "cpu") else v) for f, v in part.items()}
         except BaseException as e:           # noqa: BLE001
@@ -45,12 +51,12 @@ def run(world, reads, k, l, d, a, batches_per_rank=2, mode="route"):
     return out
 
 
-@pytest.mark.parametrize("mode", ["route", "replicate"])
+@pytest.mark.parametrize("mode", ["route", "replicate", "replicate-pipelined", "replicate-pipelined-nosize"])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_routed_path_matches_oracle(world, mode):
     from rust_mdbg_amd import synth
     reads = synth.synth_reads(3, 120000, 160, mean_len=9000, sd_len=2000, min_len=2000, max_len=15000, err_ppm=1500)
-    parts = run(world, reads, 6, 12, 0.004, 2, mode=mode)
+    parts = run(world, reads, 6, 12, 0.004, 2, batches_per_rank=3 if "pipelined" in mode else 2, mode=mode)
     check_against_oracle(parts, reads, 6, 12, 0.004, 2)
 
 
@@ -88,6 +94,16 @@ def test_rccl_communicator_world1_chunked():
             part = drv.finalize()
             part = {f: (v.cpu() if hasattr(v, "cpu") else v) for f, v in part.items()}
         check_against_oracle([part], reads, k, l, d, a)
+        # replicated-sketch mode over the same communicator, batch cut into chunks on the device (one rank: no peers, but
+        # the counts all-gather, the chunk offsets and the store sizing run as they do on 8 GPUs)
+        with R.Mdbg(k, l, d, a, device=0) as m:
+            rep = D.ReplicatedMdbg(D.GpuEngine(m, torch, dev), comm, torch)
+            tb, to = torch.from_numpy(b).to(dev), torch.from_numpy(o.view(np.int64)).to(dev)
+            rep.ingest_device_chunked(tb.data_ptr(), to, D.plan_chunks(o, 4), 0)
+            part = rep.finalize()
+            part = {f: (v.cpu() if hasattr(v, "cpu") else v) for f, v in part.items()}
+        check_against_oracle([part], reads, k, l, d, a)
+        assert comm.allgather_i64([7, 8]) == [[7, 8]]
         # raw communicator check: chunked alltoallv is the identity for one rank
         x = torch.arange(100003 * 3, device=dev, dtype=torch.int64).reshape(100003, 3)
         y, rc = comm.alltoallv(x, [100003])
