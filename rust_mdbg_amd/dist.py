@@ -297,10 +297,12 @@ class GpuEngine:
         a, b, n = self.m.finalize_begin()
         return self._view(a, (n,)), self._view(b, (n,))
 
-    def finalize_end(self):
+    def finalize_end(self, counts_only=False):
         t = self.t
         nd, row, ng = self.m.finalize_end()
         n, k = int(nd.n), self.k
+        if counts_only:                    # the node rows stay in the library's device buffers (mdbg_nodes of mdbg_finalize_end)
+            return dict(n_nodes=int(ng), n_nodes_before=int(nd.n_distinct), n_local=n)
         addr = lambda p: C.cast(p, C.c_void_p).value or 0
         v16 = lambda p, cnt: self._view_as(addr(p), cnt, t.int16, 2) & 0xFFFF
         return dict(keys=self._view(addr(nd.keys), (n, k)), index=self._view_as(addr(nd.index), n, t.int32, 4) & 0xFFFFFFFF, row=self._view(row, (n,)),
@@ -580,14 +582,17 @@ class ReplicatedMdbg:
         self._drain(pend)
         self.e.insert_owned()
 
-    def finalize(self):
+    def finalize(self, counts_only=False):
         bf, bs = self.e.finalize_begin()
         self.c.allreduce_sum_(bf)      # every bit is set by exactly one rank (distinct keys have distinct first sightings)
         self.c.allreduce_sum_(bs)
-        return self.e.finalize_end()
+        if bf.is_cuda:
+            self.t.cuda.current_stream().synchronize()     # the engine works on its own stream
+        return self.e.finalize_end(True) if counts_only else self.e.finalize_end()
 
     def finalize_device_count(self):
-        part = self.finalize()
+        """finalize with the node rows left on the device (what the benchmark times) -> global node count"""
+        part = self.finalize(counts_only=True)
         self.last_local = part["n_local"]
         return part["n_nodes"]
 
