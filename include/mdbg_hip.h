@@ -208,7 +208,8 @@ int mdbg_ingest_sketch(mdbg_ctx* ctx, const uint64_t* d_hashes, const uint32_t* 
  *                        on the device: a violation is reported as MDBG_E_PARAM by the next mdbg_insert_resident).  The
  *                        call is stream-ordered: the offsets buffer must stay alive until the next synchronising call.
  *   mdbg_last_batch      describes the batch registered last (e.g. the one mdbg_sketch_device just produced), with DEVICE
- *                        pointers to its part of the store: what a rank sends to its peers. */
+ *                        pointers to its part of the store: what a rank sends to its peers.  Synchronises the context's
+ *                        stream, so the arrays may be read from any other stream afterwards. */
 int mdbg_store_reserve(mdbg_ctx* ctx, uint64_t n_minimizers_total, uint64_t n_reads_total);
 int mdbg_sketch_reserve(mdbg_ctx* ctx, uint64_t n_minimizers, uint64_t** d_hashes, uint32_t** d_positions, uint64_t* region);
 int mdbg_sketch_commit(mdbg_ctx* ctx, uint64_t region, uint64_t n_minimizers, const uint64_t* d_read_offsets, uint64_t n_reads,
