@@ -100,7 +100,14 @@ typedef struct mdbg_stats {
 mdbg_ctx* mdbg_create(const mdbg_params* p, int* err);
 void mdbg_destroy(mdbg_ctx* ctx);
 
-/* Ingest a batch of reads given as concatenated ASCII (HOST memory) + n_reads+1 offsets.  The bytes are
+/* Threading: every entry point may be called from any host thread; calls on one context are serialised internally.
+ * mdbg_ingest_batch (and mdbg_sketch_only) may be called CONCURRENTLY from several threads, as the reference calls
+ * process_read_aux from its --threads workers (src/main.rs:834-913): each caller's PCIe copy runs in its own staging
+ * slot and overlaps the kernels of the others.  Batches are ordered by first_read_ordinal, not by call time, so the node
+ * table does not depend on the interleaving.  Result buffers (mdbg_sketch_only, mdbg_finalize) belong to the context:
+ * callers that need them concurrently use one context each.  mdbg_destroy must not race with other calls.
+ *
+ * Ingest a batch of reads given as concatenated ASCII (HOST memory) + n_reads+1 offsets.  The bytes are
  * copied to the device and processed there; the sketch of every read stays resident for mdbg_reset. */
 int mdbg_ingest_batch(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
                       uint64_t first_read_ordinal);

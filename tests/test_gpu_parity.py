@@ -298,6 +298,36 @@ def test_multik_reset_reuses_resident_sketches():
         assert_nodes_equal(m.finalize(), oracle_graph(reads[:50], 10, l, d, A))
 
 
+def test_concurrent_ingest_from_host_threads():
+    """mdbg_ingest_batch from several host threads at once (the reference calls process_read_aux from --threads workers,
+    src/main.rs:834-913): the node table must not depend on the interleaving, only on the read ordinals."""
+    import threading
+    reads = rand_reads(41, 300, 2000, 12000)
+    reads += [r[50:] for r in reads[:200]]
+    k, l, d, A = 6, 12, 0.005, 2
+    exp = oracle_graph(reads, k, l, d, A)
+    R = _mdbg()
+    step = 25
+    jobs = [(lo, min(len(reads), lo + step)) for lo in range(0, len(reads), step)]
+    for trial in range(3):
+        random.Random(trial).shuffle(jobs)
+        errs = []
+        with R.Mdbg(k, l, d, A) as m:
+            def work(js):
+                try:
+                    for lo, hi in js:
+                        m.ingest_reads(reads[lo:hi], lo)
+                except BaseException as e:       # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=work, args=(jobs[i::4],)) for i in range(4)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not errs, errs
+            got = m.finalize()
+            assert m.stats()["n_reads"] == len(reads)
+        assert_nodes_equal(got, exp)
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
