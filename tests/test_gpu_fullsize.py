@@ -103,3 +103,56 @@ def test_config3_size_routed_equals_local():
     for f in ("index", "abundance", "seqlen", "reversed", "src_read", "src_start", "src_end"):
         assert np.array_equal(tab[f].astype(np.uint64), loc[f].astype(np.uint64)), f
     assert np.array_equal(tab["shift_full"], loc["shift_full"])
+
+
+def test_batch_larger_than_one_launch_equals_split_batches():
+    """one batch of > 2^33 bases (more tiles than one sketch launch takes: the tile kernel runs twice inside one call, 32-bit
+    tile indices restart) must equal the same reads ingested as two batches"""
+    import rust_mdbg_amd as R
+    k, l, d, a = 35, 12, 0.002, 2
+    n_reads = 600000
+    with R.Mdbg(k, l, d, a) as m:
+        db, do, nb = m.synth_reads_device(seed=5, genome_len=180_000_000, n_reads=n_reads)
+        assert nb > (1 << 33)
+        m.ingest_device(db, do, n_reads, nb, 0)
+        one = m.finalize()
+        st = m.stats()
+        assert st["n_tiles"] == (nb + 65535) // 65536 > 131072 and st["n_sketch_tile_launches"] == 2
+        offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
+        half = n_reads // 2
+        cut = int(offs[half]) // 16 * 16                      # the device bases pointer must stay 16-byte aligned
+        m.reset(0)
+        import torch
+        o2 = torch.from_numpy((offs[half:] - cut).astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        m.ingest_device(db, do, half, int(offs[half]), 0)
+        m.ingest_device(db + cut, o2.data_ptr(), n_reads - half, nb - cut, half)
+        two = m.finalize()
+    assert one["n_nodes"] == two["n_nodes"] > 400000 and one["n_nodes_before"] == two["n_nodes_before"]
+    for f in FIELDS:
+        assert np.array_equal(one[f], two[f]), f
+
+
+def test_config3_size_replicated_chunked_equals_local():
+    """replicated-sketch driver with the batch cut into 4 chunks (zero-copy import path, one rank) at 7 Gbases == local"""
+    import torch
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import dist as D
+    k, l, d, a = 35, 12, 0.002, 2
+    n_reads = 466666
+    dev = torch.device("cuda", 0)
+    with R.Mdbg(k, l, d, a) as m:
+        db, do, nb = m.synth_reads_device(seed=1, genome_len=140_000_000, n_reads=n_reads)
+        m.ingest_device(db, do, n_reads, nb, 0)
+        loc = m.finalize()
+        eng = D.GpuEngine(m, torch, dev)
+        eng.reset()                                           # the partition is set on an empty context
+        drv = D.ReplicatedMdbg(eng, D.ThreadComm(D.ThreadWorld(1), 0, torch), torch)
+        offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
+        drv.ingest_device_chunked(db, eng._view(do, (n_reads + 1,)), D.plan_chunks(offs, 4), 0)
+        part = drv.finalize()
+        tab = D.gather_node_table([{f: (v.cpu().numpy().view(np.uint64) if hasattr(v, "cpu") else v) for f, v in part.items()}])
+    assert tab["n_nodes"] == loc["n_nodes"] and tab["n_nodes_before"] == loc["n_nodes_before"]
+    assert np.array_equal(tab["keys"], loc["keys"])
+    for f in ("index", "abundance", "seqlen", "reversed", "src_read", "src_start", "src_end"):
+        assert np.array_equal(tab[f].astype(np.uint64), loc[f].astype(np.uint64)), f
