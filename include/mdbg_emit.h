@@ -20,15 +20,10 @@ extern "C" {
 
 typedef struct mdbg_emit mdbg_emit; /* owns the edge buffers it hands out */
 
-typedef struct mdbg_edges {
-    uint64_t n;              /* number of L-lines ("Number of mdBG edges", main.rs:1118) */
-    const uint32_t* n1;      /* DbgEntry.index of the source node */
-    const uint8_t* o1;       /* '+' or '-' */
-    const uint32_t* n2;
-    const uint8_t* o2;
-    const uint32_t* overlap; /* min(n1.seqlen - shift, n2.seqlen - 1), main.rs:1091-1092 */
-    uint64_t presimp_removed; /* "Pre-simp = ..: N edges removed" (main.rs:1120) */
-} mdbg_edges;
+/* n = number of L-lines ("Number of mdBG edges", main.rs:1118); n1/n2 = DbgEntry.index; o1/o2 = '+' or '-';
+ * overlap = min(n1.seqlen - shift, n2.seqlen - 1) (main.rs:1091-1092); presimp_removed: main.rs:1120.
+ * Same type as the GPU edge list of include/mdbg_hip.h (mdbg_graph_edges). */
+typedef mdbg_edge_list mdbg_edges;
 
 mdbg_emit* mdbg_emit_create(void);
 void mdbg_emit_destroy(mdbg_emit* e);

@@ -186,6 +186,24 @@ int mdbg_resolve_first(mdbg_ctx* ctx, const uint64_t* d_ord, const uint8_t* d_so
 int mdbg_resolve_meta(mdbg_ctx* ctx, const uint64_t* d_ord, uint64_t n, uint64_t* d_meta);
 /* Owner side: canonical keys (k u64 each) of the given slot handles into the caller-owned DEVICE buffer d_keys. */
 int mdbg_routed_keys(mdbg_ctx* ctx, const uint64_t* d_slot, uint64_t n, uint64_t* d_keys);
+/* ---- graph edges (replaces the single-threaded edge loop of src/main.rs:1017-1117) ------------------------------
+ * Edges of the node table produced by the LAST mdbg_finalize / mdbg_finalize_device on this context (the table stays on
+ * the device): for every node n1 and both of its (k-1)-mers, the nodes listing the same normalized (k-1)-mer, the four
+ * orientation tests (main.rs:1062-1075), abundance presimplification (main.rs:1078-1090 and 1104-1115; presimp = 0
+ * disables it, the reference's default is 0.01) and overlap = min(n1.seqlen - shift(ori1), n2.seqlen - 1).  n1/n2 are
+ * DbgEntry.index values, o1/o2 are '+' / '-'.  The order is the one a sequential pass over the node table produces
+ * (n1 in table order, suffix key before prefix key, listings in table order, orientations ++, +-, -+, --); the
+ * reference iterates a DashMap, so only the multiset of its L lines is defined.
+ * mdbg_graph_edges: HOST arrays owned by the context; mdbg_graph_edges_device: DEVICE arrays; both valid until the next
+ * edge call.  The layout equals mdbg_edges of include/mdbg_emit.h, so the host copy can go straight to mdbg_emit_write_gfa. */
+typedef struct mdbg_edge_list {
+    uint64_t n;
+    const uint32_t* n1; const uint8_t* o1; const uint32_t* n2; const uint8_t* o2; const uint32_t* overlap;
+    uint64_t presimp_removed;     /* candidate edges dropped by the abundance rule (before the symmetric removal) */
+} mdbg_edge_list;
+int mdbg_graph_edges(mdbg_ctx* ctx, float presimp, mdbg_edge_list* out);
+int mdbg_graph_edges_device(mdbg_ctx* ctx, float presimp, mdbg_edge_list* out);
+
 /* ---- multi-GPU, second mode: replicated sketches, partitioned table ----------------------------------------
  * Within one node the sketch is much more compact than the k-min-mers cut from it (every minimizer sits in k windows),
  * so the ranks may exchange SKETCHES instead (one all-gather), each rank then windows the global sketch but inserts only

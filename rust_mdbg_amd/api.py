@@ -59,6 +59,11 @@ class BatchInfo(C.Structure):
                 ("first_read_ordinal", C.c_uint64), ("d_hashes", C.c_void_p), ("d_positions", C.c_void_p), ("d_read_offsets", C.c_void_p)]
 
 
+class EdgeList(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n1", C.POINTER(C.c_uint32)), ("o1", C.POINTER(C.c_uint8)), ("n2", C.POINTER(C.c_uint32)),
+                ("o2", C.POINTER(C.c_uint8)), ("overlap", C.POINTER(C.c_uint32)), ("presimp_removed", C.c_uint64)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_reads", C.c_uint64), ("mean_len", C.c_uint32),
                 ("sd_len", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("err_ppm", C.c_uint32),
@@ -70,7 +75,7 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
-           "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch"]
+           "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_graph_edges", "mdbg_graph_edges_device"]
 
 
 def lib_path():
@@ -126,6 +131,8 @@ def load_library():
     L.mdbg_sketch_reserve.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_sketch_commit.argtypes = [vp, u64, u64, vp, u64, u64]
     L.mdbg_last_batch.argtypes = [vp, C.POINTER(BatchInfo)]
+    L.mdbg_graph_edges.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
+    L.mdbg_graph_edges_device.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
     L.mdbg_finalize_begin.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_finalize_end.argtypes = [vp, C.POINTER(Nodes), C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_insert_records.argtypes = [vp, vp, u64]
@@ -274,6 +281,24 @@ class Mdbg:
 
     def ingest_sketch(self, d_hashes, d_positions, d_read_offsets, n_reads, first_read_ordinal):
         self._chk(self.L.mdbg_ingest_sketch(self.h, d_hashes, d_positions, d_read_offsets, n_reads, first_read_ordinal))
+
+    def graph_edges(self, presimp=0.01, raw=False):
+        """edges of the node table of the last finalize(), built on the GPU (src/main.rs:1017-1117)
+        -> dict(n1, o1, n2, o2, overlap, presimp_removed) of numpy arrays, o1/o2 as ASCII '+' / '-'; raw=True: the C struct"""
+        e = EdgeList()
+        self._chk(self.L.mdbg_graph_edges(self.h, presimp, C.byref(e)))
+        if raw:
+            return e
+        n = int(e.n)
+        g = lambda p, t: np.ctypeslib.as_array(p, shape=(n,)).astype(t, copy=True) if n else np.zeros(0, t)
+        return dict(n1=g(e.n1, np.uint32), o1=g(e.o1, np.uint8), n2=g(e.n2, np.uint32), o2=g(e.o2, np.uint8), overlap=g(e.overlap, np.uint32),
+                    presimp_removed=int(e.presimp_removed))
+
+    def graph_edges_device(self, presimp=0.01):
+        """-> EdgeList with DEVICE pointers (valid until the next edge call)"""
+        e = EdgeList()
+        self._chk(self.L.mdbg_graph_edges_device(self.h, presimp, C.byref(e)))
+        return e
 
     def store_reserve(self, n_minimizers_total, n_reads_total):
         self._chk(self.L.mdbg_store_reserve(self.h, n_minimizers_total, n_reads_total))

@@ -1,0 +1,19 @@
+// edges.h — interface between the C ABI (api.inc) and the edge-construction translation unit (edges.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct EdgeNodes {                 // device-resident node table of the last finalize (rows in index order)
+    const uint64_t* keys; const uint32_t* index; const uint16_t* abund; const uint32_t* seqlen; const uint16_t* shift;
+    uint64_t n; uint32_t k;
+};
+struct EdgeBuffers;                // scratch + results, owned by the context (opaque here)
+EdgeBuffers* edge_buffers_create();
+void edge_buffers_destroy(EdgeBuffers*);
+
+struct EdgeResult {                // device pointers into EdgeBuffers, valid until the next call
+    uint64_t n; const uint32_t* n1; const uint8_t* o1; const uint32_t* n2; const uint8_t* o2; const uint32_t* overlap;
+    uint64_t presimp_removed;
+};
+// returns hipSuccess or the failing HIP error; synchronises the stream before returning
+hipError_t build_edges(EdgeBuffers* B, const EdgeNodes& nd, float presimp, hipStream_t s, EdgeResult* out);

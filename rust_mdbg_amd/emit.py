@@ -11,9 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-class Edges(C.Structure):
-    _fields_ = [("n", C.c_uint64), ("n1", C.POINTER(C.c_uint32)), ("o1", C.POINTER(C.c_uint8)), ("n2", C.POINTER(C.c_uint32)),
-                ("o2", C.POINTER(C.c_uint8)), ("overlap", C.POINTER(C.c_uint32)), ("presimp_removed", C.c_uint64)]
+from .api import EdgeList as Edges          # one type for the host emitter's and the GPU's edge list (include/mdbg_hip.h)
 
 
 EXPORTS = ["mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
@@ -74,9 +72,11 @@ class Emitter:
         return dict(n1=g(e.n1, np.uint32), o1=g(e.o1, np.uint8), n2=g(e.n2, np.uint32), o2=g(e.o2, np.uint8), overlap=g(e.overlap, np.uint32),
                     presimp_removed=int(e.presimp_removed))
 
-    def write_gfa(self, path, nodes=None):
+    def write_gfa(self, path, nodes=None, edges=None):
+        """edges: an EdgeList with HOST arrays (Mdbg.graph_edges(raw=True)); default: the list of the last edges() call"""
         nt = self.nt if nodes is None else (nodes if isinstance(nodes, NodeTable) else NodeTable(nodes))
-        rc = self.L.mdbg_emit_write_gfa(path.encode(), C.byref(nt.c), C.byref(self._edges) if self._edges is not None else None)
+        ed = edges if edges is not None else self._edges
+        rc = self.L.mdbg_emit_write_gfa(path.encode(), C.byref(nt.c), C.byref(ed) if ed is not None else None)
         if rc:
             raise RuntimeError("mdbg_emit_write_gfa failed: %d" % rc)
 

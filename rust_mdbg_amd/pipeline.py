@@ -40,10 +40,13 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
             n_bases += len(bases)
         nodes = m.finalize()
         stats = m.stats()
+        # edges on the GPU from the device-resident node table (the reference's single-threaded loop, src/main.rs:1017-1117);
+        # the host copy of the list goes straight into the GFA writer
+        raw = m.graph_edges(presimp, raw=True)
+        edges = dict(n1=[0] * int(raw.n), presimp_removed=int(raw.presimp_removed))
+        em = Emitter()
+        em.write_gfa(prefix + ".gfa", nodes, raw)
     th.join()
-    em = Emitter()
-    edges = em.edges(nodes, presimp)
-    em.write_gfa(prefix + ".gfa")
     if write_sequences:                              # second pass over the input for the node sequences
         def again():
             first = 0

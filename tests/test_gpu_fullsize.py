@@ -21,6 +21,8 @@ def test_config2_100k_reads_bit_exact_nodes_and_edges():
         m.ingest_device(db, do, n_reads, nb, 0)
         got = m.finalize()
         st = m.stats()
+        import time
+        t0 = time.perf_counter(); ge = m.graph_edges(0.01); t_gpu = time.perf_counter() - t0
         bases = m.to_host(db, nb)
         offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
     assert 1.4e9 < nb < 1.6e9 and st["n_slow_tiles"] == 0
@@ -37,9 +39,14 @@ def test_config2_100k_reads_bit_exact_nodes_and_edges():
     assert edges == exp_edges and len(edges) == exp["n_edges"] > 100000 and removed == exp["presimp_removed"]
     # ... and the product's own host emitter (libmdbg_emit.so) gives the same L-lines
     from rust_mdbg_amd import emit as E
-    pe = E.Emitter().edges(got)
+    t0 = time.perf_counter(); pe = E.Emitter().edges(got); t_host = time.perf_counter() - t0
     assert sorted(zip(pe["n1"].tolist(), pe["o1"].tolist(), pe["n2"].tolist(), pe["o2"].tolist(), pe["overlap"].tolist())) == exp_edges
     assert pe["presimp_removed"] == exp["presimp_removed"]
+    # ... and so does the GPU edge builder, in the same order
+    for f in ("n1", "o1", "n2", "o2", "overlap"):
+        assert np.array_equal(ge[f], pe[f]), f
+    assert ge["presimp_removed"] == pe["presimp_removed"]
+    print("edges: %d nodes -> %d edges; GPU %.1f ms (incl. copy to host), host emitter %.1f ms" % (got["n_nodes"], len(pe["n1"]), t_gpu * 1e3, t_host * 1e3))
 
 
 def test_config3_size_properties():
