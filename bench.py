@@ -134,7 +134,7 @@ def main():
         runner = D.ReplicatedMdbg(engine, comm, torch) if replicate else D.DistributedMdbg(engine, comm, torch, profile=args.profile_dist)
         if chunked:
             import numpy as np
-            plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), n_chunks)
+            plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), n_chunks, keep_empty=replicate)
             offs_t = engine._view(d_off, (reads_per_gpu + 1,))
 
     def step():

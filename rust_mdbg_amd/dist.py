@@ -526,19 +526,23 @@ class ReplicatedMdbg:
         t, e = self.t, self.e
         pend = []
         for (r0, r1, a, nb) in plan:
-            offs_c = (offsets_dev[r0:r1 + 1] - a).contiguous()
-            if offs_c.is_cuda:
-                t.cuda.current_stream().synchronize()
-            self._with_room(pend, lambda: e.sketch_device(d_bases + a, offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0))
-            pend.append(self._share_begin(len(plan), pend))
+            if r1 > r0:
+                offs_c = (offsets_dev[r0:r1 + 1] - a).contiguous()
+                if offs_c.is_cuda:
+                    t.cuda.current_stream().synchronize()
+                self._with_room(pend, lambda: e.sketch_device(d_bases + a, offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0))
+            pend.append(self._share_begin(len(plan), pend, have_batch=r1 > r0))     # an empty chunk still takes part in the round
         self._finish(pend)
 
     def ingest_host_chunks(self, chunks):
-        """[(bases, offsets, first_ordinal)] host batches, pipelined like ingest_device_chunked"""
+        """[(bases, offsets, first_ordinal) or None] host batches, pipelined like ingest_device_chunked; every rank passes
+        the same number of entries, None = no reads in that round"""
         pend = []
-        for bases, offsets, first in chunks:
-            self._with_room(pend, lambda: self.e.sketch_host(bases, offsets, first))
-            pend.append(self._share_begin(len(chunks), pend))
+        for ch in chunks:
+            if ch is not None:
+                bases, offsets, first = ch
+                self._with_room(pend, lambda: self.e.sketch_host(bases, offsets, first))
+            pend.append(self._share_begin(len(chunks), pend, have_batch=ch is not None))
         self._finish(pend)
 
     def _with_room(self, pend, fn):
@@ -551,10 +555,16 @@ class ReplicatedMdbg:
         self._drain(pend)
         return fn()
 
-    def _share_begin(self, n_chunks, pend):
-        """start sending the batch sketched last to every peer and receiving theirs -> pending item"""
+    def _share_begin(self, n_chunks, pend, have_batch=True):
+        """start sending the batch sketched last (nothing if this rank had no reads for the round) to every peer and
+        receiving theirs -> pending item"""
         t, e, c = self.t, self.e, self.c
-        h, p, off, first, n = e.last_sketch()
+        if have_batch:
+            h, p, off, first, n = e.last_sketch()
+        else:
+            dev = getattr(e, "device", None)
+            h, p, off, first, n = (t.empty(0, dtype=t.int64, device=dev), t.empty(0, dtype=t.int32, device=dev),
+                                   t.zeros(1, dtype=t.int64, device=dev), 0, 0)
         meta = c.allgather_i64([h.shape[0], n, first])
         peers = [r for r in range(c.world) if r != c.rank]
         if not peers:
@@ -564,7 +574,8 @@ class ReplicatedMdbg:
             self._drain(pend)
             e.store_reserve(int(sum(x[0] for x in meta) * n_chunks * 1.2) + (1 << 20), int(sum(x[1] for x in meta) * n_chunks * 1.2) + 4096 * n_chunks * c.world)
             self.sized = True
-            h, p, off, first, n = e.last_sketch()          # the store may have moved
+            if have_batch:
+                h, p, off, first, n = e.last_sketch()      # the store may have moved
         bufs = self._with_room(pend, lambda: e.reserve_import([int(meta[r][0]) for r in peers]))
         offs = [t.empty(int(meta[r][1]) + 1, dtype=t.int64, device=off.device) for r in peers]
         handle = c.exchange([(r, [h, p, off]) for r in peers], [(r, [bufs[i][0], bufs[i][1], offs[i]]) for i, r in enumerate(peers)])
@@ -597,10 +608,11 @@ class ReplicatedMdbg:
         return part["n_nodes"]
 
 
-def plan_chunks(offsets_host, n_chunks):
+def plan_chunks(offsets_host, n_chunks, keep_empty=False):
     """cut a batch (host copy of its offsets) into n_chunks runs of whole reads with roughly equal bases:
     -> [(r0, r1, aligned_byte, n_bytes)]: the chunk is reads [r0, r1), passed with base pointer + aligned_byte (a multiple
-    of 16 <= offsets[r0]) and offsets rebased by it; n_bytes = offsets[r1] - aligned_byte"""
+    of 16 <= offsets[r0]) and offsets rebased by it; n_bytes = offsets[r1] - aligned_byte.  keep_empty: always n_chunks
+    entries (every rank of a collective driver must run the same number of rounds, however few reads it holds)"""
     import numpy as np
     o = np.asarray(offsets_host, dtype=np.uint64)
     n = len(o) - 1
@@ -611,7 +623,7 @@ def plan_chunks(offsets_host, n_chunks):
     cuts.append(n)
     plan = []
     for r0, r1 in zip(cuts, cuts[1:]):
-        if r1 > r0:
+        if r1 > r0 or keep_empty:
             a = int(o[r0]) // 16 * 16
             plan.append((r0, r1, a, int(o[r1]) - a))
     return plan

@@ -76,6 +76,35 @@ def test_thread_ranks_numpy_engine(world, mode):
     check_against_oracle(out, reads)
 
 
+def test_uneven_ranks_pipelined_rounds():
+    """ranks with different numbers of chunks (one of them with no reads at all): every rank still takes part in every
+    round of the pipelined replicated-sketch exchange"""
+    from engine_numpy import NumpyEngine
+    reads = workload()[:90]
+    world = 3
+    tw = D.ThreadWorld(world)
+    out, errs = [None] * world, []
+    shares = {0: [(0, 30), (30, 50), (50, 70)], 1: [(70, 90)], 2: []}
+
+    def body(r):
+        try:
+            drv = D.ReplicatedMdbg(NumpyEngine(K, L, DENS, A), D.ThreadComm(tw, r, torch), torch)
+            chunks = [O.concat_reads(reads[a:b]) + (a,) for a, b in shares[r]]
+            drv.ingest_host_chunks(chunks + [None] * (3 - len(chunks)))
+            out[r] = drv.finalize()
+        except BaseException as e:           # noqa: BLE001
+            errs.append(e)
+            tw.barrier.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    check_against_oracle(out, reads)
+    assert D.plan_chunks(np.array([0, 5, 9], dtype=np.uint64), 4, keep_empty=True)[-1][:2] == (2, 2)
+    assert len(D.plan_chunks(np.array([0, 5, 9], dtype=np.uint64), 4)) == 2
+
+
 def _gloo_worker(rank, world, port, tmpdir, mode):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)

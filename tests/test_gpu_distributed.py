@@ -140,3 +140,35 @@ def test_chunked_two_context_pipeline_matches_oracle():
     assert np.array_equal(tab["keys"], exp["keys"])
     for f in ("index", "abundance", "seqlen", "reversed", "src_read", "src_start", "src_end"):
         assert np.array_equal(tab[f].astype(np.uint64), exp[f].astype(np.uint64)), f
+
+
+def test_uneven_ranks_pipelined_rounds_gpu():
+    """ranks with different numbers of chunks, one with no reads at all, through the zero-copy import path"""
+    import torch
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import dist as D, synth
+    reads = synth.synth_reads(5, 150000, 120, mean_len=9000, sd_len=2000, min_len=2000, max_len=15000, err_ppm=1500)
+    k, l, d, a = 6, 12, 0.004, 2
+    world = 3
+    tw = D.ThreadWorld(world)
+    out, errs = [None] * world, []
+    shares = {0: [(0, 40), (40, 70), (70, 90)], 1: [(90, 120)], 2: []}
+    dev = torch.device("cuda", 0)
+
+    def body(r):
+        try:
+            with R.Mdbg(k, l, d, a, device=0) as m:
+                drv = D.ReplicatedMdbg(D.GpuEngine(m, torch, dev), D.ThreadComm(tw, r, torch), torch)
+                chunks = [O.concat_reads(reads[x:y]) + (x,) for x, y in shares[r]]
+                drv.ingest_host_chunks(chunks + [None] * (3 - len(chunks)))
+                part = drv.finalize()
+                out[r] = {f: (v.cpu() if hasattr(v, "cpu") else v) for f, v in part.items()}
+        except BaseException as e:           # noqa: BLE001
+            errs.append(e)
+            tw.barrier.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    check_against_oracle(out, reads, k, l, d, a)
