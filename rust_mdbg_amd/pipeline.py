@@ -58,3 +58,30 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
     return dict(n_reads=n_reads, n_bases=n_bases, n_minimizers=stats["n_minimizers"], n_windows=stats["n_windows"],
                 n_nodes_before=nodes["n_nodes_before"], n_nodes=nodes["n_nodes"], n_edges=len(edges["n1"]),
                 presimp_removed=edges["presimp_removed"])
+
+
+def run_multik(path, prefix, ks, l, density, min_abundance=2, reads_already_hpc=False, presimp=0.01, batch_bases=256 << 20,
+               strip_newlines=False, device=-1):
+    """One pass over the reads, one graph per k (the k sweep of the reference's utils/multik:69-78 without its contig
+    feedback): the reads are sketched once, the sketches stay resident on the GPU, and every k only clears and refills the
+    counting table (mdbg_reset) and rebuilds nodes and edges.  Writes <prefix>-k<k>.gfa; -> {k: counters}"""
+    ks = list(ks)
+    out = {}
+    n_reads = n_bases = 0
+    with Mdbg(ks[0], l, density, min_abundance, reads_already_hpc=reads_already_hpc, device=device) as m, Reader(path, strip_newlines) as r:
+        for bases, offs in r.batches(batch_bases):
+            m.ingest(bases, offs, n_reads)
+            n_reads += len(offs) - 1
+            n_bases += len(bases)
+        em = Emitter()
+        for i, k in enumerate(ks):
+            if i:
+                m.reset(k)                               # sketches stay; windows of the new k are inserted again
+            nodes = m.finalize()
+            raw = m.graph_edges(presimp, raw=True)
+            em.write_gfa("%s-k%d.gfa" % (prefix, k), nodes, raw)
+            st = m.stats()
+            out[k] = dict(n_reads=n_reads, n_bases=n_bases, n_minimizers=st["n_minimizers"], n_windows=st["n_windows"],
+                          n_nodes_before=nodes["n_nodes_before"], n_nodes=nodes["n_nodes"], n_edges=int(raw.n),
+                          presimp_removed=int(raw.presimp_removed))
+    return out

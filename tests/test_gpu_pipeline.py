@@ -36,3 +36,23 @@ def test_example_file_to_gfa(example_reads, tmp_path):
         if r["reversed"][i]:
             seq = O.revcomp(seq)
         assert f[0] == str(r["index"][i]) and f[2] == seq.decode() and f[5] == "(%d, %d)" % tuple(int(v) for v in r["shift_full"][i])
+
+
+def test_multik_from_one_pass(example_reads, tmp_path):
+    """k sweep on resident sketches (utils/multik:69-78 shape): every k must equal a from-scratch oracle run with that k"""
+    from rust_mdbg_amd import pipeline
+    prefix = str(tmp_path / "mk")
+    l, d, a = 10, 0.0008, 2
+    ks = [7, 5, 12]
+    out = pipeline.run_multik(os.path.join(GOLDEN, "reads-0.00.fa.gz"), prefix, ks, l, d, a, batch_bases=5_000_000)
+    b, o = O.concat_reads(example_reads)
+    for k in ks:
+        g = O.Graph(k, l, d, a)
+        g.ingest(b, o)
+        r = g.finalize(with_edges=True)
+        c = out[k]
+        assert (c["n_nodes_before"], c["n_nodes"], c["n_edges"], c["presimp_removed"]) == (r["n_nodes_before"], r["n_nodes"], r["n_edges"], r["presimp_removed"])
+        lines = open("%s-k%d.gfa" % (prefix, k)).read().split("\n")
+        assert [x for x in lines if x.startswith("S")] == ["S\t%d\t*\tLN:i:%d\tKC:i:%d" % (r["index"][i], r["seqlen"][i], r["abundance"][i]) for i in range(r["n_nodes"])]
+        assert sorted(x for x in lines if x.startswith("L")) == sorted("L\t%d\t%s\t%d\t%s\t%dM" % (x, chr(p), y, chr(q), ov) for x, p, y, q, ov in oracle_edges(r))
+    assert out[7]["n_nodes"] == 104 and out[5]["n_nodes"] > out[12]["n_nodes"]
