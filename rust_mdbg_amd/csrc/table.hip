@@ -197,7 +197,6 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     __syncthreads();
     if (!active) return;
     const u64* w = sh_keys + threadIdx.x;
-    if (T.own_world > 1 && window_owner(w, k, T.own_world) != T.own_rank) return;
     const bool rev = window_reversed(w, k);
     const u64 h = key_hash_window(w, k, rev);
     bool claimed;
@@ -205,6 +204,59 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     if (claimed) return;                       // the claimer is accounted for through `rep` (slot_view)
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
+}
+
+// Partitioned table (replicated-sketch mode): most windows of a batch belong to other ranks.  One workgroup scans 2048
+// candidates, lists the local indices of the windows THIS rank owns in LDS, and then works the list off densely, so the
+// long find-or-claim chains run on full wavefronts instead of one lane in eight.
+constexpr int OWN_SPAN = 2048;
+__global__ __launch_bounds__(256) void insert_owned_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
+                                                                   const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
+                                                                   u32* __restrict__ cap_err) {
+    extern __shared__ u64 sh_keys[];           // [OWN_SPAN + k] keys, then u16 list[OWN_SPAN], then the counter
+    if (cap_err[1]) return;
+    const u32 k = T.ks.k;
+    u16* const list = (u16*)(sh_keys + OWN_SPAN + k);
+    u32* const n_own = (u32*)(list + OWN_SPAN);
+    const u64 b0 = i0 + (u64)blockIdx.x * OWN_SPAN;
+    const u64 lim = b0 + OWN_SPAN + k - 1 < i1 ? b0 + OWN_SPAN + k - 1 : i1;
+    for (u64 t = b0 + threadIdx.x; t < lim; t += 256) sh_keys[t - b0] = mh[t];
+    if (threadIdx.x == 0) *n_own = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < OWN_SPAN / 256; ++u) {
+        const u32 li = u * 256 + threadIdx.x;
+        const u64 i = b0 + li;
+        bool mine = false;
+        if (i + k <= i1 && window_owner(sh_keys + li, k, T.own_world) == T.own_rank) {       // ownership first: it needs no further loads
+            const u32 slot = mread[i];
+            const u64 rs = roff[slot], re = roff[slot + 1];
+            mine = re - rs > k && i + k <= re;
+        }
+        const u64 m = __ballot(mine);
+        u32 base = 0;
+        if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(n_own, (u32)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (mine) list[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = (u16)li;
+    }
+    __syncthreads();
+    const u32 n = *n_own;
+    for (u32 j = threadIdx.x; j < n; j += 256) {
+        const u32 li = list[j];
+        const u64 i = b0 + li;
+        const u32 slot = mread[i];
+        const u64 win = i - roff[slot];
+        if (win > WIN_MASK) { *cap_err = 1; continue; }
+        const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
+        const u64* w = sh_keys + li;
+        const bool rev = window_reversed(w, k);
+        const u64 h = key_hash_window(w, k, rev);
+        bool claimed;
+        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+        if (claimed) continue;
+        atomicAdd(&T.tab[s].count, 1u);
+        push_ordinal(T, s, ord);
+    }
 }
 
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch
@@ -343,17 +395,24 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
 
 // number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
 // the same, counting only the windows owned by `rank` (replicated-sketch mode); one thread per minimizer index
-__global__ void count_owned_windows_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                           u32 k, u32 world, u32 rank, u64* __restrict__ out) {
-    const u64 i = i0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    bool mine = false;
-    if (i < i1) {
-        const u32 slot = mread[i];
-        const u64 rs = roff[slot], re = roff[slot + 1];
-        mine = re - rs > k && i + k <= re && window_owner(mh + i, k, world) == rank;
+__global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
+                                                                  u32 k, u32 world, u32 rank, u64* __restrict__ out) {
+    constexpr int WPT = 4;                   // four candidates per thread: their dependent loads overlap
+    const u64 b0 = i0 + (u64)blockIdx.x * (256 * WPT);
+    u32 slot[WPT]; bool ok[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) { const u64 i = b0 + u * 256 + threadIdx.x; ok[u] = i < i1; slot[u] = ok[u] ? mread[i] : 0; }
+    u32 mine = 0;
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const u64 i = b0 + u * 256 + threadIdx.x;
+        if (ok[u]) {
+            const u64 rs = roff[slot[u]], re = roff[slot[u] + 1];
+            if (re - rs > k && i + k <= re && window_owner(mh + i, k, world) == rank) ++mine;
+        }
     }
-    const u64 m = __ballot(mine);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd((unsigned long long*)ctr_shard(out), (unsigned long long)__popcll(m));
+    for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd((unsigned long long*)ctr_shard(out), (unsigned long long)mine);
 }
 __global__ __launch_bounds__(1024) void count_windows_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32 k, u64* __restrict__ out) {
     __shared__ u64 ws[16];
@@ -500,8 +559,13 @@ void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, 
                            u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s) {
     if (i1 <= i0) return;
     (void)n_windows;
-    hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), (256 + T.ks.k) * sizeof(u64), s, T, mh, mread, roff,
-                       i0, i1, slot0, first_ordinal, cap_err);
+    const u64 n = i1 - i0;
+    if (T.own_world > 1)
+        hipLaunchKernelGGL(insert_owned_windows_kernel, dim3((unsigned)((n + OWN_SPAN - 1) / OWN_SPAN)), dim3(256),
+                           (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err);
+    else
+        hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (256 + T.ks.k) * sizeof(u64), s, T, mh, mread, roff,
+                           i0, i1, slot0, first_ordinal, cap_err);
 }
 void launch_reserve_check(const u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s) {
     hipLaunchKernelGGL(reserve_check_kernel, dim3(1), dim3(1), 0, s, n_distinct, batch_windows, cap, too_small);
@@ -521,7 +585,7 @@ void launch_popc_prefix(const u64* bm, u64 n_words, u32* block_tmp, u32* pre, hi
     hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp, pre);
 }
 void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32 rank, u64* out_shards, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, rank, out_shards);
+    if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, rank, out_shards);
 }
 void launch_fill_mread(const u64* roff, u32 slot0, u32 n_reads, u32* mread, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(fill_mread_kernel, dim3((n_reads + 3) / 4), dim3(256), 0, s, roff, slot0, n_reads, mread);
