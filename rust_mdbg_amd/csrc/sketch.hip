@@ -138,26 +138,38 @@ __device__ inline u32 shift_in_bit(u32 acc, u64 mask) {
     return out;
 }
 
-struct RollState { u32 hist, G, R, prev; };
+// Integer VALU issue rates on gfx950 (profiles/r01_g_valu_rates.txt): v_and/or/xor, v_add_u32, v_lshrrev and v_bitop3 with
+// VGPR / inline-constant operands issue in 2 cycles per wave64 instruction; v_lshlrev, v_bfe, v_lshl_or and any instruction
+// with an SGPR source take 4.  The few wrappers below pin the 2-cycle form where the compiler would pick a 4-cycle one
+// (it counts instructions, not issue cycles); everything else in the step is left to the compiler.
+__device__ __forceinline__ u32 v_and24(u32 x) { u32 d; asm("v_and_b32 %0, 24, %1" : "=v"(d) : "v"(x)); return d; }
+__device__ __forceinline__ u32 v_shr2(u32 x) { u32 d; asm("v_lshrrev_b32 %0, 2, %1" : "=v"(d) : "v"(x)); return d; }
+__device__ __forceinline__ u32 v_shr(u32 x, u32 sh) { u32 d; asm("v_lshrrev_b32 %0, %1, %2" : "=v"(d) : "v"(sh), "v"(x)); return d; }
+__device__ __forceinline__ u32 v_dbl(u32 x) { u32 d; asm("v_add_u32 %0, %1, %1" : "=v"(d) : "v"(x)); return d; }                  // x << 1
+__device__ __forceinline__ u32 v_and_or(u32 x, u32 y, u32 z) { u32 d; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d; }   // (x & y) | z
+__device__ __forceinline__ u32 v_and(u32 x, u32 y) { u32 d; asm("v_and_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
 
-// Eight steps of the rolling partial hashes over the low 16 bits of w (8 two-bit codes), branch-free: the code history /
-// table addresses of all 8 steps first (a short ALU chain), then the 8 LDS reads back to back, then the G/R chains.
-// Lanes whose base is not a run start compute the same values and discard them with v_cndmask: with 64 lanes some lane
-// always pushes, so an exec-mask branch would never be skipped and would serialise every ds_read's latency.
+struct RollState { u32 hist, G, R, prev8; };       // prev8: code of the previous raw base << 3 (32: none)
+struct RollConsts { u32 hs_shift, k60, maskR; };   // kept in VGPRs: an SGPR source would halve the issue rate of its instruction
+
+// Eight steps of the rolling partial hashes over 8 two-bit codes (ws: code i at bits [4+2i : 3+2i]), branch-free: the code
+// history / table addresses of all 8 steps first (a short ALU chain), then the 8 LDS reads back to back, then the G/R
+// chains.  Lanes whose base is not a run start compute the same values and discard them with v_cndmask: with 64 lanes
+// some lane always pushes, so an exec-mask branch would never be skipped and would serialise every ds_read's latency.
 // Returns 8 bits, step 0 in bit 7: candidate flags (EMIT) or kept flags (!EMIT).
 template <bool HPC, bool EMIT>
-__device__ inline u32 roll8(RollState& st, u32 w, const u32* tbl, u32 bfe_off, u32 thrF, u32 thrR, u32 maskR) {
+__device__ inline u32 roll8(RollState& st, u32 ws, const u32* tbl, const RollConsts& K, u32 thrF, u32 thrR) {
     u32 ad[8]; u64 kpm[8]; bool kp[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const u32 c_ = (w >> (2 * i)) & 3u;
-        kp[i] = !HPC || c_ != st.prev;
+        const u32 c8_ = v_and24(ws);
+        ws = v_shr2(ws);
+        kp[i] = !HPC || c8_ != st.prev8;
         kpm[i] = __builtin_amdgcn_ballot_w64(kp[i]);
-        const u32 c8_ = c_ << 3;
-        ad[i] = (__builtin_amdgcn_ubfe(st.hist, bfe_off, 2u) << 5) | c8_;
+        ad[i] = v_and_or(v_shr(st.hist, K.hs_shift), K.k60, c8_);          // (out code << 5) | (in code << 3)
         const u32 hn = (st.hist << 2) | c8_;
         st.hist = __builtin_unpredictable(kp[i]) ? hn : st.hist;
-        st.prev = c_;
+        st.prev8 = c8_;
     }
     uint2 x[8];
 #pragma unroll
@@ -165,13 +177,13 @@ __device__ inline u32 roll8(RollState& st, u32 w, const u32* tbl, u32 bfe_off, u
     u32 bits = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const u32 Gn = (st.G << 1) ^ x[i].x, Rn = (st.R >> 1) ^ x[i].y;
+        const u32 Gn = v_dbl(st.G) ^ x[i].x, Rn = (st.R >> 1) ^ x[i].y;
         st.G = __builtin_unpredictable(kp[i]) ? Gn : st.G;
         st.R = __builtin_unpredictable(kp[i]) ? Rn : st.R;
         if (EMIT) {
             // a run continuation keeps G/R, so it repeats its predecessor's verdict: harmless, the fix-up rejects
             // positions that are not run starts
-            const u64 cm = __builtin_amdgcn_ballot_w64(st.G <= thrF) | __builtin_amdgcn_ballot_w64((st.R & maskR) <= thrR);
+            const u64 cm = __builtin_amdgcn_ballot_w64(st.G <= thrF) | __builtin_amdgcn_ballot_w64(v_and(st.R, K.maskR) <= thrR);
             bits = shift_in_bit(bits, cm);
         } else {
             bits = shift_in_bit(bits, kpm[i]);
@@ -266,7 +278,11 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
     }
 
     // ---- phase 2: per-lane rolling partial hashes over SEG raw bases ------------------------------
-    const u32 thrF = a.c.thrF, thrR = a.c.thrR, maskR = a.c.maskR, bfe_off = a.c.bfe_off;
+    const u32 thrF = a.c.thrF, thrR = a.c.thrR, bfe_off = a.c.bfe_off;
+    RollConsts K;                             // asm outputs: they stay in VGPRs
+    asm("v_mov_b32 %0, %1" : "=v"(K.hs_shift) : "s"(bfe_off - 5u));
+    asm("v_mov_b32 %0, 0x60" : "=v"(K.k60));
+    asm("v_mov_b32 %0, %1" : "=v"(K.maskR) : "s"(a.c.maskR));
     u32 cb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) cb[i] = 0;
@@ -281,11 +297,11 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
         for (int nW = 2;; nW = HALO / 16) {
             st.hist = 0; st.G = a.c.G0; st.R = a.c.R0; npush = 0;
             const int ws = tid * SEG_WORDS - nW;
-            st.prev = (ws - 1 >= -HALO / 16) ? codes[ws - 1] >> 30 : 4u;
+            st.prev8 = (ws - 1 >= -HALO / 16) ? (codes[ws - 1] >> 30) << 3 : 32u;
             for (int k = 0; k < nW; ++k) {
                 const u32 w = codes[ws + k];
-                npush += __popc(roll8<HPC, false>(st, w, tbl, bfe_off, thrF, thrR, maskR));
-                npush += __popc(roll8<HPC, false>(st, w >> 16, tbl, bfe_off, thrF, thrR, maskR));
+                npush += __popc(roll8<HPC, false>(st, w << 3, tbl, K, thrF, thrR));
+                npush += __popc(roll8<HPC, false>(st, w >> 13, tbl, K, thrF, thrR));
             }
             if (npush >= l || nW == HALO / 16) break;
         }
@@ -303,28 +319,29 @@ __global__ __launch_bounds__(TILE_THREADS, 7) void sketch_tile_kernel(TileArgs a
             }
             if (dirty || (runs < l + 1 && q > 0)) force = true;
             st.hist = 0; st.G = a.c.G0; st.R = a.c.R0;
-            st.prev = q > 0 ? (((u32)a.bases[q - 1] >> 1) & 3u) : 4u;
+            u32 prev = q > 0 ? (((u32)a.bases[q - 1] >> 1) & 3u) : 4u;
             for (; q < seg0; ++q) {
                 const u32 c_ = ((u32)a.bases[q] >> 1) & 3u;
-                if (!HPC || c_ != st.prev) {
+                if (!HPC || c_ != prev) {
                     const u32 c8_ = c_ << 3;
                     const u32 ad_ = (__builtin_amdgcn_ubfe(st.hist, bfe_off, 2u) << 5) | c8_;
                     st.hist = (st.hist << 2) | c8_;
                     const uint2 x_ = *(const uint2*)((const char*)tbl + ad_);
                     st.G = (st.G << 1) ^ x_.x; st.R = (st.R >> 1) ^ x_.y;
                 }
-                st.prev = c_;
+                prev = c_;
             }
+            st.prev8 = prev << 3;
         }
         // main loop: 8 iterations x 32 bases; cb[] is rotated so that every index stays static (registers)
         const uint2* segp = (const uint2*)(codes + tid * SEG_WORDS);
 #pragma unroll 1
         for (int it = 0; it < 8; ++it) {
             const uint2 v = segp[it];
-            u32 b0 = roll8<HPC, true>(st, v.x, tbl, bfe_off, thrF, thrR, maskR);
-            u32 b1 = roll8<HPC, true>(st, v.x >> 16, tbl, bfe_off, thrF, thrR, maskR);
-            u32 b2 = roll8<HPC, true>(st, v.y, tbl, bfe_off, thrF, thrR, maskR);
-            u32 b3 = roll8<HPC, true>(st, v.y >> 16, tbl, bfe_off, thrF, thrR, maskR);
+            u32 b0 = roll8<HPC, true>(st, v.x << 3, tbl, K, thrF, thrR);
+            u32 b1 = roll8<HPC, true>(st, v.x >> 13, tbl, K, thrF, thrR);
+            u32 b2 = roll8<HPC, true>(st, v.y << 3, tbl, K, thrF, thrR);
+            u32 b3 = roll8<HPC, true>(st, v.y >> 13, tbl, K, thrF, thrR);
             // each bK holds 8 flags with step 0 in bit 7: concatenate (first step in the top bit) and reverse
             const u32 word = __brev((b0 << 24) | (b1 << 16) | (b2 << 8) | b3);
 #pragma unroll
