@@ -121,19 +121,8 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, EqFn
         s = s + 1 == T.cap ? 0 : s + 1;
     }
 }
-// scalar comparison through the accessors (routed records, any key source)
-template <class KeyFn>
-__device__ inline bool same_key_scalar(const KeySrc& ks, u64 w, KeyFn mine) {
-    const u32 k = ks.k;
-    u64 diff = 0;
-    u32 j = 0;
-    for (; j + 4 <= k && !diff; j += 4)       // four elements per round so that eight loads are in flight per round trip
-        diff = (rep_elem(ks, w, j) ^ mine(j)) | (rep_elem(ks, w, j + 1) ^ mine(j + 1)) |
-               (rep_elem(ks, w, j + 2) ^ mine(j + 2)) | (rep_elem(ks, w, j + 3) ^ mine(j + 3));
-    for (; j < k && !diff; ++j) diff = rep_elem(ks, w, j) ^ mine(j);
-    return !diff;
-}
-// comparison of a window staged in LDS (wl[0..k), orientation rev_mine) with the representative in HBM: both are
+// comparison of a key given as a contiguous run wl[0..k) (a window staged in LDS with orientation rev_mine, or a routed
+// record's canonical key) with the representative in HBM: both are
 // contiguous, so the representative is read 16 bytes per load, eight values per round trip; the last round overlaps.
 typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 __device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, bool rev_mine) {
@@ -274,7 +263,7 @@ __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0
     const u64* key = T.ks.arena + r * (k + 2);
     const u64 h = key[k + 1];                  // computed by the sender (route_count_kernel)
     bool claimed;
-    const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u64 word) { return same_key_scalar(T.ks, word, [&](u32 j) { return key[j]; }); }, claimed);
+    const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u64 word) { return same_key_window(T.ks, word, key, false); }, claimed);   // record keys are canonical
     if (claimed) return;
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, key[k]);
