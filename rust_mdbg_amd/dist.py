@@ -72,27 +72,6 @@ class TorchDistComm:
         self.dist.all_gather_object(out, obj)
         return out
 
-    def allgatherv(self, x, sizes):
-        """x: this rank's 1-D tensor, sizes[r] = length on rank r -> list of tensors (rank r's data), padded collectives
-        cut into rounds of <= max_bytes per rank"""
-        t, dist = self.torch, self.dist
-        mx = max(sizes) if sizes else 0
-        outs = [t.empty(n, dtype=x.dtype, device=self.device) for n in sizes]
-        step = max(1, min(self.max_bytes, 64 << 20) // max(1, x.element_size()))      # <= 64 MB per rank and round
-        for a in range(0, mx, step):
-            n = min(step, mx - a)
-            mine = t.zeros(n, dtype=x.dtype, device=self.device)
-            k = max(0, min(n, x.shape[0] - a))
-            if k:
-                mine[:k] = x[a:a + k]
-            buf = t.empty(n * self.world, dtype=x.dtype, device=self.device)
-            dist.all_gather_into_tensor(buf, mine)
-            for r in range(self.world):
-                kr = max(0, min(n, sizes[r] - a))
-                if kr:
-                    outs[r][a:a + kr] = buf[r * n:r * n + kr]
-        return outs
-
     def allreduce_sum_(self, x):
         self.dist.all_reduce(x)
         return x
@@ -165,9 +144,6 @@ class ThreadComm:
 
     def allgather_obj(self, obj):
         return self._exchange(obj)
-
-    def allgatherv(self, x, sizes):
-        return [v.clone() for v in self._exchange(x)]
 
     def allreduce_sum_(self, x):
         allv = self._exchange(x.clone())
@@ -249,19 +225,6 @@ class GpuEngine:
     # replicated-sketch mode ------------------------------------------------------------------------------
     def set_partition(self, world, rank):
         self.m.set_partition(world, rank)
-
-    def sketch_arrays(self):
-        """this rank's resident sketch as int64 / int32 / int64 tensors (views)"""
-        s = self.m.sketch_view()
-        m, n = int(s.n_minimizers), int(s.n_reads)
-        pos = self._view(s.d_positions, ((m + 1) // 2,)).view(self.t.int32)[:m] if m else self.t.empty(0, dtype=self.t.int32, device=self.device)
-        return self._view(s.d_hashes, (m,)), pos, self._view(s.d_read_offsets, (n + 1,))
-
-    def ingest_sketch(self, hashes, pos, read_off, first_ordinal):
-        hashes, pos, read_off = hashes.contiguous(), pos.contiguous(), read_off.contiguous()
-        self.t.cuda.synchronize()
-        self.m.ingest_sketch(hashes.data_ptr() if hashes.numel() else 0, pos.data_ptr() if pos.numel() else 0, read_off.data_ptr(),
-                             read_off.shape[0] - 1, first_ordinal)
 
     def store_reserve(self, n_minimizers, n_reads):
         self.m.store_reserve(n_minimizers, n_reads)

@@ -98,15 +98,6 @@ class NumpyEngine:
     def set_partition(self, world, rank):
         self.world, self.rank = world, rank
 
-    def sketch_arrays(self):
-        hs = np.concatenate([b["sk"]["hashes"] for b in self.batches]) if self.batches else np.zeros(0, np.uint64)
-        ps = np.concatenate([b["sk"]["pos"] for b in self.batches]).astype(np.int32) if self.batches else np.zeros(0, np.int32)
-        off, base = [0], 0
-        for b in self.batches:
-            off += [base + int(x) for x in b["sk"]["off"][1:]]
-            base += len(b["sk"]["hashes"])
-        return torch.from_numpy(_i64(hs).copy()), torch.from_numpy(ps.copy()), torch.tensor(off, dtype=torch.int64)
-
     def ingest_sketch(self, hashes, pos, read_off, first_ordinal):
         sk = dict(hashes=hashes.numpy().view(np.uint64).copy(), pos=pos.numpy().astype(np.uint64), off=read_off.numpy().view(np.uint64).copy())
         b = dict(first=int(first_ordinal), n=len(sk["off"]) - 1, sk=sk)

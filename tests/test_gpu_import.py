@@ -86,3 +86,21 @@ def test_import_misuse_is_reported():
             dst.last_batch()
         with pytest.raises(R.MdbgError):                    # commit of something that was never reserved
             dst.sketch_commit(0, 10, 0, 1, 0)
+
+
+def test_copying_import_sketch_view_ingest_sketch():
+    """mdbg_sketch_view + mdbg_ingest_sketch (the copying variant of the import): context B built only from A's sketch"""
+    import rust_mdbg_amd as R
+    k, l, d, a = 4, 12, 0.008, 1
+    reads = rand_reads(21, 30, 2000, 7000) + [b"", b"ACGT"]
+    bb, oo = O.concat_reads(reads)
+    with R.Mdbg(k, l, d, a, device=0) as src, R.Mdbg(k, l, d, a, device=0) as dst:
+        src.ingest(bb, oo, 0)
+        v = src.sketch_view()
+        assert int(v.n_reads) == len(reads)
+        dst.ingest_sketch(v.d_hashes, v.d_positions, v.d_read_offsets, int(v.n_reads), 0)
+        dst.insert_resident()
+        got = dst.finalize()
+    g = O.Graph(k, l, d, a)
+    assert g.ingest(bb, oo) == 0
+    assert_nodes_equal(got, g.finalize(with_edges=False))
