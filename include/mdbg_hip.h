@@ -14,6 +14,7 @@
  *   mdbg_sketch_only       Read::extract (density scheme)                              src/read.rs:85-90,176-211
  *   mdbg_finalize          abundance filter + read-only view of dbg_nodes              src/main.rs:922-929,1014-1016
  *                          + what the .sequences line of a node is built from          src/main.rs:693-708
+ *   mdbg_graph_edges       km_index + orientation tests + presimp + overlaps           src/main.rs:1017-1117
  *   mdbg_reset             a new k over the same reads (utils/multik:69-78 re-runs the binary per k)
  *   mdbg_destroy           process exit
  *
@@ -48,8 +49,8 @@ enum {
 };
 
 #define MDBG_MAX_L 32u         /* l-mers longer than this are rejected (reference: unbounded) */
-#define MDBG_MAX_MINABUND 8u
-#define MDBG_FLAG_FORCE_GENERIC 1u /* every tile takes the generic exact sketch kernel (testing / cross-check) */   /* the table tracks the A smallest ordinals per node for A <= 8 */
+#define MDBG_MAX_MINABUND 8u   /* the table tracks the A smallest ordinals per node for A <= 8 */
+#define MDBG_FLAG_FORCE_GENERIC 1u /* every tile takes the generic exact sketch kernel (testing / cross-check) */
 
 typedef struct mdbg_ctx mdbg_ctx;
 
