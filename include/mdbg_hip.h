@@ -76,7 +76,7 @@ typedef struct mdbg_nodes {
     const uint64_t* keys;       /* n*k : canonical k-min-mer (KmerVec::normalize().0) */
     const uint32_t* index;      /* n   : DbgEntry.index = rank of first sighting among ALL distinct k-min-mers (NODE_INDEX) */
     const uint16_t* abundance;  /* n   : DbgEntry.abundance (u16, wraps like the reference) */
-    const uint32_t* seqlen;     /* n   : DbgEntry.seqlen of the A-th sighting (main.rs:680-682,778) */
+    const uint32_t* seqlen;     /* n   : DbgEntry.seqlen of the A-th sighting (main.rs:680-682,778; see n_wrapped) */
     const uint16_t* shift;      /* n*2 : DbgEntry.shift, truncated to u16 (main.rs:675) */
     const uint64_t* shift_full; /* n*2 : un-truncated shift as printed in the .sequences line (main.rs:702) */
     const uint64_t* src_read;   /* n   : ordinal of the read the A-th sighting came from */
@@ -84,7 +84,9 @@ typedef struct mdbg_nodes {
     const uint64_t* src_end;    /* n   : raw end (exclusive) = pos[i+k-1] + l              (read_offsets.1) */
     const uint8_t* reversed;    /* n   : seq_reversed of that sighting (sequence must be reverse-complemented, main.rs:701) */
     uint64_t n_distinct;        /* "Number of nodes before abundance filter" (main.rs:926) */
-    uint64_t n_wrapped;         /* nodes seen >= 65536 times: abundance wrapped (reference: u16), metadata is that of the A-th sighting */
+    uint64_t n_wrapped;         /* nodes seen >= 65536 times: the abundance wrapped like the reference's u16, and seqlen / shift / src_*
+                                 * are those of sighting A + 65536*floor((count-A)/65536): the reference refreshes the entry whenever
+                                 * the abundance before the increment equals A-1 (main.rs:676-684) */
 } mdbg_nodes;
 
 typedef struct mdbg_stats {

@@ -17,3 +17,6 @@ struct EdgeResult {                // device pointers into EdgeBuffers, valid un
 };
 // returns hipSuccess or the failing HIP error; synchronises the stream before returning
 hipError_t build_edges(EdgeBuffers* B, const EdgeNodes& nd, float presimp, hipStream_t s, EdgeResult* out);
+
+// sorts every segment [offsets[i], offsets[i+1]) of keys_in ascending into keys_out (rocPRIM segmented radix sort); B provides the scratch
+hipError_t sort_segments_u64(EdgeBuffers* B, const uint64_t* keys_in, uint64_t* keys_out, uint64_t n, uint32_t n_segments, const uint32_t* offsets, hipStream_t s);

@@ -239,3 +239,12 @@ hipError_t build_edges(EdgeBuffers* B, const EdgeNodes& nd, float presimp, hipSt
     out->overlap = B->ov.as<u32>(); out->presimp_removed = removed;
     return hipSuccess;
 }
+
+hipError_t sort_segments_u64(EdgeBuffers* B, const uint64_t* keys_in, uint64_t* keys_out, uint64_t n, uint32_t n_segments, const uint32_t* offsets, hipStream_t s) {
+    if (!n || !n_segments) return hipSuccess;
+    size_t tb = 0;
+    EHIP(rocprim::segmented_radix_sort_keys(nullptr, tb, keys_in, keys_out, (unsigned int)n, n_segments, offsets, offsets + 1, 0, 64, s));
+    EHIP(B->tmp.ensure(tb + 256));
+    EHIP(rocprim::segmented_radix_sort_keys(B->tmp.p, tb, keys_in, keys_out, (unsigned int)n, n_segments, offsets, offsets + 1, 0, 64, s));
+    return hipSuccess;
+}

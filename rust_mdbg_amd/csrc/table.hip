@@ -308,6 +308,7 @@ struct FinArgs {
     BatchTab bt;
     u64* solid_list; u64* solid_count;       // compact list of solid slots (fin_mark -> fin_emit)
     u64* o_row;                              // non-null: write node q at position q and its global row here (partitioned table)
+    const u64* ath_override;                 // [Slot.pad - 1]: sighting whose metadata a node that wrapped its u16 abundance keeps (null: none)
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
     const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
     u64* sh_solid; u64* sh_wrapped; u64* sh_distinct;   // sharded counters (CTR_SHARDS u64 each)
@@ -337,7 +338,7 @@ __device__ inline u64 rep_ordinal(const FinArgs& F, u64 word) {
 }
 struct SlotView { u32 count; u64 first, ath; bool solid; };
 // merges the claimer back in: total count, smallest ordinal, A-th smallest ordinal (valid when count >= A)
-__device__ inline SlotView slot_view(const Slot& e, u64 s, const u64* mx, u32 A, u64 r) {
+__device__ inline SlotView slot_view(const Slot& e, u64 s, const u64* mx, u32 A, u64 r, const u64* ath_override = nullptr) {
     SlotView v;
     v.count = e.count + 1u;
     v.first = r < e.m1 ? r : e.m1;
@@ -348,6 +349,7 @@ __device__ inline SlotView slot_view(const Slot& e, u64 s, const u64* mx, u32 A,
         v.ath = r < prev ? prev : (r < last ? r : last);
     }
     v.solid = A == 1 || (u16)v.count >= (u16)A;                                           // src/main.rs:922-929 (u16 abundance)
+    if (e.pad && ath_override) v.ath = ath_override[e.pad - 1];                            // see wrap_list_kernel
     return v;
 }
 
@@ -380,6 +382,80 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
     }
     __syncthreads();
     if (solid) F.solid_list[bbase + wcnt[wv] + __popcll(m & ((1ull << lane) - 1))] = s;
+}
+
+// ---- nodes whose u16 abundance wrapped (src/main.rs:676-684) ------------------------------------------
+// The reference refreshes seqlen / shift (and writes the .sequences line) whenever the abundance BEFORE the increment
+// equals minabund - 1.  The abundance is a u16 that wraps in release builds, so for a k-min-mer seen c >= 65536 + A times
+// the entry ends up describing sighting j* = A + 65536 * floor((c - A) / 65536), not the A-th.  The min-cascade of the
+// table only knows the A smallest ordinals; for these (rare, extremely repetitive) keys the exact j*-th smallest ordinal is
+// recovered here: list them (Slot.pad = rank + 1), re-scan the resident windows (or routed records) collecting the
+// ordinals of exactly those keys, sort each list, pick element j* - 1.
+__global__ __launch_bounds__(256) void wrap_list_kernel(Slot* __restrict__ tab, u64 cap, u32 A, u64* __restrict__ w_jstar, u32* __restrict__ w_count,
+                                                        unsigned long long* __restrict__ counters /* [0] nodes, [1] occurrences */) {
+    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap) return;
+    const u64 word = tab[s].word;
+    if (word == EMPTY) return;
+    const u32 count = tab[s].count + 1u;
+    if (count < A || count - A < 65536u || !(A == 1 || (u16)count >= (u16)A)) return;
+    const u32 r = (u32)atomicAdd(&counters[0], 1ull);
+    atomicAdd(&counters[1], (unsigned long long)count);
+    w_count[r] = count; w_jstar[r] = (u64)A + 65536ull * ((count - A) / 65536u);
+    tab[s].pad = r + 1;
+}
+// lookup without insertion: slot of a key that is known to be in the table, or ~0 (keys of other ranks)
+template <class EqFn>
+__device__ inline u64 find_slot(const TableArgs& T, u64 h, EqFn same_key) {
+    const u64 fp = (h >> 34) & 0x3FFFFFFFull;
+    u64 s = home_slot(h, T.cap);
+    for (;;) {
+        const u64 w = load_relaxed(&T.tab[s].word);
+        if (w == EMPTY) return ~0ull;
+        if ((w >> 34) == fp && same_key(w)) return s;
+        s = s + 1 == T.cap ? 0 : s + 1;
+    }
+}
+__global__ __launch_bounds__(256) void wrap_scan_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff,
+                                                                u64 i0, u64 i1, u32 slot0, u64 first_ordinal, const u32* __restrict__ w_start,
+                                                                u32* __restrict__ w_fill, u64* __restrict__ occ) {
+    extern __shared__ u64 sh_keys[];
+    const u32 k = T.ks.k;
+    const u64 b0 = i0 + (u64)blockIdx.x * 256;
+    const u64 lim = b0 + 256 + k - 1 < i1 ? b0 + 256 + k - 1 : i1;
+    for (u64 t = b0 + threadIdx.x; t < lim; t += 256) sh_keys[t - b0] = mh[t];
+    const u64 i = b0 + threadIdx.x;
+    bool active = i < i1;
+    u64 ord = 0;
+    if (active) {
+        const u32 slot = mread[i];
+        const u64 rs = roff[slot], re = roff[slot + 1];
+        active = re - rs > k && i + k <= re && i - rs <= WIN_MASK;
+        ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | (i - rs);
+    }
+    __syncthreads();
+    if (!active) return;
+    const u64* w = sh_keys + threadIdx.x;
+    if (T.own_world > 1 && window_owner(w, k, T.own_world) != T.own_rank) return;
+    const bool rev = window_reversed(w, k);
+    const u64 s = find_slot(T, key_hash_window(w, k, rev), [&](u64 word) { return same_key_window(T.ks, word, w, rev); });
+    if (s == ~0ull) return;
+    const u32 pad = T.tab[s].pad;
+    if (pad) occ[w_start[pad - 1] + atomicAdd(&w_fill[pad - 1], 1u)] = ord;
+}
+__global__ __launch_bounds__(256) void wrap_scan_records_kernel(TableArgs T, u64 n_records, const u32* __restrict__ w_start, u32* __restrict__ w_fill, u64* __restrict__ occ) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_records) return;
+    const u32 k = T.ks.k;
+    const u64* key = T.ks.arena + r * (k + 2);
+    const u64 s = find_slot(T, key[k + 1], [&](u64 word) { return same_key_window(T.ks, word, key, false); });
+    if (s == ~0ull) return;
+    const u32 pad = T.tab[s].pad;
+    if (pad) occ[w_start[pad - 1] + atomicAdd(&w_fill[pad - 1], 1u)] = key[k];
+}
+__global__ void wrap_pick_kernel(u32 n_w, const u32* __restrict__ w_start, const u64* __restrict__ w_jstar, const u64* __restrict__ sorted, u64* __restrict__ ath_override) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_w) ath_override[r] = sorted[w_start[r] + w_jstar[r] - 1];
 }
 
 // number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
@@ -428,7 +504,7 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
     if (q < n_solid) {
         const u64 s = F.solid_list[q];
         const Slot e = F.tab[s];
-        const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word));
+        const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word), F.ath_override);
         u64 i1, D; decode_ordinal(F, v.first, i1, D);
         const u64 below = (1ull << (D & 63)) - 1;
         const u64 row = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);          // row of the node in index order
@@ -591,6 +667,20 @@ void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* o
 }
 void launch_fin_mark(const FinArgs& F, hipStream_t s) {
     hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 1023) / 1024)), dim3(1024), 0, s, F);
+}
+void launch_wrap_list(Slot* tab, u64 cap, u32 A, u64* w_jstar, u32* w_count, unsigned long long* counters, hipStream_t s) {
+    hipLaunchKernelGGL(wrap_list_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, tab, cap, A, w_jstar, w_count, counters);
+}
+void launch_wrap_scan_windows(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
+                              const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(wrap_scan_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), (256 + T.ks.k) * sizeof(u64), s, T, mh, mread, roff,
+                                    i0, i1, slot0, first_ordinal, w_start, w_fill, occ);
+}
+void launch_wrap_scan_records(const TableArgs& T, u64 n_records, const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {
+    if (n_records) hipLaunchKernelGGL(wrap_scan_records_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, T, n_records, w_start, w_fill, occ);
+}
+void launch_wrap_pick(u32 n_w, const u32* w_start, const u64* w_jstar, const u64* sorted, u64* ath_override, hipStream_t s) {
+    if (n_w) hipLaunchKernelGGL(wrap_pick_kernel, dim3((n_w + 255) / 256), dim3(256), 0, s, n_w, w_start, w_jstar, sorted, ath_override);
 }
 void launch_fin_emit(const FinArgs& F, u64 n_solid, hipStream_t s) {
     if (n_solid) hipLaunchKernelGGL(fin_emit_kernel, dim3((unsigned)((n_solid + 255) / 256)), dim3(256), 0, s, F, n_solid);

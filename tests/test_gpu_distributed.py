@@ -172,3 +172,15 @@ def test_uneven_ranks_pipelined_rounds_gpu():
     [t.join() for t in th]
     assert not errs, errs
     check_against_oracle(out, reads, k, l, d, a)
+
+
+@pytest.mark.parametrize("mode", ["route", "replicate", "replicate-pipelined"])
+def test_abundance_wrap_in_the_multi_rank_modes(mode):
+    """k-min-mers seen > 65536 + A times (u16 abundance wraps in the reference): the partitioned tables must report the same
+    sighting as the sequential semantics — replicated mode re-scans the resident global sketch, routed mode its record arena"""
+    from test_gpu_parity import _repeat_reads
+    reads = _repeat_reads(31, 420, 190, 200)
+    k, l, d, a = 3, 8, 0.05, 2
+    parts = run(2, reads, k, l, d, a, batches_per_rank=2, mode=mode)
+    check_against_oracle(parts, reads, k, l, d, a)
+    assert sum(p["n_local"] for p in parts) == parts[0]["n_nodes"] >= 3

@@ -328,6 +328,32 @@ def test_concurrent_ingest_from_host_threads():
         assert_nodes_equal(got, exp)
 
 
+def _repeat_reads(seed, n_reads, unit_len, n_units):
+    rnd = random.Random(seed)
+    unit = bytes(rnd.choice(b"ACGT") for _ in range(unit_len))
+    reads = []
+    for r in range(n_reads):
+        a = rnd.randrange(unit_len)
+        reads.append((unit * (n_units + 2))[a:a + unit_len * n_units])
+    return reads
+
+
+@pytest.mark.parametrize("A", [1, 2, 3])
+def test_abundance_wrap_keeps_the_reference_sighting(A):
+    """k-min-mers seen more than 65536 + A times: the reference's u16 abundance wraps (release build) and the entry is
+    refreshed at every sighting whose previous abundance equals A - 1 (src/main.rs:676-684), so seqlen / shift / the sequence
+    origin are those of sighting A + 65536 * floor((count - A) / 65536), and the filter sees the wrapped abundance"""
+    reads = _repeat_reads(7 + A, 420, 190, 200)          # every k-min-mer of the unit occurs ~84,000 times
+    k, l, d = 3, 8, 0.05
+    exp = oracle_graph(reads, k, l, d, A)
+    got, st = run_gpu(reads, k, l, d, A, batches=[(0, 100), (100, 420)])
+    assert exp["n_nodes"] >= 3 and int(np.max(exp["abundance"])) < 65536
+    assert_nodes_equal(got, exp)
+    assert got["n_wrapped"] >= exp["n_nodes"] - 2          # (almost) every node of this input wrapped
+    # the wrapped sighting is NOT the A-th one: the origin lies far into the input
+    assert int(np.max(exp["src_read"])) > 200
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
