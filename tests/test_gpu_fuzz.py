@@ -137,3 +137,50 @@ def test_fuzz_edges_from_gpu_nodes(seed):
     pe = E.Emitter().edges(got, presimp=0.01)
     assert sorted(zip(pe["n1"].tolist(), pe["o1"].tolist(), pe["n2"].tolist(), pe["o2"].tolist(), pe["overlap"].tolist())) == exp_edges
     assert len(exp_edges) == exp["n_edges"] and pe["presimp_removed"] == exp["presimp_removed"]
+
+
+def long_read_case(seed):
+    """few long reads (spanning several 65,536-base tiles) with long homopolymers, N runs and low-complexity stretches: tile
+    boundaries, the halo, the warm-up replay (homopolymers longer than the halo / than 4096) and the generic-path hand-over"""
+    rnd = random.Random(seed)
+    l = rnd.choice([5, 8, 10, 12, 12, 14])
+    d = rnd.choice([0.002, 0.005, 0.02, 0.1])
+    k = rnd.choice([2, 4, 7, 21])
+    A = rnd.choice([1, 2, 3])
+    reads = []
+    for _ in range(rnd.randint(1, 6)):
+        s = bytearray()
+        target = rnd.choice([70000, 140000, 300000])
+        while len(s) < target:
+            r = rnd.random()
+            if r < 0.55:
+                s += bytes(rnd.choice(b"ACGT") for _ in range(rnd.randint(50, 20000)))
+            elif r < 0.75:
+                s += bytes([rnd.choice(b"ACGT")]) * rnd.choice([3, 40, 130, 300, 5000, 9000])        # homopolymer run
+            elif r < 0.85:
+                unit = bytes(rnd.choice(b"ACGT") for _ in range(rnd.randint(2, 6)))
+                s += unit * rnd.randint(10, 3000)                                                      # short tandem repeat
+            elif r < 0.95:
+                s += b"N" * rnd.choice([1, 2, 17, 500])
+            else:
+                s += bytes(rnd.choice(b"ACGT") for _ in range(rnd.randint(1, 30)))
+        reads.append(bytes(s))
+    rnd.shuffle(reads)
+    return dict(k=k, l=l, d=d, A=A, hpc=rnd.random() < 0.25, reads=reads)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_long_reads_across_tiles(seed):
+    R = _mdbg()
+    c = long_read_case(7000 + seed)
+    bases, offs = O.concat_reads(c["reads"])
+    exp_sk = O.sketch(bases, offs, c["l"], c["d"], already_hpc=c["hpc"])
+    assert exp_sk["err"] == 0
+    g = O.Graph(c["k"], c["l"], c["d"], c["A"], already_hpc=c["hpc"])
+    assert g.ingest(bases, offs) == 0
+    exp = g.finalize(with_edges=False)
+    with R.Mdbg(c["k"], c["l"], c["d"], c["A"], reads_already_hpc=c["hpc"]) as m:
+        assert_sketch_equal(m.sketch(bases, offs), exp_sk)
+        m.ingest(bases, offs, 0)
+        got = m.finalize()
+    assert_nodes_equal(got, exp)
