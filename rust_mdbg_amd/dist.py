@@ -475,12 +475,16 @@ class ReplicatedMdbg:
         self.e.reset()
 
     def ingest_device(self, d_bases, d_offsets, n_reads, n_bases, first_ordinal):
-        self.e.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
-        self._finish([self._share_begin(1, [])])
+        """one collective round; a rank that has no reads for it passes n_reads = 0"""
+        if n_reads:
+            self.e.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
+        self._finish([self._share_begin(1, [], have_batch=n_reads > 0)])
 
     def ingest_host(self, bases, offsets, first_ordinal):
-        self.e.sketch_host(bases, offsets, first_ordinal)
-        self._finish([self._share_begin(1, [])])
+        n_reads = len(offsets) - 1
+        if n_reads:
+            self.e.sketch_host(bases, offsets, first_ordinal)
+        self._finish([self._share_begin(1, [], have_batch=n_reads > 0)])
 
     def ingest_device_chunked(self, d_bases, offsets_dev, plan, first_ordinal):
         """One batch cut into chunks of whole reads (plan_chunks): while chunk c travels to the peers (RCCL send/recv
@@ -502,10 +506,11 @@ class ReplicatedMdbg:
         the same number of entries, None = no reads in that round"""
         pend = []
         for ch in chunks:
-            if ch is not None:
+            have = ch is not None and len(ch[1]) > 1
+            if have:
                 bases, offsets, first = ch
                 self._with_room(pend, lambda: self.e.sketch_host(bases, offsets, first))
-            pend.append(self._share_begin(len(chunks), pend, have_batch=ch is not None))
+            pend.append(self._share_begin(len(chunks), pend, have_batch=have))
         self._finish(pend)
 
     def _with_room(self, pend, fn):

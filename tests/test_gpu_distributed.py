@@ -19,6 +19,12 @@ def run(world, reads, k, l, d, a, batches_per_rank=2, mode="route"):
     tw = D.ThreadWorld(world)
     out, errs = [None] * world, []
     dev = torch.device("cuda", 0)
+    def share(rank):                          # reads [lo, hi) of a rank in steps of `step`
+        per = len(reads) // world
+        lo, hi = rank * per, (len(reads) if rank == world - 1 else (rank + 1) * per)
+        return lo, hi, max(1, (hi - lo + batches_per_rank - 1) // batches_per_rank)
+
+    n_rounds = max(len(range(*share(r))) for r in range(world))
 
     def body(rank):
         try:
@@ -26,10 +32,9 @@ def run(world, reads, k, l, d, a, batches_per_rank=2, mode="route"):
                 eng = D.GpuEngine(m, torch, dev)
                 comm = D.ThreadComm(tw, rank, torch)
                 drv = D.DistributedMdbg(eng, comm, torch) if mode == "route" else D.ReplicatedMdbg(eng, comm, torch)
-                per = len(reads) // world
-                lo, hi = rank * per, (len(reads) if rank == world - 1 else (rank + 1) * per)
-                step = (hi - lo + batches_per_rank - 1) // batches_per_rank
+                lo, hi, step = share(rank)
                 chunks = [O.concat_reads(reads[s:min(hi, s + step)]) + (s,) for s in range(lo, hi, step)]
+                chunks += [O.concat_reads([]) + (hi,)] * (n_rounds - len(chunks))      # every rank takes part in every round
                 if mode.startswith("replicate-pipelined"):
                     # all chunks in flight into reserved regions of the peers' sketch stores (mdbg_sketch_reserve / _commit);
                     # "-nosize": the store is NOT sized up front, so it has to grow mid-flight -> drain-and-retry path
