@@ -189,3 +189,20 @@ def test_abundance_wrap_in_the_multi_rank_modes(mode):
     parts = run(2, reads, k, l, d, a, batches_per_rank=2, mode=mode)
     check_against_oracle(parts, reads, k, l, d, a)
     assert sum(p["n_local"] for p in parts) == parts[0]["n_nodes"] >= 3
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_multi_rank_modes(seed):
+    """random parameters x random read sets x random world size / mode / batching (uneven ranks, empty rounds, read sets
+    without a single window included) against the oracle"""
+    import random
+    from test_gpu_fuzz import fuzz_reads
+    rnd = random.Random(9000 + seed)
+    k, l, d, a = rnd.choice([(2, 8, 0.03, 1), (3, 8, 0.05, 2), (5, 10, 0.01, 2), (7, 12, 0.008, 3), (21, 12, 0.004, 2), (4, 6, 0.05, 8)])
+    reads = fuzz_reads(rnd, n_reads=rnd.randint(12, 150), genome_len=rnd.choice([300, 5000, 40000]), mean_len=rnd.choice([40, 400, 4000]),
+                       err=rnd.choice([0.0, 0.02]), p_lower=0.0, p_n=rnd.choice([0.0, 0.2]), p_hp=rnd.choice([0.0, 0.02]))
+    reads = [r.replace(b"n", b"N") for r in reads]
+    world = rnd.choice([1, 2, 3, 5])
+    mode = rnd.choice(["route", "replicate", "replicate-pipelined", "replicate-pipelined-nosize"])
+    parts = run(world, reads, k, l, d, a, batches_per_rank=rnd.choice([1, 2, 3]), mode=mode)
+    check_against_oracle(parts, reads, k, l, d, a)
