@@ -184,3 +184,31 @@ def test_fuzz_long_reads_across_tiles(seed):
         m.ingest(bases, offs, 0)
         got = m.finalize()
     assert_nodes_equal(got, exp)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_fuzz_multik_on_resident_sketches(seed):
+    """mdbg_reset(k) sequences on the resident sketches == a fresh oracle run per k (also after a wrapped-abundance k and
+    with batches ingested between the resets)"""
+    R = _mdbg()
+    rnd = random.Random(4000 + seed)
+    l = rnd.choice([5, 8, 10, 12])
+    d = rnd.choice([0.01, 0.05, 0.2])
+    A = rnd.choice([1, 2, 3])
+    reads = fuzz_reads(rnd, n_reads=rnd.randint(20, 120), genome_len=rnd.choice([500, 5000, 40000]), mean_len=rnd.choice([400, 3000]),
+                       err=rnd.choice([0.0, 0.02]), p_lower=0.0, p_n=0.0, p_hp=rnd.choice([0.0, 0.02]))
+    cut = len(reads) // 2
+    ks = [rnd.choice([2, 3, 5, 9, 21, 40]) for _ in range(4)]
+    with R.Mdbg(ks[0], l, d, A) as m:
+        m.ingest_reads(reads[:cut], 0)
+        for step, k in enumerate(ks):
+            if step:
+                m.reset(k)
+            if step == 2:
+                m.ingest_reads(reads[cut:], cut)        # more reads arrive between two values of k
+            got = m.finalize()
+            sub = reads if step >= 2 else reads[:cut]
+            assert_nodes_equal(got, oracle_graph(sub, k, l, d, A))
+
+
+from test_gpu_parity import oracle_graph  # noqa: E402
