@@ -354,6 +354,20 @@ def test_abundance_wrap_keeps_the_reference_sighting(A):
     assert int(np.max(exp["src_read"])) > 200
 
 
+def test_sparse_density_shift_truncates_to_u16():
+    """minimizers more than 65535 bases apart: DbgEntry.shift is stored as u16 (src/main.rs:675) while the .sequences line
+    prints the un-truncated value (main.rs:702)"""
+    reads = rand_reads(77, 6, 900000, 1200000)
+    reads += [reads[0][1000:], reads[1][:-500]]
+    k, l, d, A = 2, 12, 0.00002, 1
+    exp = oracle_graph(reads, k, l, d, A)
+    got, st = run_gpu(reads, k, l, d, A)
+    assert_nodes_equal(got, exp)
+    sf = np.asarray(exp["shift_full"]).reshape(-1, 2)
+    assert exp["n_nodes"] > 20 and int(sf.max()) > 65535
+    assert np.array_equal(np.asarray(got["shift"]).reshape(-1, 2), (sf & 0xFFFF).astype(np.uint16))
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
