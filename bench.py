@@ -206,6 +206,12 @@ def main():
                     "launches_per_step": st["n_sketch_tile_launches"], "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_base": 1.0 + 12.0 * mins_per_base,
                     "kernel_gbases_per_s": st["n_sketch_tile_bases"] / (st["ms_sketch_tile"] * 1e-3) / 1e9}
+        edges = None
+        if not routed:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
+            m.graph_edges_device(0.01)
+            t1 = time.perf_counter()
+            e = m.graph_edges_device(0.01)
+            edges = {"ms": (time.perf_counter() - t1) * 1e3, "n_edges": int(e.n), "presimp_removed": int(e.presimp_removed)}
         cpu = None
         if args.cpu_seconds > 0:
             cpu = cpu_baseline(m, d_bases, d_off, reads_per_gpu, n_bases, args)
@@ -219,7 +225,8 @@ def main():
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_tile_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
-                         "partitions_add_up": consistent}}
+                         "partitions_add_up": consistent},
+               "edges_after_timed_region": edges}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     if routed and engine.tm is not m:
