@@ -235,13 +235,20 @@ int mdbg_ingest_sketch(mdbg_ctx* ctx, const uint64_t* d_hashes, const uint32_t* 
  *                        n_reads reads; d_read_offsets are relative to `region` ([0] = 0, [n_reads] = n_minimizers, checked
  *                        on the device: a violation is reported as MDBG_E_PARAM by the next mdbg_insert_resident).  The
  *                        call is stream-ordered: the offsets buffer must stay alive until the next synchronising call.
+ *                        owned_windows: see mdbg_owner_counts.
  *   mdbg_last_batch      describes the batch registered last (e.g. the one mdbg_sketch_device just produced), with DEVICE
  *                        pointers to its part of the store: what a rank sends to its peers.  Synchronises the context's
  *                        stream, so the arrays may be read from any other stream afterwards. */
 int mdbg_store_reserve(mdbg_ctx* ctx, uint64_t n_minimizers_total, uint64_t n_reads_total);
 int mdbg_sketch_reserve(mdbg_ctx* ctx, uint64_t n_minimizers, uint64_t** d_hashes, uint32_t** d_positions, uint64_t* region);
 int mdbg_sketch_commit(mdbg_ctx* ctx, uint64_t region, uint64_t n_minimizers, const uint64_t* d_read_offsets, uint64_t n_reads,
-                       uint64_t first_read_ordinal);
+                       uint64_t first_read_ordinal, uint64_t owned_windows);
+/* Windows of the batch registered last, counted per owning rank (counts[world], HOST): computed once by the rank that
+ * sketched the batch and shipped with it (mdbg_sketch_commit's owned_windows = counts[receiver]; UINT64_MAX = unknown), so
+ * that the receivers size their tables without re-counting a foreign sketch.  When world equals this context's partition,
+ * the call also records the context's own share for its own batch.  The counts are verified against what is actually
+ * inserted (MDBG_E_PARAM from mdbg_insert_resident on a mismatch). */
+int mdbg_owner_counts(mdbg_ctx* ctx, uint32_t world, uint64_t* counts);
 typedef struct mdbg_batch_info {
     uint64_t store_offset, n_minimizers, first_slot, n_reads, first_read_ordinal;
     const uint64_t* d_hashes;        /* [n_minimizers] */

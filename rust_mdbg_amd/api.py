@@ -75,7 +75,7 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
-           "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_graph_edges", "mdbg_graph_edges_device"]
+           "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device"]
 
 
 def lib_path():
@@ -129,7 +129,8 @@ def load_library():
     L.mdbg_ingest_sketch.argtypes = [vp, vp, vp, vp, u64, u64]
     L.mdbg_store_reserve.argtypes = [vp, u64, u64]
     L.mdbg_sketch_reserve.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
-    L.mdbg_sketch_commit.argtypes = [vp, u64, u64, vp, u64, u64]
+    L.mdbg_sketch_commit.argtypes = [vp, u64, u64, vp, u64, u64, u64]
+    L.mdbg_owner_counts.argtypes = [vp, u32, vp]
     L.mdbg_last_batch.argtypes = [vp, C.POINTER(BatchInfo)]
     L.mdbg_graph_edges.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
     L.mdbg_graph_edges_device.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
@@ -309,8 +310,16 @@ class Mdbg:
         self._chk(self.L.mdbg_sketch_reserve(self.h, n_minimizers, C.byref(h), C.byref(p), C.byref(r)))
         return h.value or 0, p.value or 0, r.value
 
-    def sketch_commit(self, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal):
-        self._chk(self.L.mdbg_sketch_commit(self.h, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal))
+    def sketch_commit(self, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal, owned_windows=None):
+        """owned_windows: number of windows of this batch the context owns (from the sender's owner_counts), None = unknown"""
+        ow = 0xFFFFFFFFFFFFFFFF if owned_windows is None else int(owned_windows)
+        self._chk(self.L.mdbg_sketch_commit(self.h, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal, ow))
+
+    def owner_counts(self, world):
+        """windows of the batch registered last per owning rank -> list of `world` ints"""
+        out = (C.c_uint64 * world)()
+        self._chk(self.L.mdbg_owner_counts(self.h, world, out))
+        return [int(x) for x in out]
 
     def last_batch(self):
         b = BatchInfo()

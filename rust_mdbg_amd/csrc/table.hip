@@ -81,6 +81,8 @@ struct TableArgs {
     u64* n_distinct;              // device counter
     KeySrc ks;
     u32 own_world, own_rank;      // replicated-sketch mode: insert only windows owned by own_rank (own_world <= 1: all)
+    u32* probe_err;               // set when a probe sequence visited every slot: the table was sized from a wrong window count
+    u64* own_inserted;            // sharded counter: owned windows actually inserted (checked against the senders' counts)
 };
 
 // Home slot of a key hash: range reduction by multiplication, so the capacity need not be a power of two.  It is fed
@@ -110,7 +112,7 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, EqFn
     const u64 fp = (h >> 34) & 0x3FFFFFFFull;
     const u64 myword = (fp << 34) | myword_lo;
     u64 s = home_slot(h, T.cap);
-    for (;;) {
+    for (u64 probes = 0; probes <= T.cap; ++probes) {
         u64 w = load_relaxed(&T.tab[s].word);
         if (w == EMPTY) {
             const u64 old = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)myword);
@@ -120,6 +122,8 @@ __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, EqFn
         if ((w >> 34) == fp && same_key(w)) return s;
         s = s + 1 == T.cap ? 0 : s + 1;
     }
+    *T.probe_err = 1;                          // table full: cannot happen when it was sized from the true number of windows
+    return ~0ull;
 }
 // comparison of a key given as a contiguous run wl[0..k) (a window staged in LDS with orientation rev_mine, or a routed
 // record's canonical key) with the representative in HBM: both are
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     const u64 h = key_hash_window(w, k, rev);
     bool claimed;
     const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
-    if (claimed) return;                       // the claimer is accounted for through `rep` (slot_view)
+    if (claimed || s == ~0ull) return;         // the claimer is accounted for through `rep` (slot_view)
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
 }
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(256) void insert_owned_windows_kernel(TableArgs T, 
     }
     __syncthreads();
     const u32 n = *n_own;
+    if (threadIdx.x == 0 && n) atomicAdd((unsigned long long*)ctr_shard(T.own_inserted), (unsigned long long)n);
     for (u32 j = threadIdx.x; j < n; j += 256) {
         const u32 li = list[j];
         const u64 i = b0 + li;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void insert_owned_windows_kernel(TableArgs T, 
         const u64 h = key_hash_window(w, k, rev);
         bool claimed;
         const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
-        if (claimed) continue;
+        if (claimed || s == ~0ull) continue;
         atomicAdd(&T.tab[s].count, 1u);
         push_ordinal(T, s, ord);
     }
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0
     const u64 h = key[k + 1];                  // computed by the sender (route_count_kernel)
     bool claimed;
     const u64 s = upsert_slot(T, h, (1ull << 33) | (u64)(u32)r, [&](u64 word) { return same_key_window(T.ks, word, key, false); }, claimed);   // record keys are canonical
-    if (claimed) return;
+    if (claimed || s == ~0ull) return;
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, key[k]);
     (void)n_windows;
@@ -479,6 +484,26 @@ __global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __r
     for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd((unsigned long long*)ctr_shard(out), (unsigned long long)mine);
 }
+// per-owner window counts of a batch (what a rank tells its peers, so that nobody has to re-count a foreign sketch)
+__global__ __launch_bounds__(256) void owner_hist_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
+                                                         u32 k, u32 world, u64* __restrict__ counts) {
+    extern __shared__ u32 hist[];
+    for (u32 t = threadIdx.x; t < world; t += 256) hist[t] = 0;
+    __syncthreads();
+    constexpr int WPT = 4;
+    const u64 b0 = i0 + (u64)blockIdx.x * (256 * WPT);
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const u64 i = b0 + u * 256 + threadIdx.x;
+        if (i < i1) {
+            const u32 slot = mread[i];
+            const u64 rs = roff[slot], re = roff[slot + 1];
+            if (re - rs > k && i + k <= re) atomicAdd(&hist[window_owner(mh + i, k, world)], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 t = threadIdx.x; t < world; t += 256) if (hist[t]) atomicAdd((unsigned long long*)&counts[t], (unsigned long long)hist[t]);
+}
 __global__ __launch_bounds__(1024) void count_windows_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32 k, u64* __restrict__ out) {
     __shared__ u64 ws[16];
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,6 +676,9 @@ void launch_popc_prefix(const u64* bm, u64 n_words, u32* block_tmp, u32* pre, hi
 }
 void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32 rank, u64* out_shards, hipStream_t s) {
     if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, rank, out_shards);
+}
+void launch_owner_hist(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u64* counts, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_hist_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), world * sizeof(u32), s, mh, mread, roff, i0, i1, k, world, counts);
 }
 void launch_fill_mread(const u64* roff, u32 slot0, u32 n_reads, u32* mread, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(fill_mread_kernel, dim3((n_reads + 3) / 4), dim3(256), 0, s, roff, slot0, n_reads, mread);

@@ -246,11 +246,14 @@ class GpuEngine:
             o += m
         return out
 
-    def commit_import(self, token, rel_off, first_ordinal):
+    def owner_counts(self, world):
+        return self.m.owner_counts(world)
+
+    def commit_import(self, token, rel_off, first_ordinal, owned=None):
         rel_off = rel_off.contiguous()
         self._keep = getattr(self, "_keep", [])
         self._keep.append(rel_off)             # the call is stream-ordered: keep the offsets alive until insert_owned()
-        self.m.sketch_commit(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal)
+        self.m.sketch_commit(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal, owned)
 
     def insert_owned(self):
         self.m.insert_resident()
@@ -533,7 +536,10 @@ class ReplicatedMdbg:
             dev = getattr(e, "device", None)
             h, p, off, first, n = (t.empty(0, dtype=t.int64, device=dev), t.empty(0, dtype=t.int32, device=dev),
                                    t.zeros(1, dtype=t.int64, device=dev), 0, 0)
-        meta = c.allgather_i64([h.shape[0], n, first])
+        # every rank counts the windows of its own batch per owner once and ships the counts with the sizes, so that no
+        # rank has to re-count a foreign sketch to size its table
+        counts = e.owner_counts(c.world) if (have_batch and c.world > 1 and hasattr(e, "owner_counts")) else None
+        meta = c.allgather_i64([h.shape[0], n, first, 0 if counts is None and n else 1] + (counts if counts is not None else [0] * c.world))
         peers = [r for r in range(c.world) if r != c.rank]
         if not peers:
             return None
@@ -547,14 +553,17 @@ class ReplicatedMdbg:
         bufs = self._with_room(pend, lambda: e.reserve_import([int(meta[r][0]) for r in peers]))
         offs = [t.empty(int(meta[r][1]) + 1, dtype=t.int64, device=off.device) for r in peers]
         handle = c.exchange([(r, [h, p, off]) for r in peers], [(r, [bufs[i][0], bufs[i][1], offs[i]]) for i, r in enumerate(peers)])
-        return handle, [(bufs[i][2], offs[i], int(meta[r][2])) for i, r in enumerate(peers)]
+        return handle, [(bufs[i][2], offs[i], int(meta[r][2]), int(meta[r][4 + c.rank]) if meta[r][3] else None) for i, r in enumerate(peers)]
 
     def _drain(self, pend):
         for item in pend:
             if item is not None and item[0] is not None:
                 item[0].wait()
-                for token, off, first in item[1]:
-                    self.e.commit_import(token, off, first)
+                for token, off, first, owned in item[1]:
+                    if owned is None:
+                        self.e.commit_import(token, off, first)
+                    else:
+                        self.e.commit_import(token, off, first, owned)
         pend[:] = []
 
     def _finish(self, pend):

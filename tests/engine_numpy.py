@@ -117,7 +117,7 @@ class NumpyEngine:
             out.append((h, p, (h, p)))           # the token of this engine is simply the pair of receive buffers
         return out
 
-    def commit_import(self, token, rel_off, first_ordinal):
+    def commit_import(self, token, rel_off, first_ordinal, owned=None):
         self.ingest_sketch(token[0], token[1], rel_off, first_ordinal)
 
     @staticmethod

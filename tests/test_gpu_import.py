@@ -104,3 +104,53 @@ def test_copying_import_sketch_view_ingest_sketch():
     g = O.Graph(k, l, d, a)
     assert g.ingest(bb, oo) == 0
     assert_nodes_equal(got, g.finalize(with_edges=False))
+
+
+def test_owner_counts_are_used_and_verified():
+    """mdbg_owner_counts: the sender's per-owner window counts size the receivers' tables without a re-count; a count that
+    does not match the imported sketch is reported by the insertion, not silently accepted"""
+    import torch
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import dist as D
+    dev = torch.device("cuda", 0)
+    k, l, d, a = 5, 12, 0.006, 2
+    base = rand_reads(61, 40, 3000, 9000)
+    reads = base + [r[50:] for r in base[:30]]
+    bb, oo = O.concat_reads(reads)
+    for wrong in (False, True):
+        with R.Mdbg(k, l, d, a, device=0) as src, R.Mdbg(k, l, d, a, device=0) as d0, R.Mdbg(k, l, d, a, device=0) as d1:
+            es = D.GpuEngine(src, torch, dev)
+            es.sketch_host(bb, oo, 0)
+            counts = src.owner_counts(2)
+            assert len(counts) == 2 and min(counts) > 0
+            h, p, off, first, n = es.last_sketch()
+            parts = []
+            for rank, dst in enumerate((d0, d1)):
+                dst.set_partition(2, rank)
+                ed = D.GpuEngine(dst, torch, dev)
+                (hv, pv, token), = ed.reserve_import([h.shape[0]])
+                hv.copy_(h); pv.copy_(p)
+                torch.cuda.synchronize()
+                ed.commit_import(token, off.clone(), first, counts[rank] + (7 if wrong and rank == 1 else 0))
+                if wrong and rank == 1:
+                    with pytest.raises(R.MdbgError) as ei:
+                        ed.insert_owned()
+                    assert ei.value.code == -1
+                    continue
+                ed.insert_owned()
+                assert dst.stats()["n_windows"] == counts[rank]
+                bf, bs = ed.finalize_begin()
+                parts.append((ed, bf, bs))
+            if wrong:
+                continue
+            tot_f, tot_s = parts[0][1] + parts[1][1], parts[0][2] + parts[1][2]      # the driver's all-reduce
+            for ed, bf, bs in parts:
+                bf.copy_(tot_f); bs.copy_(tot_s)
+            torch.cuda.synchronize()
+            outs = [ed.finalize_end() for ed, _, _ in parts]
+            tab = D.gather_node_table([{f: (v.cpu().numpy().view(np.uint64) if hasattr(v, "cpu") else v) for f, v in o.items()} for o in outs])
+        g = O.Graph(k, l, d, a)
+        assert g.ingest(bb, oo) == 0
+        exp = g.finalize(with_edges=False)
+        assert tab["n_nodes"] == exp["n_nodes"] > 20 and np.array_equal(tab["keys"], exp["keys"])
+        assert np.array_equal(tab["abundance"].astype(np.uint64), exp["abundance"].astype(np.uint64))
