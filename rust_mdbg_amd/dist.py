@@ -134,13 +134,17 @@ class ThreadComm:
         offs = [0]
         for c in counts:
             offs.append(offs[-1] + int(c))
-        allv = self._exchange((send, offs))
+        allv = self._exchange_keep((send, offs))          # the senders' buffers (views of their engines' memory) stay untouched ...
         parts, rc = [], []
         for src in range(self.world):
             s, o = allv[src]
             parts.append(s[o[self.rank]:o[self.rank + 1]])
             rc.append(o[self.rank + 1] - o[self.rank])
-        return t.cat(parts, 0).clone(), rc
+        out = t.cat(parts, 0).clone()
+        if out.is_cuda:
+            t.cuda.current_stream().synchronize()
+        self.tw.barrier.wait()                           # ... until every receiver has finished copying
+        return out, rc
 
     def allgather_obj(self, obj):
         return self._exchange(obj)
