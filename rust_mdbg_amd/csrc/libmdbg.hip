@@ -1,4 +1,4 @@
-// libmdbg.hip — single translation unit of libmdbg_hip.so (gfx950).
+// libmdbg.hip — main translation unit of libmdbg_hip.so (gfx950); edges.hip (rocPRIM sort / scans) is compiled separately.
 #include "sketch.hip"
 #include "table.hip"
 #include "synth.hip"
