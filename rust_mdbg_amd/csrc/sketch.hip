@@ -510,6 +510,29 @@ __global__ void read_offsets_kernel(const u32* __restrict__ mread, u64 m0, u64 m
 }
 __global__ void acc_slow_kernel(const u32* __restrict__ slow_count, u64* __restrict__ slow_total) { *slow_total += *slow_count; }
 
+// Error path only (a byte outside ACGTN was seen somewhere in the batch): the reference's exact rule — nthash panics iff a
+// read whose HPC string has at least l bases holds such a byte (src/read.rs:157-174 decides the length).  One wave per
+// read; *which = smallest offending read index (~0: none).
+__global__ __launch_bounds__(256) void alphabet_rule_kernel(const u8* __restrict__ bases, const u64* __restrict__ off, u32 n_reads, u32 l, u32 hpc,
+                                                            unsigned long long* __restrict__ which) {
+    const u32 r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const u32 lane = threadIdx.x & 63;
+    const u64 a = off[r], b = off[r + 1];
+    u64 kept = 0; bool bad = false;
+    for (u64 p = a + lane; p < b; p += 64) {
+        const u8 c = bases[p];
+        bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N');
+        if (!hpc || p == a || !(c == bases[p - 1] && in_hpc_set(c))) ++kept;
+    }
+    for (int d = 32; d; d >>= 1) kept += __shfl_down(kept, d, 64);
+    const bool any_bad = __ballot(bad) != 0;
+    if (lane == 0 && any_bad && kept >= l) atomicMin(which, (unsigned long long)r);
+}
+void launch_alphabet_rule(const u8* bases, const u64* off, u32 n_reads, u32 l, bool hpc, unsigned long long* which, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(alphabet_rule_kernel, dim3((n_reads + 3) / 4), dim3(256), 0, s, bases, off, n_reads, l, hpc ? 1u : 0u, which);
+}
+
 // ---- host launchers -------------------------------------------------------------------------------
 struct SketchLaunch {
     const u8* bases; u64 n_bases; const u64* offsets; u32 n_reads;
