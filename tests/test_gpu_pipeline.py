@@ -56,3 +56,24 @@ def test_multik_from_one_pass(example_reads, tmp_path):
         assert [x for x in lines if x.startswith("S")] == ["S\t%d\t*\tLN:i:%d\tKC:i:%d" % (r["index"][i], r["seqlen"][i], r["abundance"][i]) for i in range(r["n_nodes"])]
         assert sorted(x for x in lines if x.startswith("L")) == sorted("L\t%d\t%s\t%d\t%s\t%dM" % (x, chr(p), y, chr(q), ov) for x, p, y, q, ov in oracle_edges(r))
     assert out[7]["n_nodes"] == 104 and out[5]["n_nodes"] > out[12]["n_nodes"]
+
+
+def test_plain_c_program_over_the_two_abis(example_reads, tmp_path):
+    """examples/mdbg_cli.c (gcc, no Python, no torch): reads-0.00.fa.gz -> .gfa / .sequences through include/mdbg_hip.h and
+    include/mdbg_emit.h exactly as a foreign host would call them; output identical to the Python pipeline's"""
+    import subprocess
+    from conftest import ROOT
+    from rust_mdbg_amd import pipeline
+    exe = str(tmp_path / "mdbg_cli")
+    lib = os.path.join(ROOT, "rust_mdbg_amd")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "mdbg_cli.c"), "-L" + lib, "-lmdbg_hip", "-lmdbg_emit",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+    src = os.path.join(GOLDEN, "reads-0.00.fa.gz")
+    r = subprocess.run([exe, src, "-k", "7", "-l", "10", "--density", "0.0008", "--minabund", "2", "--prefix", str(tmp_path / "c")],
+                       check=True, capture_output=True, text=True)
+    assert "Number of nodes after abundance filter: 104" in r.stdout and "Number of mdBG edges: 206" in r.stdout
+    pipeline.run_file(src, str(tmp_path / "py"), 7, 10, 0.0008, 2)
+    assert open(str(tmp_path / "c.gfa")).read() == open(str(tmp_path / "py.gfa")).read()
+    assert read_lz4_frame(str(tmp_path / "c.0.sequences")) == read_lz4_frame(str(tmp_path / "py.0.sequences"))
+    bad = subprocess.run([exe, src, "-k", "1"], capture_output=True, text=True)            # errors are codes + text, not aborts
+    assert bad.returncode == 1 and "invalid parameter" in bad.stderr
