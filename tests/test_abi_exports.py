@@ -57,3 +57,14 @@ def test_create_without_gpu_fails_cleanly():
     with pytest.raises(R.MdbgError) as e:
         R.Mdbg(1, 12, 0.01)
     assert e.value.code == -1
+
+
+def test_headers_are_plain_c_and_the_example_links(tmp_path):
+    """include/*.h must be usable from C (the drop-in boundary is a C ABI): the plain-C example host compiles with gcc -std=c99
+    and links against the two libraries (running it needs a GPU: tests/test_gpu_pipeline.py)"""
+    import subprocess
+    lib = os.path.join(ROOT, "rust_mdbg_amd")
+    exe = str(tmp_path / "mdbg_cli")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "mdbg_cli.c"), "-L" + lib, "-lmdbg_hip", "-lmdbg_emit", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    assert os.path.exists(exe)
