@@ -206,3 +206,41 @@ def test_fuzz_multi_rank_modes(seed):
     mode = rnd.choice(["route", "replicate", "replicate-pipelined", "replicate-pipelined-nosize"])
     parts = run(world, reads, k, l, d, a, batches_per_rank=rnd.choice([1, 2, 3]), mode=mode)
     check_against_oracle(parts, reads, k, l, d, a)
+
+
+def test_replicated_multik_on_resident_global_sketch():
+    """mdbg_reset(k) on every rank of the replicated-sketch mode: the global sketch is resident everywhere, so a new k needs no
+    exchange at all (the owner counts shipped with the sketches were for the old k and must not be trusted again)"""
+    import torch
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import dist as D, synth
+    reads = synth.synth_reads(9, 120000, 150, mean_len=9000, sd_len=2000, min_len=2000, max_len=15000, err_ppm=1500)
+    l, d, a = 12, 0.004, 2
+    world = 2
+    tw = D.ThreadWorld(world)
+    out, errs = {}, []
+    dev = torch.device("cuda", 0)
+
+    def body(r):
+        try:
+            with R.Mdbg(6, l, d, a, device=0) as m:
+                eng = D.GpuEngine(m, torch, dev)
+                drv = D.ReplicatedMdbg(eng, D.ThreadComm(tw, r, torch), torch)
+                per = len(reads) // world
+                lo, hi = r * per, (len(reads) if r == world - 1 else (r + 1) * per)
+                drv.ingest_host_chunks([O.concat_reads(reads[lo:(lo + hi) // 2]) + (lo,), O.concat_reads(reads[(lo + hi) // 2:hi]) + ((lo + hi) // 2,)])
+                for k in (6, 9, 4):
+                    if k != 6:
+                        m.reset(k)
+                    part = drv.finalize()
+                    out[(k, r)] = {f: (v.cpu() if hasattr(v, "cpu") else v) for f, v in part.items()}
+        except BaseException as e:           # noqa: BLE001
+            errs.append(e)
+            tw.barrier.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k in (6, 9, 4):
+        check_against_oracle([out[(k, r)] for r in range(world)], reads, k, l, d, a)
