@@ -368,6 +368,28 @@ def test_sparse_density_shift_truncates_to_u16():
     assert np.array_equal(np.asarray(got["shift"]).reshape(-1, 2), (sf & 0xFFFF).astype(np.uint16))
 
 
+def test_finalize_is_repeatable_and_incremental():
+    """finalize, ingest more, finalize again (no reset): the second table is that of all reads; finalize twice in a row
+    gives the same table; table growth / rehash happens in between (tiny capacity hint)"""
+    reads = rand_reads(91, 120, 2000, 9000)
+    reads += [r[30:] for r in reads[:80]]
+    k, l, d, A = 5, 12, 0.006, 2
+    R = _mdbg()
+    with R.Mdbg(k, l, d, A, table_capacity_hint=16) as m:
+        m.ingest_reads(reads[:60], 0)
+        first = m.finalize()
+        assert_nodes_equal(first, oracle_graph(reads[:60], k, l, d, A))
+        assert_nodes_equal(m.finalize(), first)
+        m.ingest_reads(reads[60:150], 60)
+        m.ingest_reads(reads[150:], 150)
+        got = m.finalize()
+        e1 = m.graph_edges(0.01)
+        assert_nodes_equal(m.finalize(), got)
+        e2 = m.graph_edges(0.01)
+    assert_nodes_equal(got, oracle_graph(reads, k, l, d, A))
+    assert all(np.array_equal(e1[f], e2[f]) for f in ("n1", "o1", "n2", "o2", "overlap"))
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
