@@ -390,6 +390,25 @@ def test_finalize_is_repeatable_and_incremental():
     assert all(np.array_equal(e1[f], e2[f]) for f in ("n1", "o1", "n2", "o2", "overlap"))
 
 
+@pytest.mark.parametrize("k", [300, 1000, 4096])
+def test_large_k(k):
+    """large k: dynamic LDS of the insert kernels (256 + k keys), the overlapping 8-value compare rounds, edges over long keys"""
+    from rust_mdbg_amd import emit as E
+    base = rand_reads(500 + k, 6, 60000, 90000)
+    reads = base + [r[200:] for r in base] + [base[0][:30000]]
+    l, d, A = 10, 0.05, 2
+    exp = oracle_graph(reads, k, l, d, A)
+    R = _mdbg()
+    with R.Mdbg(k, l, d, A) as m:
+        m.ingest_reads(reads, 0)
+        got = m.finalize()
+        ge = m.graph_edges(0.01)
+    assert_nodes_equal(got, exp)
+    assert exp["n_nodes"] > 100
+    he = E.Emitter().edges(got, 0.01)
+    assert all(np.array_equal(ge[f], he[f]) for f in ("n1", "o1", "n2", "o2", "overlap")) and len(ge["n1"]) > 100
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
