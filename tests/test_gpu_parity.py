@@ -409,6 +409,23 @@ def test_large_k(k):
     assert all(np.array_equal(ge[f], he[f]) for f in ("n1", "o1", "n2", "o2", "overlap")) and len(ge["n1"]) > 100
 
 
+@pytest.mark.parametrize("d", [0.0, 1e-30, 0.999999, 1.0, 1.5, 7.0])
+def test_density_extremes(d):
+    """hash_bound = floor(d * 2^64) saturates like the reference's `as u64` cast (src/read.rs:183): d = 0 selects (almost) nothing,
+    d >= 1 selects every l-mer"""
+    reads = rand_reads(3, 12, 500, 3000)
+    k, l, A = 3, 9, 1
+    b, o = O.concat_reads(reads)
+    exp_sk = O.sketch(b, o, l, d)
+    R = _mdbg()
+    with R.Mdbg(k, l, d, A) as m:
+        assert_sketch_equal(m.sketch(b, o), exp_sk)
+        m.ingest(b, o, 0)
+        got = m.finalize()
+    assert_nodes_equal(got, oracle_graph(reads, k, l, d, A))
+    assert (int(exp_sk["off"][-1]) == 0) == (d < 1e-20)
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
