@@ -426,6 +426,30 @@ def test_density_extremes(d):
     assert (int(exp_sk["off"][-1]) == 0) == (d < 1e-20)
 
 
+def test_large_and_sparse_read_ordinals():
+    """read ordinals are caller-defined (position of the record in the input): huge values and gaps between batches are fine,
+    the order of first sightings follows the ordinals, not the call order"""
+    reads = rand_reads(17, 60, 2000, 6000)
+    reads += [r[10:] for r in reads[:40]]
+    k, l, d, A = 4, 12, 0.006, 2
+    cuts = [(0, 30, (1 << 37) + 5), (30, 70, 12), (70, 100, (1 << 37) + 1000)]          # (lo, hi, first ordinal): the middle batch comes FIRST in ordinal order
+    g = O.Graph(k, l, d, A)
+    for lo, hi, first in sorted(cuts, key=lambda c: c[2]):
+        b, o = O.concat_reads(reads[lo:hi])
+        assert g.ingest(b, o, first) == 0
+    exp = g.finalize(with_edges=False)
+    R = _mdbg()
+    with R.Mdbg(k, l, d, A) as m:
+        for lo, hi, first in cuts:
+            m.ingest_reads(reads[lo:hi], first)
+        got = m.finalize()
+        with pytest.raises(R.MdbgError) as ei:
+            m.ingest_reads(reads[:2], 1 << 38)                      # ordinal << 26 must fit in 64 bits
+        assert ei.value.code == -3
+    assert_nodes_equal(got, exp)
+    assert int(got["src_read"].max()) > (1 << 37) and exp["n_nodes"] > 500
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
