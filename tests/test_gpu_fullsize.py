@@ -163,3 +163,24 @@ def test_config3_size_replicated_chunked_equals_local():
     assert np.array_equal(tab["keys"], loc["keys"])
     for f in ("index", "abundance", "seqlen", "reversed", "src_read", "src_start", "src_end"):
         assert np.array_equal(tab[f].astype(np.uint64), loc[f].astype(np.uint64)), f
+
+
+def test_chromosome_scale_reads():
+    """reference-genome-like input (--reference use case): a few reads of tens of megabases each, spanning hundreds of tiles"""
+    import rust_mdbg_amd as R
+    rng = np.random.default_rng(5)
+    chrom = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=24_000_000).tobytes()
+    reads = [chrom, chrom[5_000_000:17_000_000], b"ACGT" * 10, chrom[::-1][:3_000_000]]
+    k, l, d, a = 21, 12, 0.003, 2
+    bases, offs = O.concat_reads(reads)
+    g = O.Graph(k, l, d, a)
+    assert g.ingest(bases, offs) == 0
+    exp = g.finalize(with_edges=False)
+    with R.Mdbg(k, l, d, a) as m:
+        m.ingest(bases, offs, 0)
+        got = m.finalize()
+        st = m.stats()
+    assert exp["n_nodes"] > 50000 and st["n_tiles"] > 500
+    assert got["n_nodes"] == exp["n_nodes"] and got["n_nodes_before"] == exp["n_nodes_before"]
+    for f in FIELDS:
+        assert np.array_equal(got[f], exp[f]), f
