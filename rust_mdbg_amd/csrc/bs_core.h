@@ -1,0 +1,239 @@
+// bs_core.h — bit-sliced building blocks of the sketch kernel (gfx950), written so that the same source also
+// compiles as plain host C++: tests/emu/ runs these functions on the CPU, lane by lane, against the oracle
+// (test infrastructure only; the product never executes them on the host).
+//
+// Representation.  A raw or homopolymer-compressed ("dense") base stream is held as TWO BIT PLANES, 32 positions
+// per 32-bit word, MSB FIRST: position 32*w + i lives in bit (31 - i) of word w.  Plane 0 = bit 0 of the 2-bit
+// code, plane 1 = bit 1; code = (ascii >> 1) & 3, i.e. A=0 C=1 T=2 G=3 (complement = code ^ 2).
+// MSB-first makes every "look back by u positions" a right funnel shift (one v_alignbit_b32) and lets the
+// compaction below count with right shifts, which issue at twice the rate of left shifts on gfx950
+// (profiles/r01_g_valu_rates.txt).
+//
+// What is computed (reference: nthash crate 0.5.1 as called from rust-mdbg src/read.rs:196):
+//   fh(e) = XOR_{u<l} rol(h[c(e-u)], u)        forward hash of the l-mer ENDING at dense position e
+//   rh(e) = XOR_{u<l} rol(rc[c(e-u)], l-1-u)   reverse-complement hash of the same l-mer
+//   selected iff min(fh, rh) <= bound (src/read.rs:196, inclusive).
+// The kernel evaluates only the top BS_B bits of fh and rh, bit-sliced over 32 positions per lane, as a
+// NECESSARY condition (prefix(hash) <= prefix(bound)); the rare survivors are re-evaluated exactly (64 bits).
+//
+// Bit b of fh(e) = XOR_u H_{b-u}[e-u] with H_j[q] = bit j of h[c(q)]: a fixed boolean function of the two code
+// bits per j.  With T_j = H_j delayed by (63 - j), every out-bit is a sliding XOR over l consecutive T planes:
+//   W_b = XOR_{j=b-l+1..b} T_j   and   out_b, delayed by (63 - b), equals W_b.
+// So one funnel shift per hash-bit plane j (l + BS_B - 1 of them per strand), one XOR per plane and out-bit, and
+// one final per-out-bit alignment (which needs the neighbouring word: a DPP wave shift on the device).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BS_HD __host__ __device__ __forceinline__
+#else
+#define BS_HD inline
+#endif
+
+typedef uint32_t bs_u32;
+typedef uint64_t bs_u64;
+
+// ntHash seeds by code (A C T G) and their complements' seeds (T G A C)
+#define BS_SEED_A 0x3c8bfbb395c60474ull
+#define BS_SEED_C 0x3193c18562a02b4cull
+#define BS_SEED_G 0x20323ed082572324ull
+#define BS_SEED_T 0x295549f54be24456ull
+
+constexpr int BS_B = 10;             // hash bits evaluated by the bit-sliced filter (top bits 63 .. 64-BS_B)
+constexpr int BS_MAX_L = 32;
+
+BS_HD constexpr bs_u64 bs_seed_f(int code) { return code == 0 ? BS_SEED_A : code == 1 ? BS_SEED_C : code == 2 ? BS_SEED_T : BS_SEED_G; }
+BS_HD constexpr bs_u64 bs_seed_r(int code) { return bs_seed_f(code ^ 2); }
+// truth table over the code (bit c = value for code c) of hash bit j
+BS_HD constexpr bs_u32 bs_truth_f(int j) {
+    return (bs_u32)(((bs_seed_f(0) >> j) & 1) | (((bs_seed_f(1) >> j) & 1) << 1) | (((bs_seed_f(2) >> j) & 1) << 2) | (((bs_seed_f(3) >> j) & 1) << 3));
+}
+BS_HD constexpr bs_u32 bs_truth_r(int j) {
+    return (bs_u32)(((bs_seed_r(0) >> j) & 1) | (((bs_seed_r(1) >> j) & 1) << 1) | (((bs_seed_r(2) >> j) & 1) << 2) | (((bs_seed_r(3) >> j) & 1) << 3));
+}
+
+BS_HD bs_u32 bs_popc(bs_u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (bs_u32)__popc(x);
+#else
+    return (bs_u32)__builtin_popcount(x);
+#endif
+}
+// ({hi, lo} >> s) & 0xffffffff, s in 0..31
+BS_HD bs_u32 bs_alignbit(bs_u32 hi, bs_u32 lo, bs_u32 s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return (bs_u32)(((((bs_u64)hi) << 32) | lo) >> (s & 31));
+#endif
+}
+BS_HD bs_u32 bs_brev(bs_u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    return __builtin_bswap32(x);
+#endif
+}
+BS_HD bs_u64 bs_rol64(bs_u64 x, unsigned r) { r &= 63; return (x << r) | (x >> ((64 - r) & 63)); }
+
+// plane "in[p - u]" of a stream held as (prev2, prev, cur) words, u in 0..63
+BS_HD bs_u32 bs_delay(bs_u32 cur, bs_u32 prev, bs_u32 prev2, int u) {
+    if (u == 0) return cur;
+    if (u < 32) return bs_alignbit(prev, cur, (bs_u32)u);
+    if (u == 32) return prev;
+    return bs_alignbit(prev2, prev, (bs_u32)(u - 32));
+}
+
+// boolean function of the two code planes given by a truth table with bit 0 clear (value for code 0 is 0);
+// after inlining with a constant table each case is one v_bitop3 / v_and / v_xor
+BS_HD bs_u32 bs_plane0(bs_u32 truth, bs_u32 p0, bs_u32 p1) {
+    bs_u32 r = 0;
+    if (truth & 2) r |= p0 & ~p1;
+    if (truth & 4) r |= ~p0 & p1;
+    if (truth & 8) r |= p0 & p1;
+    return r;
+}
+
+// ---- homopolymer compaction: both planes of one raw word squeezed towards the MSB under keep mask m --------
+// (Hacker's Delight 7-4 "compress", mirrored: zeros are counted from the MSB side, so the parallel prefix uses
+// right shifts and only the moves use left shifts.)
+BS_HD void bs_compress2(bs_u32 m, bs_u32& x0, bs_u32& x1) {
+    x0 &= m; x1 &= m;
+    bs_u32 mk = ~m >> 1;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 5; ++i) {
+        bs_u32 mp = mk ^ (mk >> 1);
+        mp ^= mp >> 2; mp ^= mp >> 4; mp ^= mp >> 8; mp ^= mp >> 16;
+        const bs_u32 mv = mp & m;
+        const int s = 1 << i;
+        m = (m ^ mv) | (mv << s);
+        const bs_u32 t0 = x0 & mv; x0 = (x0 ^ t0) | (t0 << s);
+        const bs_u32 t1 = x1 & mv; x1 = (x1 ^ t1) | (t1 << s);
+        mk &= ~mp;
+    }
+}
+
+// position (0 = MSB) of the (n+1)-th set bit of m counted from the MSB; n < popcount(m)
+BS_HD bs_u32 bs_select_msb(bs_u32 m, bs_u32 n) {
+    bs_u32 pos = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int w = 16; w >= 1; w >>= 1) {
+        const bs_u32 top = m >> (32 - w);            // the w most significant bits still under consideration
+        const bs_u32 c = bs_popc(top);
+        if (n >= c) { n -= c; pos += (bs_u32)w; m <<= w; }
+    }
+    return pos;
+}
+
+// ---- bit-sliced filter: per-strand W planes of one dense word -------------------------------------------------
+// Input: planes of the word (c*), of the word before (p*) and two before (q*).  Output W[0..BS_B): W[i] belongs to
+// hash bit b = 63 - i; complement constants are folded into `inv` (bit i set: plane i holds the complement).
+template <int L, bool FWD>
+BS_HD void bs_strand_planes(bs_u32 c0, bs_u32 c1, bs_u32 p0, bs_u32 p1, bs_u32 q0, bs_u32 q1, bs_u32 W[BS_B], bs_u32& inv) {
+    constexpr int JLO = 64 - BS_B - L + 1;          // lowest hash bit that reaches an evaluated out-bit
+    constexpr int NT = L + BS_B - 1;                // planes T_JLO .. T_63
+    bs_u32 T[NT];                                   // normalised planes (truth table with bit 0 clear); complements -> `inv`
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int t = 0; t < NT; ++t) {
+        const int j = JLO + t;
+        bs_u32 truth = FWD ? bs_truth_f(j) : bs_truth_r(j);
+        // forward: base at distance u feeds out-bit b through hash bit j = b - u, T_j is H_j delayed by 63 - j;
+        // reverse: j = b - (l-1) + u, T_j is R_j delayed by j - JLO
+        const int d = FWD ? 63 - j : j - JLO;
+        if (truth & 1) truth ^= 15;
+        if (truth == 0) { T[t] = 0; }
+        else {
+            // the delayed plane is a function of the delayed code planes; build it from the word pair it straddles
+            const bs_u32 a_cur = d < 32 ? bs_plane0(truth, c0, c1) : bs_plane0(truth, p0, p1);
+            const bs_u32 a_prev = d < 32 ? bs_plane0(truth, p0, p1) : bs_plane0(truth, q0, q1);
+            const int dd = d < 32 ? d : d - 32;
+            T[t] = dd == 0 ? a_cur : bs_alignbit(a_prev, a_cur, (bs_u32)dd);
+        }
+    }
+    // sliding XOR over L consecutive planes: W_b = XOR_{j=b-L+1..b} T_j  (forward)
+    //                                         W_b = XOR_{j=b-L+1..b} T_j  (reverse: same index set, other delays)
+    inv = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < BS_B; ++i) {
+        const int b = 63 - i;
+        const int t_hi = b - JLO, t_lo = b - L + 1 - JLO;
+        bs_u32 w = 0; bs_u32 par = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int t = t_lo; t <= t_hi; ++t) {
+            w ^= T[t];
+            const int j = JLO + t;
+            const bs_u32 truth = FWD ? bs_truth_f(j) : bs_truth_r(j);
+            par ^= truth & 1;
+        }
+        W[i] = w;
+        inv |= par << i;
+    }
+}
+
+// final alignment and the bit-sliced comparison "top BS_B bits of the hash <= top BS_B bits of the bound".
+// W: this word's planes, Wp: the planes of the word before (neighbouring lane).  bmask[i] is all-ones iff bit
+// (63 - i) of the bound is set.  The result is the candidate plane for END positions shifted by BS_B - 1:
+// bit for stream position x reports the l-mer ending at x - (BS_B - 1).
+template <bool FWD>
+BS_HD bs_u32 bs_strand_compare(const bs_u32 W[BS_B], const bs_u32 Wp[BS_B], bs_u32 inv, const bs_u32 bmask[BS_B]) {
+    bs_u32 le = 0xFFFFFFFFu;
+    // from the least significant evaluated bit up: le = bound_bit ? (le | ~x) : (le & ~x)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = BS_B - 1; i >= 0; --i) {
+        const int b = 63 - i;
+        // forward: out_b is W_b delayed by (63 - b) already; bring every bit to the common delay BS_B - 1
+        const int d = FWD ? (BS_B - 1) - (63 - b) : 63 - b;
+        bs_u32 x = d == 0 ? W[i] : bs_alignbit(Wp[i], W[i], (bs_u32)d);
+        if ((inv >> i) & 1) x = ~x;
+        const bs_u32 nx = ~x;
+        le = (le & nx) | (bmask[i] & (le | nx));
+    }
+    return le;
+}
+
+// ---- exact 64-bit evaluation of one candidate -----------------------------------------------------------------
+// v0 / v1: the code planes of the 32 dense positions ending at the candidate, bit u = position e - u.
+// t4: 256 x {F4, R4}: 4-base groups indexed by (nibble of v0) | (nibble of v1) << 4, bit v of a nibble = distance v:
+//   F4 = XOR_v rol(h[c_v], v), R4 = XOR_v rol(rc[c_v], 3 - v).
+BS_HD bs_u64 bs_exact_hash(bs_u32 v0, bs_u32 v1, int l, const bs_u64* t4) {
+    bs_u64 fh = 0, rh = 0;
+    const int G = l >> 2;
+    for (int g = 0; g < G; ++g) {
+        const bs_u32 idx = ((v0 >> (4 * g)) & 15u) | (((v1 >> (4 * g)) & 15u) << 4);
+        fh ^= bs_rol64(t4[2 * idx], (unsigned)(4 * g));
+        rh ^= bs_rol64(t4[2 * idx + 1], (unsigned)(l - 4 - 4 * g));
+    }
+    for (int u = 4 * G; u < l; ++u) {
+        const int c = (int)(((v1 >> u) & 1u) << 1 | ((v0 >> u) & 1u));
+        fh ^= bs_rol64(bs_seed_f(c), (unsigned)u);
+        rh ^= bs_rol64(bs_seed_r(c), (unsigned)(l - 1 - u));
+    }
+    return fh < rh ? fh : rh;
+}
+
+inline void bs_make_t4(bs_u64* t4 /* 512 */) {
+    for (int idx = 0; idx < 256; ++idx) {
+        bs_u64 f = 0, r = 0;
+        for (int v = 0; v < 4; ++v) {
+            const int c = (((idx >> (4 + v)) & 1) << 1) | ((idx >> v) & 1);
+            f ^= bs_rol64(bs_seed_f(c), (unsigned)v);
+            r ^= bs_rol64(bs_seed_r(c), (unsigned)(3 - v));
+        }
+        t4[2 * idx] = f; t4[2 * idx + 1] = r;
+    }
+}

@@ -8,17 +8,14 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-// ---- tile geometry of the sketch kernel -------------------------------------------------------
-// One workgroup = 256 lanes (4 wave64), each lane rolls the hash over SEG contiguous raw bases.
+// ---- tile geometry of the sketch kernel (sketch.hip) ----------------------------------------------
+// One workgroup = 256 lanes stages TILE_RAW_WORDS words of 32 raw bases: HALO_BASES of look-back (owned by the tile
+// in front) followed by the TILE_STRIDE bases whose l-mer END positions the tile owns.
 constexpr int TILE_THREADS = 256;
-constexpr int SEG = 256;                          // raw bases per lane
-constexpr int TILE = TILE_THREADS * SEG;          // 65536 raw bases per tile
-constexpr int HALO = 128;                         // raw bases staged in front of the tile
-constexpr int SEG_WORDS = SEG / 16;               // 2-bit codes, 16 per dword
+constexpr int TILE_RAW_WORDS = 1024;
+constexpr int HALO_BASES = 256;
+constexpr int TILE_STRIDE = TILE_RAW_WORDS * 32 - HALO_BASES;   // 32,512 raw bases per tile
 constexpr int MDBG_MAX_L_DEV = 32;                // = MDBG_MAX_L of the C ABI
-constexpr int QCAP = 2048;                        // candidate capacity of a fast tile (slab slots)
-constexpr u32 SLOW_MARK = 0xFFFFFFFFu;            // n_cand value of a tile handed to the generic path
-constexpr int FAST_MAX_L = 14;                    // 32-bit code history: 3 + 2*l <= 31
 
 // ordinal = (global read ordinal << WIN_BITS) | window index within the read
 constexpr int WIN_BITS = 26;
@@ -35,15 +32,6 @@ struct __attribute__((aligned(16))) Rec {         // one slab slot / one selecte
 #define NT_SEED_C 0x3193c18562a02b4cull
 #define NT_SEED_G 0x20323ed082572324ull
 #define NT_SEED_T 0x295549f54be24456ull
-
-struct SketchConsts {
-    u64 bound;          // hash_bound (src/read.rs:183)
-    u32 l;
-    u32 hpc;            // 1: homopolymer-compress (default), 0: --skiphpc
-    // candidate filter on 32-bit partial hashes (see DESIGN.md "sketch kernel")
-    u32 thrF, thrR, maskR, G0, R0, bfe_off;
-    u32 tbl[32];        // 16 x {XF, XR} indexed by out*4+in
-};
 
 __host__ __device__ inline u64 rol64(u64 x, unsigned r) { r &= 63; return (x << r) | (x >> ((64 - r) & 63)); }
 

@@ -59,7 +59,7 @@ def test_config3_size_properties():
         m.ingest_device(db, do, n_reads, nb, 0)
         one = m.finalize()
         st = m.stats()
-        assert st["n_slow_tiles"] == 0 and st["n_tiles"] == (nb + 65535) // 65536
+        assert st["n_slow_tiles"] == 0 and st["n_tiles"] == (nb + 32511) // 32512
         # 1. node rows are sorted by index, indices are unique and < number of distinct keys
         assert np.all(np.diff(one["index"].astype(np.int64)) > 0) and int(one["index"][-1]) < one["n_nodes_before"]
         # 2. abundance filter and metadata identities (src/main.rs:778: seqlen = last - first + 2; end = last + l)
@@ -112,9 +112,9 @@ def test_config3_size_routed_equals_local():
     assert np.array_equal(tab["shift_full"], loc["shift_full"])
 
 
-def test_batch_larger_than_one_launch_equals_split_batches():
-    """one batch of > 2^33 bases (more tiles than one sketch launch takes: the tile kernel runs twice inside one call, 32-bit
-    tile indices restart) must equal the same reads ingested as two batches"""
+def test_batch_larger_than_2_33_bases_equals_split_batches():
+    """one batch of > 2^33 bases (64-bit positions everywhere, > 2^18 tiles in one look-back chain) must equal the same reads
+    ingested as two batches"""
     import rust_mdbg_amd as R
     k, l, d, a = 35, 12, 0.002, 2
     n_reads = 600000
@@ -124,7 +124,7 @@ def test_batch_larger_than_one_launch_equals_split_batches():
         m.ingest_device(db, do, n_reads, nb, 0)
         one = m.finalize()
         st = m.stats()
-        assert st["n_tiles"] == (nb + 65535) // 65536 > 131072 and st["n_sketch_tile_launches"] == 2
+        assert st["n_tiles"] == (nb + 32511) // 32512 > 262144 and st["n_sketch_tile_launches"] == 1
         offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
         half = n_reads // 2
         cut = int(offs[half]) // 16 * 16                      # the device bases pointer must stay 16-byte aligned
