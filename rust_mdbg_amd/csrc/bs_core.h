@@ -39,7 +39,7 @@ typedef uint64_t bs_u64;
 #define BS_SEED_G 0x20323ed082572324ull
 #define BS_SEED_T 0x295549f54be24456ull
 
-constexpr int BS_B = 10;             // hash bits evaluated by the bit-sliced filter (top bits 63 .. 64-BS_B)
+constexpr int BS_B = 8;              // hash bits evaluated by the bit-sliced filter (top bits 63 .. 64-BS_B)
 constexpr int BS_MAX_L = 32;
 
 BS_HD constexpr bs_u64 bs_seed_f(int code) { return code == 0 ? BS_SEED_A : code == 1 ? BS_SEED_C : code == 2 ? BS_SEED_T : BS_SEED_G; }
@@ -75,6 +75,13 @@ BS_HD bs_u32 bs_brev(bs_u32 x) {
     x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
     x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
     return __builtin_bswap32(x);
+#endif
+}
+BS_HD bs_u32 bs_xor3(bs_u32 a, bs_u32 b, bs_u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
 #endif
 }
 BS_HD bs_u64 bs_rol64(bs_u64 x, unsigned r) { r &= 63; return (x << r) | (x >> ((64 - r) & 63)); }
@@ -159,26 +166,31 @@ BS_HD void bs_strand_planes(bs_u32 c0, bs_u32 c1, bs_u32 p0, bs_u32 p1, bs_u32 q
             T[t] = dd == 0 ? a_cur : bs_alignbit(a_prev, a_cur, (bs_u32)dd);
         }
     }
-    // sliding XOR over L consecutive planes: W_b = XOR_{j=b-L+1..b} T_j  (forward)
-    //                                         W_b = XOR_{j=b-L+1..b} T_j  (reverse: same index set, other delays)
+    // sliding XOR over L consecutive planes: W_b = XOR_{j=b-L+1..b} T_j (same index set for both strands, other delays);
+    // W_63 in full (three-input XORs), then W_{b-1} = W_b ^ T_b ^ T_{b-L}
     inv = 0;
+    {
+        constexpr int hi0 = NT - 1, lo0 = NT - L;
+        bs_u32 w = T[lo0];
+        int t = lo0 + 1;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (; t + 1 <= hi0; t += 2) w = bs_xor3(w, T[t], T[t + 1]);
+        if (t <= hi0) w ^= T[t];
+        W[0] = w;
+    }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 1; i < BS_B; ++i) W[i] = bs_xor3(W[i - 1], T[NT - i], T[NT - i - L]);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int i = 0; i < BS_B; ++i) {
         const int b = 63 - i;
-        const int t_hi = b - JLO, t_lo = b - L + 1 - JLO;
-        bs_u32 w = 0; bs_u32 par = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int t = t_lo; t <= t_hi; ++t) {
-            w ^= T[t];
-            const int j = JLO + t;
-            const bs_u32 truth = FWD ? bs_truth_f(j) : bs_truth_r(j);
-            par ^= truth & 1;
-        }
-        W[i] = w;
+        bs_u32 par = 0;
+        for (int j = b - L + 1; j <= b; ++j) par ^= (FWD ? bs_truth_f(j) : bs_truth_r(j)) & 1;
         inv |= par << i;
     }
 }
@@ -208,17 +220,19 @@ BS_HD bs_u32 bs_strand_compare(const bs_u32 W[BS_B], const bs_u32 Wp[BS_B], bs_u
 
 // ---- exact 64-bit evaluation of one candidate -----------------------------------------------------------------
 // v0 / v1: the code planes of the 32 dense positions ending at the candidate, bit u = position e - u.
-// t4: 256 x {F4, R4}: 4-base groups indexed by (nibble of v0) | (nibble of v1) << 4, bit v of a nibble = distance v:
-//   F4 = XOR_v rol(h[c_v], v), R4 = XOR_v rol(rc[c_v], 3 - v).
-BS_HD bs_u64 bs_exact_hash(bs_u32 v0, bs_u32 v1, int l, const bs_u64* t4) {
+// tab: (1 << 2*GS) x {F, R}: GS-base groups indexed by (GS bits of v0) | (GS bits of v1) << GS, bit v = distance v:
+//   F = XOR_v rol(h[c_v], v), R = XOR_v rol(rc[c_v], GS - 1 - v).
+template <int GS>
+BS_HD bs_u64 bs_exact_hash(bs_u32 v0, bs_u32 v1, int l, const bs_u64* tab) {
     bs_u64 fh = 0, rh = 0;
-    const int G = l >> 2;
+    const int G = l / GS;
+    constexpr bs_u32 M = (1u << GS) - 1u;
     for (int g = 0; g < G; ++g) {
-        const bs_u32 idx = ((v0 >> (4 * g)) & 15u) | (((v1 >> (4 * g)) & 15u) << 4);
-        fh ^= bs_rol64(t4[2 * idx], (unsigned)(4 * g));
-        rh ^= bs_rol64(t4[2 * idx + 1], (unsigned)(l - 4 - 4 * g));
+        const bs_u32 idx = ((v0 >> (GS * g)) & M) | (((v1 >> (GS * g)) & M) << GS);
+        fh ^= bs_rol64(tab[2 * idx], (unsigned)(GS * g));
+        rh ^= bs_rol64(tab[2 * idx + 1], (unsigned)(l - GS - GS * g));
     }
-    for (int u = 4 * G; u < l; ++u) {
+    for (int u = GS * G; u < l; ++u) {
         const int c = (int)(((v1 >> u) & 1u) << 1 | ((v0 >> u) & 1u));
         fh ^= bs_rol64(bs_seed_f(c), (unsigned)u);
         rh ^= bs_rol64(bs_seed_r(c), (unsigned)(l - 1 - u));
@@ -226,14 +240,16 @@ BS_HD bs_u64 bs_exact_hash(bs_u32 v0, bs_u32 v1, int l, const bs_u64* t4) {
     return fh < rh ? fh : rh;
 }
 
-inline void bs_make_t4(bs_u64* t4 /* 512 */) {
-    for (int idx = 0; idx < 256; ++idx) {
+template <int GS>
+inline void bs_make_table(bs_u64* tab /* 2 << 2*GS */) {
+    for (int idx = 0; idx < (1 << (2 * GS)); ++idx) {
         bs_u64 f = 0, r = 0;
-        for (int v = 0; v < 4; ++v) {
-            const int c = (((idx >> (4 + v)) & 1) << 1) | ((idx >> v) & 1);
+        for (int v = 0; v < GS; ++v) {
+            const int c = (((idx >> (GS + v)) & 1) << 1) | ((idx >> v) & 1);
             f ^= bs_rol64(bs_seed_f(c), (unsigned)v);
-            r ^= bs_rol64(bs_seed_r(c), (unsigned)(3 - v));
+            r ^= bs_rol64(bs_seed_r(c), (unsigned)(GS - 1 - v));
         }
-        t4[2 * idx] = f; t4[2 * idx + 1] = r;
+        tab[2 * idx] = f; tab[2 * idx + 1] = r;
     }
 }
+constexpr int BS_GS = 3;             // group size of the exact tables: 64 entries x 16 B = 1 KB of LDS

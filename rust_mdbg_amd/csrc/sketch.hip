@@ -13,8 +13,9 @@
 //               funnel-shifted boolean planes, compared with the bound as bit planes -> candidate bitmap;
 //     4. exact  every candidate (a fraction ~2.5 d of the positions) is re-evaluated with the full 64-bit hashes
 //               from a 4-base lookup table, mapped back to raw coordinates and to its read;
-//     5. output the tile's count enters a decoupled look-back scan over the tiles (one 64-bit state word per tile),
-//               so the minimizers are written once, directly at their final, position-ordered place.
+//     5. output the survivors go to the tile's slab in position order with their count; three tiny scan kernels and
+//               gather_kernel then squeeze the slabs into the final arrays, which are therefore ordered by (read,
+//               position) exactly like Read.transformed / minimizers_pos.  Tiles are independent of each other.
 //   Tiles that hold a byte outside ACGT (N, lower case, garbage) or whose look-back window is one long
 //   homopolymer take the generic exact walker inside the same kernel (slow_tile): exact, one thread per position.
 #include "mdbg_dev.h"
@@ -30,10 +31,11 @@ struct SketchArgs {
     const u64* offsets; u32 n_reads;
     const u32* bread;            // read containing the first staged base of tile t, [n_tiles + 2]
     u32 n_tiles;
-    u64* tstate; u32* ticket;    // look-back state per tile (zeroed), tile ticket (zeroed)
-    u64 out_base, out_cap; u64* out_hash; u32* out_pos; u32* out_read;
-    u64* total_out;              // <- out_base + minimizers of the launch (written by the last tile)
-    const u64* t4;               // 256 x {F4, R4} (bs_make_t4)
+    u32 tile0;                   // workgroup b runs tile tile0 + b
+    Rec* slab; u32 slab_cap;     // records of workgroup b: slab[b * slab_cap ..), in position order
+    u32* n_valid;                // [n_tiles] number of minimizers whose l-mer ENDS in the tile
+    u32* over_max;               // <- largest n_valid that did not fit its slab (0: none; the host then retries with larger slabs)
+    const u64* t4;               // (2 << 2*BS_GS) x u64: {F, R} per 3-base group (bs_make_table)
     const u8* tile_flags;        // FMT_PLANES: nonzero = an exception falls into the tile's staged range (null: none)
     const u64* exc_pos; const u8* exc_val; u32 n_exc;
     u32* err_flag; unsigned long long* slow_total;
@@ -109,22 +111,24 @@ constexpr int HW = HALO_BASES / 32;           // leading halo words
 constexpr int TT = TILE_THREADS;
 constexpr int WPT = RW / TT;                  // raw words per thread
 constexpr int DPAD = 4;                       // zero words in front of the dense stream (look-back of the first words)
-constexpr int QCAP = 1024;                    // candidates per evaluation round
-constexpr u64 TS_FLAG_A = 1ull << 62, TS_FLAG_P = 2ull << 62, TS_VAL = (1ull << 62) - 1;
+constexpr int QCAP = 768;                     // candidates per evaluation round
+constexpr int RS_CAP = 32;                    // read starts of a tile kept in LDS (more: binary search in global memory)
 
 struct __attribute__((aligned(16))) TileLds {
-    u32 dense[2 * (DPAD + RW + 4)];           // dense word D: planes at [2 * (DPAD + D)], [.. + 1]
+    u32 dense[2 * (DPAD + RW + 4)];           // dense word D: planes at [2 * (DPAD + D)], [.. + 1]; during phases 1-2 the first RW
+                                              // words hold the read-start bitmap (every reader zeroes what it read)
     u32 kw[RW];                               // keep mask of raw word w
     u16 rpre[RW + 8];                         // kept bases in front of raw word w; [RW] = all
     u16 dfirst[RW + 8];                       // raw word that holds dense position 32 * D
     union {
         u32 stage[2 * RW];                    // FMT_ASCII: half planes of the 16-base chunks (phase 1 only)
-        struct { u32 cand[RW + 8]; u16 cpre[RW + 8]; } c;
+        struct { u32 cand[RW + 8]; u16 cpre[RW + 8]; u16 list[QCAP]; } c;
     } a;
-    union { u32 force[RW]; u16 list[QCAP]; } b;   // read starts (phases 1-2) | candidate list (phases 4-)
-    u32 misc[32];                             // [0..4] scan scratch, [8] slow, [9] tile, [10] H, [11] Hh, [12..13] counts, [14,15] base, [16] next chunk
+    u64 t3[2 << (2 * BS_GS)];                 // exact evaluation: 3-base groups {F, R}
+    int64_t rs_rel[RS_CAP];                   // start of read rl + i, relative to the first staged position
+    u32 misc[32];                             // [0..4] scan scratch, [8] slow, [11] Hh, [16] next round, [17] list fill
 };
-static_assert(sizeof(TileLds) * 5 <= 160 * 1024, "5 workgroups per CU");
+static_assert(sizeof(TileLds) * 6 <= 160 * 1024, "6 workgroups per CU");
 
 // 16 ASCII bases -> {plane0 half | plane1 half}, MSB first (base 0 in bits 31 / 15); bad != 0: a byte outside ACGT
 __device__ inline u32 ascii16_to_hp(uint4 v, u32& bad) {
@@ -156,39 +160,21 @@ __device__ inline u32 range_mask(int64_t a, int64_t b) {
 }
 
 __device__ inline u32 dpp_wave_shr1(u32 x) {        // lane i <- lane i-1 (lane 0: 0)
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
 }
 
-// decoupled look-back over the tiles of the launch: called by wave 0; returns the exclusive prefix (out_base included)
-__device__ inline u64 lookback_publish(u64* tstate, u32 gt, u64 n, u64 out_base) {
-    const int lane = threadIdx.x & 63;
-    u64 excl = out_base;
-    if (gt != 0) {
-        if (lane == 0) __hip_atomic_store(&tstate[gt], TS_FLAG_A | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int64_t j = (int64_t)gt;
-        for (;;) {
-            const int64_t idx = j - 1 - lane;
-            u64 v = TS_FLAG_P;                                   // in front of tile 0: prefix 0
-            if (idx >= 0) v = __hip_atomic_load(&tstate[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u32 flag = (u32)(v >> 62);
-            const u64 notready = __ballot(flag == 0), isP = __ballot(flag == 2);
-            const int firstP = isP ? __ffsll((unsigned long long)isP) - 1 : 64;
-            const u64 need = firstP >= 63 ? ~0ull : ((2ull << firstP) - 1);
-            if (notready & need) { __builtin_amdgcn_s_sleep(2); continue; }
-            u64 contrib = lane <= firstP ? (v & TS_VAL) : 0;
-            for (int d = 32; d; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
-            excl += contrib;
-            if (firstP < 64) break;
-            j -= 64;
-        }
-    }
-    if (lane == 0) __hip_atomic_store(&tstate[gt], TS_FLAG_P | (excl - out_base + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
+// what a tile hands to the gather: records in position order + their number
+__device__ inline void put_rec(const SketchArgs& a, Rec* slab, u32 rank, u64 hash, u32 pos, u32 read) {
+    if (rank < a.slab_cap) { Rec r; r.hash = hash; r.pos = pos; r.read = read; slab[rank] = r; }
+}
+__device__ inline void put_count(const SketchArgs& a, u32 gt, u32 n) {
+    a.n_valid[gt] = n;
+    if (n > a.slab_cap) atomicMax(a.over_max, n);
 }
 
 // ---- generic exact path for one tile (inside the tile kernel) --------------------------------------------
 template <bool HPC, class Src>
-__device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, TileLds& S) {
+__device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, TileLds& S) {
     const int tid = threadIdx.x;
     const u64 t_lo = (u64)gt * TILE_STRIDE;
     u64 t_hi = t_lo + TILE_STRIDE; if (t_hi > a.n_bases) t_hi = a.n_bases;
@@ -196,38 +182,23 @@ __device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, TileLds& 
     const u64 first_base = a.offsets[0];
     u32* tmp = S.misc;
     if (tid == 0) atomicAdd(a.slow_total, 1ull);
-    u64 base = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        u32 running = 0;
-        for (u64 p0 = t_lo; p0 < t_hi; p0 += TT) {
-            const u64 p = p0 + tid;
-            u32 sel = 0; u64 hash = 0, start = 0; u32 r = 0; u64 rlo = 0;
-            if (p < t_hi && p >= first_base) {
-                r = find_read(a.offsets, rl, rh_, p);
-                rlo = a.offsets[r];
-                if (pass == 0) { const u8 c = src.at(p); if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') *a.err_flag = 1; }   // the host applies the length rule
-                if (kept_at<HPC>(src, rlo, p) && walk_lmer<HPC>(src, rlo, p, a.l, start, hash) && hash <= a.bound) sel = 1;
-            }
-            if (pass == 0) { running += sel; continue; }
-            u32 total;
-            const u32 rank = block_excl_scan_256(sel, tmp, total);
-            if (sel) {
-                const u64 idx = base + running + rank;
-                if (idx < a.out_cap) { a.out_hash[idx] = hash; a.out_pos[idx] = (u32)(start - rlo); a.out_read[idx] = r + a.read_base; }
-            }
-            running += total;
+    u32 running = 0;
+    for (u64 p0 = t_lo; p0 < t_hi; p0 += TT) {
+        const u64 p = p0 + tid;
+        u32 sel = 0; u64 hash = 0, start = 0; u32 r = 0; u64 rlo = 0;
+        if (p < t_hi && p >= first_base) {
+            r = find_read(a.offsets, rl, rh_, p);
+            rlo = a.offsets[r];
+            const u8 c = src.at(p);
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') *a.err_flag = 1;      // the host applies the length rule
+            if (kept_at<HPC>(src, rlo, p) && walk_lmer<HPC>(src, rlo, p, a.l, start, hash) && hash <= a.bound) sel = 1;
         }
-        if (pass == 0) {
-            u32 total;
-            (void)block_excl_scan_256(running, tmp, total);
-            if (tid < 64) {
-                const u64 excl = lookback_publish(a.tstate, gt, total, a.out_base);
-                if (tid == 0) { S.misc[14] = (u32)excl; S.misc[15] = (u32)(excl >> 32); if (gt == a.n_tiles - 1) *a.total_out = excl + total; }
-            }
-            __syncthreads();
-            base = (u64)S.misc[14] | ((u64)S.misc[15] << 32);
-        }
+        u32 total;
+        const u32 rank = block_excl_scan_256(sel, tmp, total);
+        if (sel) put_rec(a, slab, running + rank, hash, (u32)(start - rlo), r + a.read_base);
+        running += total;
     }
+    if (tid == 0) put_count(a, gt, running);
 }
 
 // ---- fast tile kernel ---------------------------------------------------------------------------------------------
@@ -237,37 +208,56 @@ template <int L>
 __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     __shared__ TileLds S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { S.misc[9] = atomicAdd(a.ticket, 1u); S.misc[8] = a.force_slow; S.misc[11] = 0; }
-    for (int i = tid; i < 2 * (DPAD + RW + 4); i += TT) S.dense[i] = 0;
-    for (int i = tid; i < RW; i += TT) S.b.force[i] = 0;
-    __syncthreads();
-    const u32 gt = S.misc[9];
-#define MDBG_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(size_t)gt * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    const u32 gt = a.tile0 + blockIdx.x;
+    Rec* const slab = a.slab + (size_t)blockIdx.x * a.slab_cap;
+#define MDBG_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(size_t)gt * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
     MDBG_STAMP(0);
     const int64_t raw0 = (int64_t)gt * TILE_STRIDE - HALO_BASES;      // first staged raw position (negative for tile 0)
     const int64_t nb = (int64_t)a.n_bases;
     const bool hpc = a.hpc != 0;
-    const u32 rl = a.bread[gt], rh_ = a.bread[gt + 2];
-    const int64_t first_base = (int64_t)a.offsets[0];      // positions in front of it belong to no read
-
-    // ---- phase 1: read starts, load, planes ---------------------------------------------------------------------
-    for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) {
-        const int64_t rel = (int64_t)a.offsets[r] - raw0;
-        if (rel >= 0 && rel < RW * 32) atomicOr(&S.b.force[rel >> 5], 0x80000000u >> (rel & 31));
-    }
-    u32 x0[WPT], x1[WPT], pv0 = 0, pv1 = 0;          // my raw words (MSB first); pv*: bit 0 = the base in front of them
     const bool interior = raw0 >= 0 && raw0 + RW * 32 <= nb;
+
+    // ---- phase 1: load (issued first: everything below hides under its latency), read starts, planes -------------------
+    u32 x0[WPT], x1[WPT], pv0 = 0, pv1 = 0;          // my raw words (MSB first); pv*: bit 0 = the base in front of them
+    constexpr int CPT = RW * 2 / TT;                  // FMT_ASCII: 16-base chunks per thread
+    uint4 av[CPT]; uint2 pr[WPT];
+    const int64_t pi0 = raw0 / 32 + (int64_t)WPT * tid;       // FMT_PLANES: my first word pair (raw0 is a multiple of 32, also when negative)
+    const int64_t n_pairs = (nb + 31) >> 5;
     if (a.fmt == FMT_ASCII) {
-        u32 bad_any = 0;
-        constexpr int CPT = RW * 2 / TT;              // 16-base chunks per thread
         if (interior) {
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4* src = (const u32x4*)(a.bases + raw0);
-            uint4 v[CPT];
 #pragma unroll
-            for (int g = 0; g < CPT; ++g) { const u32x4 q = __builtin_nontemporal_load(src + tid + TT * g); v[g] = make_uint4(q.x, q.y, q.z, q.w); }
+            for (int g = 0; g < CPT; ++g) { const u32x4 q = __builtin_nontemporal_load(src + tid + TT * g); av[g] = make_uint4(q.x, q.y, q.z, q.w); }
+        }
+    } else {
+        if (interior) {
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4* src = (const u32x4*)(a.planes + pi0);
 #pragma unroll
-            for (int g = 0; g < CPT; ++g) S.a.stage[tid + TT * g] = ascii16_to_hp(v[g], bad_any);
+            for (int i = 0; i < WPT / 2; ++i) { const u32x4 q = __builtin_nontemporal_load(src + i); pr[2 * i] = make_uint2(q.x, q.y); pr[2 * i + 1] = make_uint2(q.z, q.w); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) { const int64_t pi = pi0 + i; pr[i] = (pi >= 0 && pi < n_pairs) ? a.planes[pi] : make_uint2(0u, 0u); }
+        }
+        if (tid && pi0 - 1 >= 0 && pi0 - 1 < n_pairs) { const uint2 q = a.planes[pi0 - 1]; pv0 = q.x >> 31; pv1 = q.y >> 31; }
+    }
+    const u32 rl = a.bread[gt], rh_ = a.bread[gt + 2];
+    const int64_t first_base = (int64_t)a.offsets[0];      // positions in front of it belong to no read
+    for (int i = tid; i < 2 * (DPAD + RW + 4); i += TT) S.dense[i] = 0;
+    if (tid < (2 << (2 * BS_GS))) S.t3[tid] = a.t4[tid];
+    if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[11] = 0; S.misc[17] = 0; }
+    __syncthreads();
+    for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) {
+        const int64_t rel = (int64_t)a.offsets[r] - raw0;
+        if (r - rl < RS_CAP) S.rs_rel[r - rl] = rel;
+        if (rel >= 0 && rel < RW * 32) atomicOr(&S.dense[rel >> 5], 0x80000000u >> (rel & 31));
+    }
+    if (a.fmt == FMT_ASCII) {
+        u32 bad_any = 0;
+        if (interior) {
+#pragma unroll
+            for (int g = 0; g < CPT; ++g) S.a.stage[tid + TT * g] = ascii16_to_hp(av[g], bad_any);
         } else {
 #pragma unroll 1
             for (int g = 0; g < CPT; ++g) {
@@ -299,21 +289,9 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         }
         if (tid) { const u32 hp = S.a.stage[2 * WPT * tid - 1]; pv0 = hp >> 16; pv1 = hp; }
     } else {
-        const int64_t pi0 = raw0 / 32 + (int64_t)WPT * tid;       // raw0 is a multiple of 32 (also when negative)
-        const int64_t n_pairs = (nb + 31) >> 5;
-        uint2 pr[WPT];
-        if (interior) {
-            const uint4* src = (const uint4*)(a.planes + pi0);
-#pragma unroll
-            for (int i = 0; i < WPT / 2; ++i) { const uint4 q = src[i]; pr[2 * i] = make_uint2(q.x, q.y); pr[2 * i + 1] = make_uint2(q.z, q.w); }
-        } else {
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) { const int64_t pi = pi0 + i; pr[i] = (pi >= 0 && pi < n_pairs) ? a.planes[pi] : make_uint2(0u, 0u); }
-        }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) { x0[i] = __brev(pr[i].x); x1[i] = __brev(pr[i].y); }
-        if (tid && pi0 - 1 >= 0 && pi0 - 1 < n_pairs) { const uint2 q = a.planes[pi0 - 1]; pv0 = q.x >> 31; pv1 = q.y >> 31; }
-        if (tid == 0 && a.tile_flags && a.tile_flags[gt]) S.misc[8] = 1;
+        __syncthreads();
     }
     MDBG_STAMP(1);
 
@@ -328,9 +306,10 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
             u32 k = vm;
             if (hpc) {
                 const u32 d0 = bs_alignbit(i ? x0[i - 1] : pv0, x0[i], 1), d1 = bs_alignbit(i ? x1[i - 1] : pv1, x1[i], 1);
-                k = ((x0[i] ^ d0) | (x1[i] ^ d1) | S.b.force[w]) & vm;
+                k = ((x0[i] ^ d0) | (x1[i] ^ d1) | S.dense[w]) & vm;
                 if (w == 0) k |= 0x80000000u & vm;           // nothing staged in front of the first position
             }
+            S.dense[w] = 0;                                  // the read-start bitmap has been consumed: back to an empty dense stream
             kw[i] = k; n_kept[i] = bs_popc(k); mine += n_kept[i];
         }
 #pragma unroll
@@ -339,7 +318,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         }
     }
     u32 H;
-    u32 off = block_excl_scan_256(mine, S.misc, H);
+    u32 off = block_excl_scan_256(mine, S.misc, H);          // (its barriers also order the bitmap reset before the stream writes)
     if (tid == HW / WPT) S.misc[11] = off;                   // kept bases of the halo words
     if (tid == TT - 1) S.rpre[RW] = (u16)H;
 #pragma unroll
@@ -364,17 +343,19 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     if (S.misc[8] || (!true_start && Hh < (u32)L)) {
         // N / foreign bytes, or the look-back window is one long homopolymer: exact generic walker for the whole tile
         __syncthreads();
-        if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) slow_tile<true>(a, src, gt, S); else slow_tile<false>(a, src, gt, S); }
-        else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) slow_tile<true>(a, src, gt, S); else slow_tile<false>(a, src, gt, S); }
+        if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
+        else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
         return;
     }
 
-    // ---- phase 3: bit-sliced filter over the dense stream ---------------------------------------------------------
+    // ---- phase 3: bit-sliced filter over the dense stream -> candidate bitmap + (unordered) candidate list ---------------
+    // candidate plane coordinate x = e + BS_B - 1; owned END positions e in [max(Hh, L-1), H)
+    const u32 e_lo = Hh > (u32)(L - 1) ? Hh : (u32)(L - 1);
+    const u32 n_out = H ? ((H + BS_B - 2) >> 5) + 1 : 0;              // words of the candidate plane
     {
         u32 bmask[BS_B];
 #pragma unroll
         for (int i = 0; i < BS_B; ++i) bmask[i] = ((a.btop >> (BS_B - 1 - i)) & 1u) ? 0xFFFFFFFFu : 0u;
-        const u32 n_out = H ? ((H + BS_B - 2) >> 5) + 1 : 0;          // words of the candidate plane (shifted by BS_B - 1)
         const u32 n_steps = (n_out + 62) / 63;
         for (u32 st = wv; st < n_steps; st += TT / 64) {
             const int D = (int)(63 * st) + lane - 1;                  // lane 0 recomputes the word before the step's first
@@ -391,31 +372,33 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
 #pragma unroll
             for (int i = 0; i < BS_B; ++i) Wp[i] = dpp_wave_shr1(W[i]);
             cand |= bs_strand_compare<false>(W, Wp, inv, bmask);
-            if (lane && (u32)D < n_out) S.a.c.cand[D] = cand;
+            if (lane && (u32)D < n_out) {
+                cand &= range_mask((int64_t)e_lo + BS_B - 1 - 32 * (int64_t)D, (int64_t)H + BS_B - 1 - 32 * (int64_t)D);
+                S.a.c.cand[D] = cand;
+                if (cand) {                                           // common case: all candidates of the tile fit one unordered list
+                    u32 slot = atomicAdd(&S.misc[17], bs_popc(cand));
+                    while (cand) {
+                        const u32 b = (u32)__clz(cand); cand &= ~(0x80000000u >> b);
+                        if (slot < QCAP) S.a.c.list[slot] = (u16)(32 * D + b - (BS_B - 1));
+                        ++slot;
+                    }
+                }
+            }
         }
+        for (u32 D = n_out + tid; D < RW + 8; D += TT) S.a.c.cand[D] = 0;
     }
     __syncthreads();
     MDBG_STAMP(3);
 
-    // ---- phase 4: owned candidates, exact evaluation, output -----------------------------------------------------------
-    // candidate plane coordinate x = e + BS_B - 1; owned END positions e in [max(Hh, L-1), H)
-    const u32 e_lo = Hh > (u32)(L - 1) ? Hh : (u32)(L - 1);
+    // ---- phase 4: exact evaluation, ranks, records -------------------------------------------------------------------
     const int nw = tid == TT - 1 ? WPT + 1 : WPT;                     // words 4*tid .. ; the last thread also takes word RW
-    auto count_words = [&](bool mask_range) -> u32 {                  // cpre[] <- exclusive candidate counts per word; returns the total
+    auto count_words = [&]() -> u32 {                                 // cpre[] <- exclusive counts of the bitmap per word; returns the total
         u32 cnt = 0, cw[WPT + 1];
-        for (int i = 0; i < nw; ++i) {
-            const int D = WPT * tid + i;
-            u32 w = S.a.c.cand[D];
-            if (mask_range) {
-                const u32 n_out = H ? ((H + BS_B - 2) >> 5) + 1 : 0;
-                w = (u32)D < n_out ? w & range_mask((int64_t)e_lo + BS_B - 1 - 32 * (int64_t)D, (int64_t)H + BS_B - 1 - 32 * (int64_t)D) : 0u;
-                S.a.c.cand[D] = w;
-            }
-            cw[i] = bs_popc(w); cnt += cw[i];
-        }
+        for (int i = 0; i < nw; ++i) { cw[i] = bs_popc(S.a.c.cand[WPT * tid + i]); cnt += cw[i]; }
         u32 total;
         u32 o = block_excl_scan_256(cnt, S.misc, total);
         for (int i = 0; i < nw; ++i) { S.a.c.cpre[WPT * tid + i] = (u16)o; o += cw[i]; }
+        __syncthreads();
         return total;
     };
     // one round of candidates = whole words, at most QCAP candidates, starting at rank c0; list[] <- their END positions.
@@ -431,7 +414,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
             const u32 n = bs_popc(w);
             if (n == 0 || r < c0 || r + n > c0 + QCAP) continue;
             hi = r + n;
-            while (w) { const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b); S.b.list[r - c0] = (u16)(32 * D + b - (BS_B - 1)); ++r; }
+            while (w) { const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b); S.a.c.list[r - c0] = (u16)(32 * D + b - (BS_B - 1)); ++r; }
         }
         if (hi > c0) atomicMax(&S.misc[16], hi);
         __syncthreads();
@@ -442,78 +425,134 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         while (S.rpre[w + 1] <= r) ++w;
         return 32 * w + bs_select_msb(S.kw[w], r - S.rpre[w]);
     };
+    const u32 n_rs = rh_ - rl + 1;                                     // reads that touch the staged range
     auto eval = [&](u32 e, CandOut& o) -> bool {                       // exact: src/read.rs:196-208 for the l-mer ending at dense position e
         const u32 wi = e >> 5, s = e & 31;
         const u32* dw = S.dense + 2 * (DPAD + wi);
         const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);
-        const u64 h = bs_exact_hash(v0, v1, L, a.t4);
+        const u64 h = bs_exact_hash<BS_GS>(v0, v1, L, S.t3);
         if (h > a.bound) return false;
-        const int64_t abs_end = raw0 + dense_to_raw(e);
-        const u32 r = find_read(a.offsets, rl, rh_, (u64)abs_end);
-        const int64_t q0 = (int64_t)a.offsets[r];
+        const int64_t rel_end = dense_to_raw(e);
+        u32 r; int64_t q0;                                             // the read holding the END position; q0: its start, tile-relative
+        if (n_rs <= RS_CAP) {
+            u32 i = 0;
+            while (i + 1 < n_rs && S.rs_rel[i + 1] <= rel_end) ++i;
+            r = rl + i; q0 = S.rs_rel[i];
+        } else { r = find_read(a.offsets, rl, rh_, (u64)(raw0 + rel_end)); q0 = (int64_t)a.offsets[r] - raw0; }
         const u32 sd = e - (u32)(L - 1);
-        if (q0 > raw0) {                                               // the read starts inside the staged range: the l-mer must not cross it
-            const u32 rel = (u32)(q0 - raw0), w = rel >> 5, b = rel & 31;
+        if (q0 > 0) {                                                  // the read starts inside the staged range: the l-mer must not cross it
+            const u32 w = (u32)q0 >> 5, b = (u32)q0 & 31;
             const u32 ds = S.rpre[w] + (b ? bs_popc(S.kw[w] >> (32 - b)) : 0u);
             if (sd < ds) return false;
         }
-        o.hash = h; o.pos = (u32)(raw0 + dense_to_raw(sd) - q0); o.read = r + a.read_base;
+        o.hash = h; o.pos = (u32)((int64_t)dense_to_raw(sd) - q0); o.read = r + a.read_base;
         return true;
     };
+    auto clear_bit = [&](u32 e) { const u32 x = e + BS_B - 1; atomicAnd(&S.a.c.cand[x >> 5], ~(0x80000000u >> (x & 31))); };
+    auto rank_of = [&](u32 e) -> u32 { const u32 x = e + BS_B - 1, D = x >> 5, b = x & 31; return S.a.c.cpre[D] + (b ? bs_popc(S.a.c.cand[D] >> (32 - b)) : 0u); };
 
-    const u32 n_cand = count_words(true);
-    CandOut keep[QCAP / TT]; u32 keep_ok = 0;
-    const bool one_round = n_cand <= QCAP;
-    // pass A: validate every candidate, clear the bits of the ones that fail (rounds are whole words: later rounds unaffected)
-    for (u32 c0 = 0; c0 < n_cand;) {
-        const u32 c1 = build_list(c0);
+    const u32 n_cand = S.misc[17];
+    if (n_cand <= QCAP) {
+        // every candidate sits in the list (any order): evaluate, drop the failures from the bitmap, rank the survivors there
+        CandOut keep[QCAP / TT]; u32 keep_ok = 0;
 #pragma unroll
         for (int i = 0; i < QCAP / TT; ++i) {
             const u32 j = tid + TT * i;
-            if (j < c1 - c0) {
-                const u32 e = S.b.list[j];
-                CandOut o;
-                const bool ok = eval(e, o);
-                if (ok && one_round) { keep[i] = o; keep_ok |= 1u << i; }
-                if (!ok) { const u32 x = e + BS_B - 1; atomicAnd(&S.a.c.cand[x >> 5], ~(0x80000000u >> (x & 31))); }
-            }
+            if (j < n_cand) { const u32 e = S.a.c.list[j]; if (eval(e, keep[i])) keep_ok |= 1u << i; else clear_bit(e); }
         }
         __syncthreads();
-        c0 = c1;
-    }
-    MDBG_STAMP(4);
-    const u32 nv = n_cand ? count_words(false) : 0;
-    if (tid < 64) {
-        const u64 excl = lookback_publish(a.tstate, gt, nv, a.out_base);
-        if (tid == 0) { S.misc[14] = (u32)excl; S.misc[15] = (u32)(excl >> 32); if (gt == a.n_tiles - 1) *a.total_out = excl + nv; }
-    }
-    __syncthreads();
-    const u64 base = (u64)S.misc[14] | ((u64)S.misc[15] << 32);
-    if (one_round) {
-        // ranks among the survivors: position of the candidate's bit in the refined bitmap
+        MDBG_STAMP(4);
+        const u32 nv = n_cand ? count_words() : 0;
+        MDBG_STAMP(5);
 #pragma unroll
-        for (int i = 0; i < QCAP / TT; ++i) if ((keep_ok >> i) & 1u) {
-            const u32 e = S.b.list[tid + TT * i], x = e + BS_B - 1, D = x >> 5, b = x & 31;
-            const u64 idx = base + S.a.c.cpre[D] + (b ? bs_popc(S.a.c.cand[D] >> (32 - b)) : 0u);
-            if (idx < a.out_cap) { a.out_hash[idx] = keep[i].hash; a.out_pos[idx] = keep[i].pos; a.out_read[idx] = keep[i].read; }
-        }
+        for (int i = 0; i < QCAP / TT; ++i) if ((keep_ok >> i) & 1u) put_rec(a, slab, rank_of(S.a.c.list[tid + TT * i]), keep[i].hash, keep[i].pos, keep[i].read);
+        if (tid == 0) { put_count(a, gt, nv); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; } }
     } else {
-        for (u32 c0 = 0; c0 < nv;) {
+        // dense settings: rounds of whole bitmap words; pass A validates, pass B (after the recount) writes
+        __syncthreads();
+        const u32 n_all = count_words();
+        for (u32 c0 = 0; c0 < n_all;) {
             const u32 c1 = build_list(c0);
-#pragma unroll
-            for (int i = 0; i < QCAP / TT; ++i) {
-                const u32 j = tid + TT * i;
-                if (j < c1 - c0) {
-                    CandOut o;
-                    if (eval(S.b.list[j], o)) { const u64 idx = base + c0 + j; if (idx < a.out_cap) { a.out_hash[idx] = o.hash; a.out_pos[idx] = o.pos; a.out_read[idx] = o.read; } }
-                }
-            }
+            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; const u32 e = S.a.c.list[j]; if (!eval(e, o)) clear_bit(e); }
             __syncthreads();
             c0 = c1;
         }
+        MDBG_STAMP(4);
+        const u32 nv = count_words();
+        MDBG_STAMP(5);
+        for (u32 c0 = 0; c0 < nv;) {
+            const u32 c1 = build_list(c0);
+            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; if (eval(S.a.c.list[j], o)) put_rec(a, slab, c0 + j, o.hash, o.pos, o.read); }
+            __syncthreads();
+            c0 = c1;
+        }
+        if (tid == 0) { put_count(a, gt, nv); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_all; a.dbg[(size_t)gt * 16 + 10] = nv; } }
     }
-    MDBG_STAMP(5);
+    MDBG_STAMP(7);
 #undef MDBG_STAMP
+}
+
+// ---- gather: per-tile records -> final position-ordered arrays ---------------------------------------------
+// exclusive scan of n_valid over the tiles (carry[0] in/out = running total), three small kernels:
+// sums of 1024-tile blocks, scan of the block sums by one workgroup, per-block scan + base.
+__global__ __launch_bounds__(1024) void tile_scan_sums_kernel(u32 n, const u32* __restrict__ n_valid, u64* __restrict__ block_sum) {
+    __shared__ u32 ws[16];
+    const u32 i = blockIdx.x * 1024 + threadIdx.x;
+    u32 v = i < n ? n_valid[i] : 0;
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 t = 0; for (int q = 0; q < 16; ++q) t += ws[q]; block_sum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void tile_scan_top_kernel(u32 n_blocks, u64* __restrict__ block_sum, u64* __restrict__ carry) {
+    __shared__ u64 ws[16]; __shared__ u64 run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) run = carry[0];
+    __syncthreads();
+    for (u32 i0 = 0; i0 < n_blocks; i0 += 1024) {
+        const u32 i = i0 + tid;
+        const u64 v = i < n_blocks ? block_sum[i] : 0;
+        u64 inc = v;
+        for (int d = 1; d < 64; d <<= 1) { const u64 o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) ws[wv] = inc;
+        __syncthreads();
+        u64 b = run, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wv) b += ws[q]; tot += ws[q]; }
+        if (i < n_blocks) block_sum[i] = b + inc - v;
+        __syncthreads();
+        if (tid == 0) run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) carry[0] = run;
+}
+__global__ __launch_bounds__(1024) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base) {
+    __shared__ u32 ws[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 i = blockIdx.x * 1024 + tid;
+    const u32 v = i < n ? n_valid[i] : 0;
+    const u32 inc = wave_incl_scan(v);
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    u64 b = block_base[blockIdx.x];
+    for (int q = 0; q < wv; ++q) b += ws[q];
+    if (i < n) tile_base[i] = b + inc - v;
+}
+// one wave per tile of the launch (tiles [tile0, tile0 + n)); a tile whose records did not fit is skipped (the host retries)
+__global__ __launch_bounds__(256) void gather_kernel(u32 tile0, u32 n, const Rec* __restrict__ slab, u32 slab_cap, const u32* __restrict__ n_valid,
+                                                     const u64* __restrict__ tile_base, u64* __restrict__ out_hash,
+                                                     u32* __restrict__ out_pos, u32* __restrict__ out_read, u64 out_cap) {
+    const u32 b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const u32 lane = threadIdx.x & 63;
+    const u32 nv = n_valid[tile0 + b];
+    if (!nv || nv > slab_cap) return;
+    const Rec* s = slab + (size_t)b * slab_cap;
+    const u64 base = tile_base[b];
+    for (u32 j = lane; j < nv; j += 64) {
+        const Rec r = s[j];
+        const u64 idx = base + j;
+        if (idx < out_cap) { out_hash[idx] = r.hash; out_pos[idx] = r.pos; out_read[idx] = r.read; }
+    }
 }
 
 // per-read offsets into the ordered minimizer arrays: off[slot] = first i with mread[i] >= slot, for the batch's
@@ -572,13 +611,13 @@ void launch_alphabet_rule(const SketchArgs& a, unsigned long long* which, hipStr
     else hipLaunchKernelGGL(alphabet_rule_kernel<PlaneSrc>, g, b, 0, s, PlaneSrc{a.planes, a.exc_pos, a.exc_val, a.n_exc}, a.offsets, a.n_reads, a.l, a.hpc, which);
 }
 
-template <int L> static void launch_bs(const SketchArgs& a, hipStream_t s) { hipLaunchKernelGGL(sketch_bs_kernel<L>, dim3(a.n_tiles), dim3(TT), 0, s, a); }
-// one launch covers the whole batch (launch boundaries would only re-synchronise the workgroups' phases)
-void launch_sketch(const SketchArgs& a, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
-    if (!a.n_tiles) return;
+template <int L> static void launch_bs(const SketchArgs& a, u32 n_wg, hipStream_t s) { hipLaunchKernelGGL(sketch_bs_kernel<L>, dim3(n_wg), dim3(TT), 0, s, a); }
+// one launch covers the whole batch (launch boundaries would only re-synchronise the workgroups' phases); n_wg = tiles to run
+void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+    if (!n_wg) return;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (a.l) {
-#define MDBG_L(n) case n: launch_bs<n>(a, s); break;
+#define MDBG_L(n) case n: launch_bs<n>(a, n_wg, s); break;
         MDBG_L(2) MDBG_L(3) MDBG_L(4) MDBG_L(5) MDBG_L(6) MDBG_L(7) MDBG_L(8) MDBG_L(9) MDBG_L(10) MDBG_L(11) MDBG_L(12) MDBG_L(13)
         MDBG_L(14) MDBG_L(15) MDBG_L(16) MDBG_L(17) MDBG_L(18) MDBG_L(19) MDBG_L(20) MDBG_L(21) MDBG_L(22) MDBG_L(23) MDBG_L(24)
         MDBG_L(25) MDBG_L(26) MDBG_L(27) MDBG_L(28) MDBG_L(29) MDBG_L(30) MDBG_L(31) MDBG_L(32)
@@ -594,6 +633,17 @@ void launch_read_offsets(const u32* mread, u64 m0, u64 m1, u32 slot0, u32 n_read
 }
 
 // hash_bound = floor(density * 2^64), saturating (src/read.rs:183)
+// scan + gather of the tiles [tile0, tile0 + n) of one launch; carry[0] in/out = running total of minimizers
+void launch_gather(u32 tile0, u32 n, const Rec* slab, u32 slab_cap, const u32* n_valid, u64* scan_tmp, u64* tile_base, u64* carry,
+                   u64* out_hash, u32* out_pos, u32* out_read, u64 out_cap, hipStream_t s) {
+    if (!n) return;
+    const u32 nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(1024), 0, s, n, n_valid + tile0, scan_tmp);
+    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(1024), 0, s, nb, scan_tmp, carry);
+    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(1024), 0, s, n, n_valid + tile0, scan_tmp, tile_base);
+    hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tile0, n, slab, slab_cap, n_valid, tile_base, out_hash, out_pos, out_read, out_cap);
+}
+
 u64 make_hash_bound(double density) {
     const double v = density * 18446744073709551616.0;
     return !(v > 0.0) ? 0 : (v >= 18446744073709551616.0 ? ~0ull : (u64)v);

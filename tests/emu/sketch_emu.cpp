@@ -149,7 +149,7 @@ void tile(const u8* bases, int64_t nb, const u64* offsets, u32 n_reads, bool hpc
             const u32 wi = e >> 5, s = e & 31;
             const u32* dw = dense.data() + 2 * (DPAD + wi);
             const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);
-            const u64 h = bs_exact_hash(v0, v1, L, t4);
+            const u64 h = bs_exact_hash<BS_GS>(v0, v1, L, t4);
             if (h > bound) continue;
             const int64_t abs_end = raw0 + dense_to_raw(e);
             const u32 r = find_read(offsets, 0, n_reads - 1, (u64)abs_end);
@@ -177,7 +177,7 @@ int64_t emu_sketch(const u8* bases, u64 n_bases, const u64* offsets, u64 n_reads
     if (!fn || !n_reads) return fn ? 0 : -1;
     const double v = density * 18446744073709551616.0;
     const u64 bound = !(v > 0.0) ? 0 : (v >= 18446744073709551616.0 ? ~0ull : (u64)v);
-    u64 t4[512]; bs_make_t4(t4);
+    u64 t4[2 << (2 * BS_GS)]; bs_make_table<BS_GS>(t4);
     Out out; *n_slow = 0; *n_cand = 0;
     const u64 n_tiles = (n_bases + TILE_STRIDE - 1) / TILE_STRIDE;
     for (u64 t = 0; t < n_tiles; ++t) fn(bases, (int64_t)n_bases, offsets, (u32)n_reads, hpc != 0, bound, t4, (u32)t, out, n_slow, n_cand);
