@@ -199,20 +199,35 @@ BS_HD void bs_strand_planes(bs_u32 c0, bs_u32 c1, bs_u32 p0, bs_u32 p1, bs_u32 q
 // W: this word's planes, Wp: the planes of the word before (neighbouring lane).  bmask[i] is all-ones iff bit
 // (63 - i) of the bound is set.  The result is the candidate plane for END positions shifted by BS_B - 1:
 // bit for stream position x reports the l-mer ending at x - (BS_B - 1).
-template <bool FWD>
+// ZERO: the top BS_B bits of the bound are all zero (density < 2^-BS_B, the usual setting): the comparison is
+// "all BS_B hash bits are zero", a plain OR-reduction.
+template <bool FWD, bool ZERO>
 BS_HD bs_u32 bs_strand_compare(const bs_u32 W[BS_B], const bs_u32 Wp[BS_B], bs_u32 inv, const bs_u32 bmask[BS_B]) {
+    bs_u32 x[BS_B];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < BS_B; ++i) {
+        // forward: out_b is W_b delayed by (63 - b) = i already; bring every bit to the common delay BS_B - 1
+        const int d = FWD ? (BS_B - 1) - i : i;
+        x[i] = d == 0 ? W[i] : bs_alignbit(Wp[i], W[i], (bs_u32)d);
+        if ((inv >> i) & 1) x[i] = ~x[i];
+    }
+    if (ZERO) {
+        bs_u32 any = x[0];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 1; i < BS_B; ++i) any |= x[i];
+        return ~any;
+    }
     bs_u32 le = 0xFFFFFFFFu;
     // from the least significant evaluated bit up: le = bound_bit ? (le | ~x) : (le & ~x)
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int i = BS_B - 1; i >= 0; --i) {
-        const int b = 63 - i;
-        // forward: out_b is W_b delayed by (63 - b) already; bring every bit to the common delay BS_B - 1
-        const int d = FWD ? (BS_B - 1) - (63 - b) : 63 - b;
-        bs_u32 x = d == 0 ? W[i] : bs_alignbit(Wp[i], W[i], (bs_u32)d);
-        if ((inv >> i) & 1) x = ~x;
-        const bs_u32 nx = ~x;
+        const bs_u32 nx = ~x[i];
         le = (le & nx) | (bmask[i] & (le | nx));
     }
     return le;

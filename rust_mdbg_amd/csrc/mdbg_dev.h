@@ -48,13 +48,17 @@ __device__ inline bool in_hpc_set(u8 c) {
 }
 
 // ---- wave / block scans (wave = 64 lanes) -------------------------------------------------------
+// inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips): 4 steps inside each row of 16,
+// then row 15 -> rows 1/3 and lane 31 -> rows 2,3
 __device__ inline u32 wave_incl_scan(u32 v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+#define MDBG_DPP_ADD(ctrl, rmask) v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, true)
+    MDBG_DPP_ADD(0x111, 0xF);      // row_shr:1
+    MDBG_DPP_ADD(0x112, 0xF);      // row_shr:2
+    MDBG_DPP_ADD(0x114, 0xF);      // row_shr:4
+    MDBG_DPP_ADD(0x118, 0xF);      // row_shr:8
+    MDBG_DPP_ADD(0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+    MDBG_DPP_ADD(0x143, 0xC);      // row_bcast:31 into rows 2 and 3
+#undef MDBG_DPP_ADD
     return v;
 }
 // exclusive scan over a 256-thread block; tmp must hold 5 u32 in LDS; every thread gets `total`

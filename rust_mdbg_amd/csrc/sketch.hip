@@ -42,7 +42,8 @@ struct SketchArgs {
     u32 read_base;               // slot index of the batch's first read in the resident store
     u64 bound; u32 l; u32 hpc; u32 btop;   // btop = top BS_B bits of the bound
     u32 force_slow;              // MDBG_FLAG_FORCE_GENERIC: every tile takes the generic exact walker
-    u64* dbg;                    // diagnostic: per-tile phase timestamps [n_tiles][8] (null in production)
+    u64* dbg;                    // diagnostic: per-tile phase timestamps [n_tiles][16] (null in production)
+    u32 stop_phase;              // diagnostic (MDBG_STOP_PHASE): tiles stop after this phase and report no minimizers (0: run everything)
 };
 
 // largest r in [lo, hi] with off[r] <= p
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         __syncthreads();
     }
     MDBG_STAMP(1);
+    if (a.stop_phase == 1) { if (tid == 0) a.n_valid[gt] = x0[0] == 0x12345u; return; }
 
     // ---- phase 2: keep masks, compaction, dense stream ----------------------------------------------------------------
     u32 kw[WPT], n_kept[WPT], mine = 0;
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     }
     __syncthreads();
     MDBG_STAMP(2);
+    if (a.stop_phase == 2) { if (tid == 0) a.n_valid[gt] = 0; return; }
     const u32 Hh = S.misc[11];
     const bool true_start = raw0 <= first_base;       // the stream begins inside this tile: nothing to look back at
     if (S.misc[8] || (!true_start && Hh < (u32)L)) {
@@ -357,6 +360,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
 #pragma unroll
         for (int i = 0; i < BS_B; ++i) bmask[i] = ((a.btop >> (BS_B - 1 - i)) & 1u) ? 0xFFFFFFFFu : 0u;
         const u32 n_steps = (n_out + 62) / 63;
+        const bool zero_test = a.btop == 0;                          // density < 2^-BS_B: "all evaluated hash bits are zero"
         for (u32 st = wv; st < n_steps; st += TT / 64) {
             const int D = (int)(63 * st) + lane - 1;                  // lane 0 recomputes the word before the step's first
             const u32* dw = S.dense + 2 * (DPAD + (D < RW + 3 ? D : RW + 3));     // words past the stream are zero; their results are dropped
@@ -367,11 +371,11 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
             bs_strand_planes<L, true>(c.x, c.y, p.x, p.y, q.x, q.y, W, inv);
 #pragma unroll
             for (int i = 0; i < BS_B; ++i) Wp[i] = dpp_wave_shr1(W[i]);
-            u32 cand = bs_strand_compare<true>(W, Wp, inv, bmask);
+            u32 cand = zero_test ? bs_strand_compare<true, true>(W, Wp, inv, bmask) : bs_strand_compare<true, false>(W, Wp, inv, bmask);
             bs_strand_planes<L, false>(c.x, c.y, p.x, p.y, q.x, q.y, W, inv);
 #pragma unroll
             for (int i = 0; i < BS_B; ++i) Wp[i] = dpp_wave_shr1(W[i]);
-            cand |= bs_strand_compare<false>(W, Wp, inv, bmask);
+            cand |= zero_test ? bs_strand_compare<false, true>(W, Wp, inv, bmask) : bs_strand_compare<false, false>(W, Wp, inv, bmask);
             if (lane && (u32)D < n_out) {
                 cand &= range_mask((int64_t)e_lo + BS_B - 1 - 32 * (int64_t)D, (int64_t)H + BS_B - 1 - 32 * (int64_t)D);
                 S.a.c.cand[D] = cand;
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     }
     __syncthreads();
     MDBG_STAMP(3);
+    if (a.stop_phase == 3) { if (tid == 0) a.n_valid[gt] = 0; return; }
 
     // ---- phase 4: exact evaluation, ranks, records -------------------------------------------------------------------
     const int nw = tid == TT - 1 ? WPT + 1 : WPT;                     // words 4*tid .. ; the last thread also takes word RW

@@ -127,7 +127,8 @@ void tile(const u8* bases, int64_t nb, const u64* offsets, u32 n_reads, bool hpc
             u32 Wf[BS_B], Wr[BS_B], invf, invr;
             bs_strand_planes<L, true>(dw[0], dw[1], dw[-2], dw[-1], q0, q1, Wf, invf);
             bs_strand_planes<L, false>(dw[0], dw[1], dw[-2], dw[-1], q0, q1, Wr, invr);
-            if (D >= 0) cand[D] = bs_strand_compare<true>(Wf, Wf_prev, invf, bmask) | bs_strand_compare<false>(Wr, Wr_prev, invr, bmask);
+            if (D >= 0) cand[D] = btop == 0 ? (bs_strand_compare<true, true>(Wf, Wf_prev, invf, bmask) | bs_strand_compare<false, true>(Wr, Wr_prev, invr, bmask))
+                                       : (bs_strand_compare<true, false>(Wf, Wf_prev, invf, bmask) | bs_strand_compare<false, false>(Wr, Wr_prev, invr, bmask));
             memcpy(Wf_prev, Wf, sizeof Wf); memcpy(Wr_prev, Wr, sizeof Wr);
         }
     }
