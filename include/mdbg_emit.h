@@ -54,6 +54,15 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
 int mdbg_reader_is_fasta(const mdbg_reader* r);
 void mdbg_reader_close(mdbg_reader* r);
 
+/* ---- host packer for mdbg_ingest_batch_packed (layout: mdbg_packed_batch in mdbg_hip.h) -----------------------------
+ * Replaces the per-read String copy of src/main.rs:733-739: the reader's ASCII batch is squeezed to 2 bits per base
+ * (two 32-bit planes per 32 bases) before it crosses PCIe.  words: (n_bases + 31) / 32 entries.  Bytes outside "ACGT" go
+ * to exc_pos / exc_val (ascending; room for exc_cap entries); *n_exc is their number, MDBG_E_CAPACITY if it exceeds exc_cap
+ * (the words are complete either way).  threads <= 1: the calling thread only. */
+uint64_t mdbg_packed_words(uint64_t n_bases);
+int mdbg_pack_reads(const uint8_t* bases, uint64_t n_bases, uint64_t* words, uint64_t* exc_pos, uint8_t* exc_val,
+                    uint64_t exc_cap, uint64_t* n_exc, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,8 @@
  *     (= Read::extract_density  src/read.rs:176-211, encode_rle src/read.rs:157-174, nthash::NtHashIterator,
  *        the k-min-mer window loop src/main.rs:756-781, KmerVec::normalize src/kmer_vec.rs:34-39 and
  *        add_kminmer's counting upsert src/main.rs:632-691)
+ *   mdbg_ingest_batch_packed   the same over reads packed 2 bits per base by the host (mdbg_pack_reads of mdbg_emit.h), replacing
+ *                          the per-read String copies of src/main.rs:733-739: a quarter of the bytes over PCIe and through HBM
  *   mdbg_sketch_only       Read::extract (density scheme)                              src/read.rs:85-90,176-211
  *   mdbg_finalize          abundance filter + read-only view of dbg_nodes              src/main.rs:922-929,1014-1016
  *                          + what the .sequences line of a node is built from          src/main.rs:693-708
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDBG_ABI_VERSION 1
+#define MDBG_ABI_VERSION 2
 
 enum {
     MDBG_OK = 0,
@@ -91,7 +93,7 @@ typedef struct mdbg_nodes {
 
 typedef struct mdbg_stats {
     uint64_t n_reads, n_bases, n_minimizers, n_windows, n_distinct, table_capacity;
-    uint64_t n_slow_tiles;      /* tiles that took the generic exact path (N, dense candidates, l > 14) */
+    uint64_t n_slow_tiles;      /* tiles that took the generic exact walker (a byte outside ACGT, or > 200 bases of one homopolymer in front of the tile) */
     uint64_t n_tiles;
     double ms_sketch, ms_insert, ms_finalize; /* device time (HIP events) accumulated over calls since create/reset */
     double ms_sketch_tile;      /* of ms_sketch: time inside sketch_tile_kernel launches only (HIP events around each launch) */
@@ -119,6 +121,33 @@ int mdbg_ingest_batch(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offse
  * middle of a larger buffer). */
 int mdbg_ingest_batch_device(mdbg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
                              uint64_t n_bases, uint64_t first_read_ordinal);
+
+/* ---- 2-bit packed input -------------------------------------------------------------------------------------
+ * Layout: one uint64_t per 32 bases of the concatenated batch, word w = bases [32w, 32w + 32): bit i (0..31) = bit 1 of the
+ * ASCII byte of base 32w + i, bit 32 + i = bit 2 of that byte, i.e. the two bits of the code (ascii >> 1) & 3 (A=0 C=1 T=2
+ * G=3) as two 32-bit planes.  Bits past the last base are ignored.  Every byte that is not one of "ACGT" (N, lower case,
+ * anything else) is listed in the exception side-list (position in the batch ascending, original byte); its two bits in
+ * the words are ignored.  The GPU kernel reads the planes as they are (no unpacking step) and treats tiles that hold an
+ * exception with the generic exact walker, so N hashes as 0 and other bytes raise MDBG_E_ALPHABET under the reference's
+ * rule, exactly as with ASCII input.  mdbg_pack_reads (mdbg_emit.h, host) and mdbg_pack_device (below) produce the layout. */
+typedef struct mdbg_packed_batch {
+    const uint64_t* words;      /* (n_bases + 31) / 32 words, 16-byte aligned when in device memory */
+    const uint64_t* offsets;    /* n_reads + 1 offsets in BASES into the concatenated batch */
+    uint64_t n_reads;
+    const uint64_t* exc_pos;    /* n_exc positions, ascending */
+    const uint8_t* exc_val;     /* n_exc bytes */
+    uint64_t n_exc;
+} mdbg_packed_batch;
+/* HOST buffers (offsets[0] must be 0); same semantics and thread-safety as mdbg_ingest_batch. */
+int mdbg_ingest_batch_packed(mdbg_ctx* ctx, const mdbg_packed_batch* batch, uint64_t first_read_ordinal);
+/* DEVICE buffers; n_bases = offsets[n_reads].  _sketch_ runs the sketch stage only (see mdbg_sketch_device). */
+int mdbg_ingest_batch_packed_device(mdbg_ctx* ctx, const mdbg_packed_batch* batch, uint64_t n_bases, uint64_t first_read_ordinal);
+int mdbg_sketch_packed_device(mdbg_ctx* ctx, const mdbg_packed_batch* batch, uint64_t n_bases, uint64_t first_read_ordinal);
+/* ASCII -> packed on the device (DEVICE buffers; d_words holds (n_bases + 31) / 32 words).  Exceptions are appended to
+ * d_exc_pos / d_exc_val (room for exc_cap entries, sorted by position on return); *n_exc is their number — if it exceeds
+ * exc_cap the lists are incomplete and the call returns MDBG_E_CAPACITY. */
+int mdbg_pack_device(mdbg_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uint64_t* d_words, uint64_t* d_exc_pos,
+                     uint8_t* d_exc_val, uint64_t exc_cap, uint64_t* n_exc);
 
 /* The Read::extract seam alone: sketches a batch (HOST buffers) without touching the node table.
  * Outputs (library-owned host memory, valid until the next call on ctx): hashes[m] = Read.transformed,

@@ -64,6 +64,11 @@ class EdgeList(C.Structure):
                 ("o2", C.POINTER(C.c_uint8)), ("overlap", C.POINTER(C.c_uint32)), ("presimp_removed", C.c_uint64)]
 
 
+class PackedBatch(C.Structure):          # mdbg_packed_batch
+    _fields_ = [("words", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64), ("exc_pos", C.c_void_p),
+                ("exc_val", C.c_void_p), ("n_exc", C.c_uint64)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_reads", C.c_uint64), ("mean_len", C.c_uint32),
                 ("sd_len", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("err_ppm", C.c_uint32),
@@ -75,7 +80,8 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
-           "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device"]
+           "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
+           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device"]
 
 
 def lib_path():
@@ -109,6 +115,10 @@ def load_library():
     L.mdbg_ingest_batch_device.argtypes = [vp, vp, vp, u64, u64, u64]
     L.mdbg_sketch_device.argtypes = [vp, vp, vp, u64, u64, u64]
     L.mdbg_insert_resident.argtypes = [vp]
+    L.mdbg_ingest_batch_packed.argtypes = [vp, C.POINTER(PackedBatch), u64]
+    L.mdbg_ingest_batch_packed_device.argtypes = [vp, C.POINTER(PackedBatch), u64, u64]
+    L.mdbg_sketch_packed_device.argtypes = [vp, C.POINTER(PackedBatch), u64, u64]
+    L.mdbg_pack_device.argtypes = [vp, vp, u64, vp, vp, vp, u64, C.POINTER(u64)]
     L.mdbg_sketch_only.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(u64)]
     L.mdbg_finalize.argtypes = [vp, C.POINTER(Nodes)]
     L.mdbg_finalize_device.argtypes = [vp, C.POINTER(Nodes)]
@@ -145,7 +155,8 @@ def load_library():
               "mdbg_finalize", "mdbg_finalize_device", "mdbg_reset", "mdbg_get_stats", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync",
               "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device", "mdbg_routed_export", "mdbg_resolve_first",
               "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve", "mdbg_set_partition", "mdbg_sketch_view",
-              "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end"):
+              "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end", "mdbg_ingest_batch_packed",
+              "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device"):
         getattr(L, f).restype = C.c_int
     _LIB = L
     return L
@@ -202,6 +213,31 @@ class Mdbg:
 
     def insert_resident(self):
         self._chk(self.L.mdbg_insert_resident(self.h))
+
+    # --- 2-bit packed input (mdbg_packed_batch) ---
+    def ingest_packed(self, packed, first_read_ordinal=0):
+        """packed: dict from rust_mdbg_amd.emit.pack_reads (host arrays words / offsets / exc_pos / exc_val)"""
+        b = PackedBatch(packed["words"].ctypes.data, packed["offsets"].ctypes.data, len(packed["offsets"]) - 1,
+                        packed["exc_pos"].ctypes.data, packed["exc_val"].ctypes.data, len(packed["exc_pos"]))
+        self._chk(self.L.mdbg_ingest_batch_packed(self.h, C.byref(b), first_read_ordinal))
+
+    def ingest_packed_device(self, d_words, d_offsets, n_reads, n_bases, first_read_ordinal=0, d_exc_pos=0, d_exc_val=0, n_exc=0, sketch_only=False):
+        b = PackedBatch(d_words, d_offsets, n_reads, d_exc_pos, d_exc_val, n_exc)
+        fn = self.L.mdbg_sketch_packed_device if sketch_only else self.L.mdbg_ingest_batch_packed_device
+        self._chk(fn(self.h, C.byref(b), n_bases, first_read_ordinal))
+
+    def pack_device(self, d_bases, n_bases, d_words, d_exc_pos=0, d_exc_val=0, exc_cap=0):
+        n = C.c_uint64()
+        self._chk(self.L.mdbg_pack_device(self.h, d_bases, n_bases, d_words, d_exc_pos, d_exc_val, exc_cap, C.byref(n)))
+        return n.value
+
+    def store_sketch(self):
+        """host copy of the whole resident sketch store: hashes, positions, per-read offsets"""
+        v = self.sketch_view()
+        m, n = int(v.n_minimizers), int(v.n_reads)
+        return dict(hashes=self.to_host(v.d_hashes, m * 8, np.uint64) if m else np.zeros(0, np.uint64),
+                    pos=self.to_host(v.d_positions, m * 4, np.uint32).astype(np.uint64) if m else np.zeros(0, np.uint64),
+                    off=self.to_host(v.d_read_offsets, (n + 1) * 8, np.uint64))
 
     # --- Read::extract seam ---
     def sketch(self, bases, offsets):

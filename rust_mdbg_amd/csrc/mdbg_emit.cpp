@@ -301,3 +301,74 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
 void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->f) gzclose(r->f); delete r; } }
 
 }  // extern "C"
+
+// ---- host packer: ASCII -> two 32-bit planes per 32 bases (mdbg_packed_batch of mdbg_hip.h) -------------------------
+#include <immintrin.h>
+#include <thread>
+namespace {
+// planes of 32 bases at p (n <= 32 valid): bit i of lo / hi = bit 1 / bit 2 of byte i; *bad = mask of bytes outside ACGT
+inline void pack32_scalar(const uint8_t* p, unsigned n, uint32_t& lo, uint32_t& hi, uint32_t& bad) {
+    lo = hi = bad = 0;
+    for (unsigned i = 0; i < n; ++i) {
+        const uint8_t c = p[i];
+        lo |= (uint32_t)((c >> 1) & 1u) << i; hi |= (uint32_t)((c >> 2) & 1u) << i;
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') bad |= 1u << i;
+    }
+}
+__attribute__((target("avx2"))) inline void pack32_avx2(const uint8_t* p, uint32_t& lo, uint32_t& hi, uint32_t& bad) {
+    const __m256i v = _mm256_loadu_si256((const __m256i*)p);
+    lo = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 6));      // bit 1 of every byte -> its sign bit
+    hi = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 5));      // bit 2
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(v, _mm256_set1_epi8('C'))),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(v, _mm256_set1_epi8('T'))));
+    bad = ~(uint32_t)_mm256_movemask_epi8(ok);
+}
+inline void pack32_sse2(const uint8_t* p, uint32_t& lo, uint32_t& hi, uint32_t& bad) {
+    lo = hi = 0; uint32_t okm = 0;
+    for (int h = 0; h < 2; ++h) {
+        const __m128i v = _mm_loadu_si128((const __m128i*)(p + 16 * h));
+        lo |= (uint32_t)_mm_movemask_epi8(_mm_slli_epi16(v, 6)) << (16 * h);
+        hi |= (uint32_t)_mm_movemask_epi8(_mm_slli_epi16(v, 5)) << (16 * h);
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, _mm_set1_epi8('A')), _mm_cmpeq_epi8(v, _mm_set1_epi8('C'))),
+                                        _mm_or_si128(_mm_cmpeq_epi8(v, _mm_set1_epi8('G')), _mm_cmpeq_epi8(v, _mm_set1_epi8('T'))));
+        okm |= (uint32_t)_mm_movemask_epi8(ok) << (16 * h);
+    }
+    bad = ~okm;
+}
+struct ExcList { std::vector<uint64_t> pos; std::vector<uint8_t> val; };
+void pack_range(const uint8_t* bases, uint64_t n_bases, uint64_t w0, uint64_t w1, uint64_t* words, ExcList& ex, bool avx2) {
+    for (uint64_t w = w0; w < w1; ++w) {
+        const uint64_t p = w * 32;
+        uint32_t lo, hi, bad;
+        if (p + 32 <= n_bases) { if (avx2) pack32_avx2(bases + p, lo, hi, bad); else pack32_sse2(bases + p, lo, hi, bad); }
+        else pack32_scalar(bases + p, (unsigned)(n_bases - p), lo, hi, bad);
+        words[w] = (uint64_t)lo | ((uint64_t)hi << 32);
+        while (bad) { const unsigned i = (unsigned)__builtin_ctz(bad); bad &= bad - 1; ex.pos.push_back(p + i); ex.val.push_back(bases[p + i]); }
+    }
+}
+}  // namespace
+
+extern "C" {
+uint64_t mdbg_packed_words(uint64_t n_bases) { return (n_bases + 31) / 32; }
+
+int mdbg_pack_reads(const uint8_t* bases, uint64_t n_bases, uint64_t* words, uint64_t* exc_pos, uint8_t* exc_val, uint64_t exc_cap,
+                    uint64_t* n_exc, int threads) {
+    if (!n_exc || (n_bases && (!bases || !words))) return MDBG_E_PARAM;
+    const uint64_t nw = (n_bases + 31) / 32;
+    const bool avx2 = __builtin_cpu_supports("avx2");
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > nw / 4096 + 1) threads = (int)(nw / 4096 + 1);
+    std::vector<ExcList> ex((size_t)threads);
+    if (threads == 1) pack_range(bases, n_bases, 0, nw, words, ex[0], avx2);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t)
+            th.emplace_back([&, t] { pack_range(bases, n_bases, nw * (uint64_t)t / threads, nw * (uint64_t)(t + 1) / threads, words, ex[(size_t)t], avx2); });
+        for (auto& x : th) x.join();
+    }
+    uint64_t n = 0;
+    for (auto& e : ex) for (size_t i = 0; i < e.pos.size(); ++i, ++n) if (n < exc_cap && exc_pos && exc_val) { exc_pos[n] = e.pos[i]; exc_val[n] = e.val[i]; }
+    *n_exc = n;
+    return n > exc_cap ? MDBG_E_CAPACITY : MDBG_OK;
+}
+}  // extern "C"

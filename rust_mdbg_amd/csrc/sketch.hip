@@ -601,6 +601,40 @@ __global__ void tile_flags_kernel(const u64* __restrict__ exc_pos, u32 n_exc, u3
     if (t + 1 < n_tiles && p + HALO_BASES >= (t + 1) * (u64)TILE_STRIDE) flags[t + 1] = 1;      // falls into the next tile's look-back window
 }
 
+// ---- ASCII -> 2-bit planes on the device (mdbg_pack_device) -------------------------------------------------------
+// one thread per 32 bases; bytes outside ACGT are appended (unordered) to the exception list
+__global__ __launch_bounds__(256) void pack_planes_kernel(const u8* __restrict__ bases, u64 n_bases, uint2* __restrict__ words,
+                                                          u64* __restrict__ exc_pos, u8* __restrict__ exc_val, u64 exc_cap,
+                                                          unsigned long long* __restrict__ n_exc) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 p0 = w * 32;
+    if (p0 >= n_bases) return;
+    u32 bad = 0, hp[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const u64 p = p0 + 16 * h;
+        u32 w4[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+        if (p + 16 <= n_bases) { const uint4 q = *(const uint4*)(bases + p); w4[0] = q.x; w4[1] = q.y; w4[2] = q.z; w4[3] = q.w; }
+        else for (int i = 0; i < 16; ++i) if (p + i < n_bases) w4[i >> 2] = (w4[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((u32)bases[p + i] << (8 * (i & 3)));
+        hp[h] = ascii16_to_hp(make_uint4(w4[0], w4[1], w4[2], w4[3]), bad);
+    }
+    // half planes are MSB first; the external layout has base i in bit i
+    words[w] = make_uint2(__brev((hp[0] & 0xFFFF0000u) | (hp[1] >> 16)), __brev((hp[0] << 16) | (hp[1] & 0xFFFFu)));
+    if (bad) {
+        for (int i = 0; i < 32 && p0 + i < n_bases; ++i) {
+            const u8 c = bases[p0 + i];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') {
+                const u64 slot = atomicAdd(n_exc, 1ull);
+                if (slot < exc_cap) { exc_pos[slot] = p0 + i; exc_val[slot] = c; }
+            }
+        }
+    }
+}
+void launch_pack_planes(const u8* bases, u64 n_bases, uint2* words, u64* exc_pos, u8* exc_val, u64 exc_cap, unsigned long long* n_exc, hipStream_t s) {
+    const u64 nw = (n_bases + 31) / 32;
+    if (nw) hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, bases, n_bases, words, exc_pos, exc_val, exc_cap, n_exc);
+}
+
 // ---- host launchers -------------------------------------------------------------------------------
 void launch_bread(const u64* offsets, u32 n_reads, u64 n_bases, u32 n_tiles, u32* bread, hipStream_t s) {
     const u32 n = n_tiles + 2;

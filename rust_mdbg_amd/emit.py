@@ -14,7 +14,7 @@ _LIB = None
 from .api import EdgeList as Edges          # one type for the host emitter's and the GPU's edge list (include/mdbg_hip.h)
 
 
-EXPORTS = ["mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
+EXPORTS = ["mdbg_packed_words", "mdbg_pack_reads", "mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
            "mdbg_seqfile_write_batch", "mdbg_seqfile_close"]
 
 
@@ -34,6 +34,9 @@ def load_library():
         L.mdbg_seqfile_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
         L.mdbg_seqfile_write_batch.argtypes = [vp, C.POINTER(Nodes), vp, vp, C.c_uint64, C.c_uint64]
         L.mdbg_seqfile_close.argtypes = [vp]
+        L.mdbg_packed_words.restype = C.c_uint64
+        L.mdbg_packed_words.argtypes = [C.c_uint64]
+        L.mdbg_pack_reads.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
         _LIB = L
     return _LIB
 
@@ -157,3 +160,23 @@ class Reader:
 
     def __exit__(self, *a):
         self.close()
+
+
+def pack_reads(bases, offsets, threads=1, exc_cap=None):
+    """ASCII batch -> mdbg_packed_batch arrays (host): dict(words, offsets, exc_pos, exc_val, n_bases)"""
+    L = load_library()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(bases)
+    words = np.zeros(int(L.mdbg_packed_words(n)), dtype=np.uint64)
+    cap = 1024 if exc_cap is None else exc_cap
+    while True:
+        ep, ev, ne = np.zeros(cap, np.uint64), np.zeros(cap, np.uint8), C.c_uint64()
+        rc = L.mdbg_pack_reads(bases.ctypes.data, n, words.ctypes.data, ep.ctypes.data, ev.ctypes.data, cap, C.byref(ne), threads)
+        if rc == 0:
+            break
+        if rc != -3 or exc_cap is not None:
+            raise RuntimeError("mdbg_pack_reads failed: %d" % rc)
+        cap = int(ne.value)
+    k = int(ne.value)
+    return dict(words=words, offsets=offsets, exc_pos=np.ascontiguousarray(ep[:k]), exc_val=np.ascontiguousarray(ev[:k]), n_bases=n)

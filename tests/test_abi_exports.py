@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert sorted(api.EXPORTS) == syms
-    assert L.mdbg_abi_version() == 1
+    assert L.mdbg_abi_version() == 2
     assert L.mdbg_strerror(0) == b"ok" and b"ACGTN" in L.mdbg_strerror(-2)
 
 
@@ -28,7 +28,7 @@ def test_emit_library_exports_every_declared_symbol():
     from rust_mdbg_amd import emit
     h = open(os.path.join(ROOT, "include", "mdbg_emit.h")).read()
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
-    syms = sorted(set(re.findall(r"\b(mdbg_(?:emit|seqfile|reader)_[a-z_0-9]+)\s*\(", h)))
+    syms = sorted(set(re.findall(r"\b(mdbg_(?:emit|seqfile|reader|pack|packed)_[a-z_0-9]+)\s*\(", h)))
     L = emit.load_library()
     assert syms == sorted(emit.EXPORTS + emit.READER_EXPORTS)
     for s in syms:
