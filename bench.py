@@ -4,13 +4,15 @@
 A "step" = one pass of the hot path over one batch already resident in HBM:
     reset -> sketch (HPC + ntHash + density filter) -> k-min-mer windows -> counting table -> finalized node table.
 Workload at N=1: BASELINE.json configs[2] (synthetic D. melanogaster: 140 Mb genome @50x, ~15 kb reads, 0.1 % errors,
-k=35 l=12 d=0.002 minabund=2).  For N>1 every rank holds a fixed-size shard of reads of a genome N times larger (weak
-scaling, coverage constant) and the k-min-mer occurrences are routed to their owning rank by key range with one RCCL
-all-to-all per step (rust_mdbg_amd/dist.py).
+k=35 l=12 d=0.002 minabund=2).  For N>1: BASELINE.json configs[3] (synthetic human 3 Gb @52x over 8 GPUs = 375 Mb of genome
+and 19.5 Gbases of reads per GPU, k=35 l=14 d=0.003; weak scaling: the genome grows with N, coverage constant) and the
+k-min-mer occurrences are routed to their owning rank by key range with one RCCL all-to-all per step (rust_mdbg_amd/dist.py).
+The reads sit in HBM in the north star's layout, packed 2 bits per base (--input ascii: one byte per base).
 
-Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_tile_kernel) and is measured live with
-HIP events on the stream the kernel is launched on; `cpu_baseline` is the CPU oracle (a port of the reference's path)
-timed on a bounded sample of the same reads on this box's host cores.
+Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_bs_kernel) as fed in the timed region and
+is measured live with HIP events on the stream the kernel is launched on; `roofline_ascii` is the same kernel fed ASCII
+(b_in = 0.25 vs 1.0 byte per base), measured right after the timed region; `cpu_baseline` is the CPU oracle
+(a port of the reference's path) timed on a bounded sample of the same reads on this box's host cores.
 """
 import argparse
 import json
@@ -30,40 +32,66 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mb", type=float, default=140.0, help="genome size per GPU in Mb")
-    ap.add_argument("--coverage", type=float, default=50.0)
+    ap.add_argument("--genome-mb", type=float, default=None, help="genome size per GPU in Mb (default: 140 at N=1, 375 at N>1)")
+    ap.add_argument("--coverage", type=float, default=None, help="default: 50 at N=1, 52 at N>1")
     ap.add_argument("-k", type=int, default=35)
-    ap.add_argument("-l", type=int, default=12)
-    ap.add_argument("--density", type=float, default=0.002)
+    ap.add_argument("-l", type=int, default=None, help="default: 12 at N=1, 14 at N>1")
+    ap.add_argument("--density", type=float, default=None, help="default: 0.002 at N=1, 0.003 at N>1")
     ap.add_argument("--minabund", type=int, default=2)
+    ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="layout of the reads in HBM during the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
-    ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
-                    help="multi-GPU mode: all-gather of sketches + partitioned table (intra-node default), or all-to-all of k-min-mer records")
+    ap.add_argument("--dist-mode", choices=["replicate", "route"], default="route",
+                    help="multi-GPU mode: all-to-all of k-min-mer records by key range (the north star's exchange), or all-gather of sketches + partitioned table")
     ap.add_argument("--chunks", type=int, default=0,
                     help="multi-GPU: chunks per step; the exchange of chunk c overlaps the sketch of chunk c+1 (0 = 4 in replicate mode, 1 in route mode)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cfg3 = world > 1 or a.force_dist            # BASELINE.json configs[3] shard per GPU, else configs[2]
+    if a.genome_mb is None: a.genome_mb = 375.0 if cfg3 and world > 1 else 140.0
+    if a.coverage is None: a.coverage = 52.0 if cfg3 and world > 1 else 50.0
+    if a.l is None: a.l = 14 if cfg3 and world > 1 else 12
+    if a.density is None: a.density = 0.003 if cfg3 and world > 1 else 0.002
+    return a
 
 
-def pmc_traffic(bases_per_launch, args):
+def pmc_traffic(bases_per_launch, args, fmt=None):
     """HBM bytes per launch of sketch_tile_kernel from the committed rocprofv3 PMC passes of this very command
     (profiles/summarize.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).  PMC counters cannot
     be read from inside the process, so the figure is only reported when the workload of this run matches the profiled one."""
     import glob
+    fmt = fmt or args.input
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             j = json.load(open(p))
             ref = json.load(open(p.replace("_pmc_traffic.json", "_bench.json")))
-            k = j["kernels"]["sketch_tile_kernel<true>"]       # <true> = homopolymer compression on (the bench never passes --reads-already-hpc)
+            k = j["kernels"]["sketch_bs_kernel<%d>" % args.l]
             c = ref["config"]
-            same = (c["k"], c["l"], c["density"], c["minabund"]) == (args.k, args.l, args.density, args.minabund) and \
+            same = (c["k"], c["l"], c["density"], c["minabund"], c.get("input_format")) == (args.k, args.l, args.density, args.minabund, args.input) and \
                 abs(c["bases_per_gpu"] / ref["roofline"]["launches_per_step"] - bases_per_launch) < 1e-6 * bases_per_launch
             if same:
-                return k["hbm_bytes_per_launch"], os.path.relpath(p, ROOT)
+                by = j.get("tile_kernel_by_input") or {}
+                return by.get(fmt, k["hbm_bytes_per_launch"] if not by else None), os.path.relpath(p, ROOT)
         except Exception:
             continue
     return None, None
+
+
+def sq_counters(args):
+    """VALU figures of the tile kernel from the committed SQ counter pass of this very command (profiles/r*_sq_counters.json;
+    rocprofv3 --pmc cannot run inside the process): instructions per base and the share of the kernel's cycles in which a
+    SIMD's VALU is busy."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")), reverse=True):
+        try:
+            j = json.load(open(p))
+            c = j["config"]
+            if (c["k"], c["l"], c["density"], c["minabund"], c["input_format"]) == (args.k, args.l, args.density, args.minabund, args.input):
+                return dict(j["derived"], source=os.path.relpath(p, ROOT))
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
@@ -88,8 +116,9 @@ def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     solid, wins = O.count_threaded(b1, offs[:r1 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
     dt = time.perf_counter() - t
     return {"value": float(offs[r1]) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads (%.3f Gbases) of the same synthetic workload, %d threads, %.1f s; reads in RAM -> filtered node count"
-                      % (r1, float(offs[r1]) / 1e9, cores, dt)}
+            "sample": "first %d reads (%.3f Gbases) of the same synthetic workload, %d threads, %.1f s; reads in RAM -> filtered node count; "
+                      "the port counts into one std::unordered_map per thread and merges them serially at the end, which undersells a %d-core box"
+                      % (r1, float(offs[r1]) / 1e9, cores, dt, cores)}
 
 
 def main():
@@ -121,6 +150,14 @@ def main():
     d_bases, d_off, n_bases = m.synth_reads_device(seed=1, genome_len=genome_len, n_reads=reads_per_gpu, mean_len=15000, sd_len=1500,
                                                    min_len=8000, max_len=25000, err_ppm=1000, first_read=rank * reads_per_gpu)
     first_ordinal = rank * reads_per_gpu
+    packed = args.input == "packed"
+    d_words = None
+    if packed:          # outside the timed region: the batch as the host packer (mdbg_pack_reads) would have delivered it
+        words = torch.zeros((n_bases + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+        exc = (torch.zeros(64, dtype=torch.int64, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda"))
+        assert m.pack_device(d_bases, n_bases, words.data_ptr(), exc[0].data_ptr(), exc[1].data_ptr(), 64) == 0      # synthetic reads are pure ACGT
+        d_words = words.data_ptr()
+    d_in = d_words if packed else d_bases
 
     if routed:
         from rust_mdbg_amd import dist as D
@@ -130,6 +167,7 @@ def main():
         chunked = n_chunks > 1 and not args.profile_dist
         mt = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank) if chunked and not replicate else None     # owner-side context
         engine = D.GpuEngine(m, torch, dev, table=mt)
+        engine.packed = packed
         comm = D.TorchDistComm(dist, torch, dev)
         runner = D.ReplicatedMdbg(engine, comm, torch) if replicate else D.DistributedMdbg(engine, comm, torch, profile=args.profile_dist)
         if chunked:
@@ -143,12 +181,15 @@ def main():
         else:
             m.reset(0)
         if not routed:
-            m.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
+            if packed:
+                m.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
+            else:
+                m.ingest_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
             return m.finalize_device().n
         if chunked:
-            runner.ingest_device_chunked(d_bases, offs_t, plan, first_ordinal)
+            runner.ingest_device_chunked(d_in, offs_t, plan, first_ordinal)
         else:
-            runner.ingest_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
+            runner.ingest_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
         return runner.finalize_device_count()
 
     def fence():
@@ -195,17 +236,38 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = total_bases * args.steps / dt / 1e9
         mins_per_base = st["n_minimizers"] / max(1, st["n_bases"])
-        alg_bytes = st["n_sketch_tile_bases"] * (1.0 + 12.0 * mins_per_base)     # b_in (ASCII) + 12*m per raw base
-        roof = None
-        if st["n_sketch_tile_launches"]:
-            avg_ms = st["ms_sketch_tile"] / st["n_sketch_tile_launches"]
-            ach = alg_bytes / st["n_sketch_tile_launches"] / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args)
-            roof = {"bound": "hbm", "kernel": "sketch_tile_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes / st["n_sketch_tile_launches"],
-                    "launches_per_step": st["n_sketch_tile_launches"], "avg_launch_ms": avg_ms,
-                    "algorithmic_bytes_per_base": 1.0 + 12.0 * mins_per_base,
-                    "kernel_gbases_per_s": st["n_sketch_tile_bases"] / (st["ms_sketch_tile"] * 1e-3) / 1e9}
+
+        def roofline(stt, b_in, fmt):
+            """algorithmic bytes per raw base of the sketch kernel = b_in + 12 m (input + u64 hash + u32 position)"""
+            if not stt["n_sketch_tile_launches"]:
+                return None
+            per_base = b_in + 12.0 * mins_per_base
+            alg = stt["n_sketch_tile_bases"] * per_base
+            avg_ms = stt["ms_sketch_tile"] / stt["n_sketch_tile_launches"]
+            ach = alg / stt["n_sketch_tile_launches"] / (avg_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "sketch_bs_kernel<%d>" % args.l, "input_format": fmt, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                    "algorithmic_bytes_per_launch": alg / stt["n_sketch_tile_launches"], "launches_per_step": stt["n_sketch_tile_launches"],
+                    "avg_launch_ms": avg_ms, "algorithmic_bytes_per_base": per_base,
+                    "kernel_gbases_per_s": stt["n_sketch_tile_bases"] / (stt["ms_sketch_tile"] * 1e-3) / 1e9}
+        roof = roofline(st, 0.25 if packed else 1.0, args.input)
+        if roof:
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args)
+            sq = sq_counters(args)
+            if sq:
+                roof.update(valu_util=sq.get("valu_util"), valu_lane_ops_per_base=sq.get("valu_lane_ops_per_base"), sq_source=sq.get("source"))
+        roof_ascii = None
+        if packed and not routed:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
+            for _ in range(2):
+                m.reset(0)
+                m.sketch_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
+            sta = m.stats()
+            roof_ascii = roofline(sta, 1.0, "ascii")
+            if roof_ascii:
+                roof_ascii["traffic"], roof_ascii["traffic_source"] = pmc_traffic(sta["n_sketch_tile_bases"] / sta["n_sketch_tile_launches"], args, "ascii")
+            m.reset(0)
+            m.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)      # the table the edge stage and the baseline below refer to
+            m.finalize_device()
         edges = None
         if not routed:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
             m.graph_edges_device(0.01)
@@ -218,11 +280,14 @@ def main():
         out = {"metric": "Gbases/s ingested to k-min-mer graph", "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
-               "config": {"workload": "synthetic D. melanogaster 140 Mb @50x per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1% errors",
+               "config": {"workload": ("synthetic human 3 Gb @52x over 8 GPUs (BASELINE.json configs[3]): %.0f Mb of genome and %.1f Gbases of ~15 kb HiFi-shaped reads per GPU, 0.1%% errors"
+                                       % (args.genome_mb, n_bases / 1e9)) if world > 1 else
+                                      "synthetic D. melanogaster %.0f Mb @%.0fx per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1%% errors" % (args.genome_mb, args.coverage),
                           "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
-                          "bases_per_gpu": n_bases, "input": "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records")) if routed else "single GPU"},
-               "roofline": roof, "cpu_baseline": cpu,
-               "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_tile_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
+                          "bases_per_gpu": n_bases, "input_format": args.input,
+                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records")) if routed else "single GPU"},
+               "roofline": roof, "roofline_ascii": roof_ascii, "cpu_baseline": cpu,
+               "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent},

@@ -6,6 +6,8 @@
   write : rocprofv3 --kernel-trace --pmc WRITE_SIZE ...   (separate pass: FETCH_SIZE takes 3 and WRITE_SIZE 2 of the 4 TCC slots)
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and on gfx950 FETCH_SIZE reports
 half of the bytes of a wide (16 B/lane) coalesced streaming read (MI355X_MICROARCH.md, HBM section).
+  sq, sq2 : two passes of 8 SQ counters each (scratch/gpu_profile_set.sh); the launches of the bench's ASCII side measurement
+            (roofline_ascii) are told apart from the timed packed ones by their order: the bench runs them last.
 usage: summarize.py <dir> <out_prefix>
 """
 import csv
@@ -38,7 +40,80 @@ def main(d, out):
         w_kb = wr[k][1] / wr[k][0] if k in wr and wr[k][0] else 0.0
         pm[k] = {"launches_sampled": fe[k][0], "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
                  "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0}
-    json.dump({"note": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, see profiles/summarize.py", "kernels": pm}, open(out + "_pmc_traffic.json", "w"), indent=1)
+    json.dump({"note": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, see profiles/summarize.py; averaged over every launch of the run "
+                       "(with --input packed the bench also launches the tile kernel twice on ASCII input for roofline_ascii, see per_launch)",
+               "kernels": pm, "per_launch": per_launch(d), "tile_kernel_by_input": by_input(d)}, open(out + "_pmc_traffic.json", "w"), indent=1)
+    sq_summary(d, out)
+
+
+def per_launch(d):
+    """FETCH/WRITE of every single launch of the tile kernel, in launch order"""
+    out = {}
+    for sub, f, name in (("fetch", "f", "FETCH_SIZE"), ("write", "w", "WRITE_SIZE")):
+        try:
+            rows = [r for r in csv.DictReader(open("%s/%s/%s_counter_collection.csv" % (d, sub, f))) if r["Counter_Name"] == name and "sketch_bs_kernel" in r["Kernel_Name"]]
+            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+            out[name + "_KB"] = [float(r["Counter_Value"]) for r in rows]
+        except Exception as e:      # noqa: BLE001
+            out[name + "_KB"] = str(e)
+    return out
+
+
+def by_input(d):
+    """HBM bytes per launch of the tile kernel by input format: with --input packed the LAST TWO launches of a bench run are the
+    ASCII side measurement, the ones before them the timed format"""
+    try:
+        fmt = json.load(open(d + "/bench.json"))["config"]["input_format"]
+    except Exception:      # noqa: BLE001
+        return None
+    pl = per_launch(d)
+    f, w = pl.get("FETCH_SIZE_KB"), pl.get("WRITE_SIZE_KB")
+    if not isinstance(f, list) or not isinstance(w, list) or len(f) != len(w) or not f:
+        return None
+    hbm = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w)]
+    if fmt != "packed" or len(hbm) < 3:
+        return {fmt: sum(hbm) / len(hbm)}
+    return {"packed": sum(hbm[:-2]) / len(hbm[:-2]), "ascii": sum(hbm[-2:]) / 2.0}
+
+
+def sq_summary(d, out):
+    import os
+    try:
+        bench = json.load(open(d + "/bench.json"))
+    except Exception:      # noqa: BLE001
+        return
+    agg = defaultdict(lambda: defaultdict(list))
+    for sub in ("sq", "sq2"):
+        p = "%s/%s/q_counter_collection.csv" % (d, sub)
+        if not os.path.exists(p):
+            return
+        rows = sorted(csv.DictReader(open(p)), key=lambda r: int(r["Start_Timestamp"]))
+        for r in rows:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    cfg = bench["config"]
+    tile = [k for k in agg if k.startswith("sketch_bs_kernel")]
+    res = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes) -- python bench.py --steps 1 --warmup 1 --cpu-seconds 0; per launch; "
+                   "the FIRST launches are the timed input format, the last two (if the bench ran packed) the ASCII side measurement",
+           "config": {f: cfg[f] for f in ("k", "l", "density", "minabund", "input_format", "bases_per_gpu")}, "kernels": {}}
+    for k in agg:
+        if not (k.startswith("sketch_bs") or k.startswith("insert_windows") or k.startswith("fin_") or k.startswith("gather")):
+            continue
+        res["kernels"][k] = {c: v for c, v in agg[k].items()}
+    if tile:
+        c = agg[tile[0]]
+        first = lambda name: c[name][0]
+        nb = cfg["bases_per_gpu"]
+        res["derived"] = {
+            "valu_lane_ops_per_base": first("SQ_INSTS_VALU") * 64.0 / nb,
+            "valu_instr_per_simd_cycle": first("SQ_INSTS_VALU") / (first("SQ_BUSY_CU_CYCLES") * 4.0),
+            "valu_util": first("SQ_ACTIVE_INST_VALU") * 4.0 / (first("SQ_BUSY_CU_CYCLES") * 4.0),
+            "valu_util_definition": "SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SQ_BUSY_CU_CYCLES * 4 SIMDs); gfx950 issues the simple integer ops in 2 cycles but "
+                                    "counts a quad-cycle per instruction, so a saturated VALU reads above 1",
+            "wave_time_split": {"active": first("SQ_ACTIVE_INST_ANY") / first("SQ_WAVE_CYCLES"), "parked_waitcnt_barrier": first("SQ_WAIT_ANY") / first("SQ_WAVE_CYCLES"),
+                                "issue_stall": first("SQ_WAIT_INST_ANY") / first("SQ_WAVE_CYCLES")},
+            "salu_per_valu": first("SQ_INSTS_SALU") / first("SQ_INSTS_VALU"), "lds_per_valu": first("SQ_INSTS_LDS") / first("SQ_INSTS_VALU")}
+    json.dump(res, open(out + "_sq_counters.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

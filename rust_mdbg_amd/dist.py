@@ -39,7 +39,10 @@ class TorchDistComm:
         rcl = [int(x) for x in rc.tolist()]
         send = send.contiguous()
         recv = alloc(sum(rcl)) if alloc is not None else t.empty((sum(rcl),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.device)
-        row_bytes = max(1, send.element_size() * (send.numel() // max(1, send.shape[0]) if send.shape[0] else 1))
+        row_bytes = send.element_size()              # from the trailing dimensions only: identical on every rank, also for an empty send
+        for dim in send.shape[1:]:
+            row_bytes *= int(dim)
+        row_bytes = max(1, row_bytes)
         max_rows = max(1, self.max_bytes // row_bytes)
         biggest = t.tensor([max(counts + rcl + [0])], dtype=t.int64, device=self.device)
         dist.all_reduce(biggest, op=dist.ReduceOp.MAX)
@@ -193,6 +196,7 @@ class GpuEngine:
         contexts (own HIP streams) lets DistributedMdbg overlap one chunk's sketch with the previous chunk's exchange."""
         self.m, self.t, self.device, self.ranges = mdbg, torch, device, []
         self.tm = table if table is not None else mdbg
+        self.packed = False              # True: sketch_device gets 2-bit packed words (mdbg_packed_batch layout) instead of ASCII
 
     @property
     def k(self):
@@ -213,8 +217,15 @@ class GpuEngine:
         self.ranges = []
 
     def sketch_device(self, d_bases, d_offsets, n_reads, n_bases, first_ordinal):
-        self.m.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
+        if self.packed:
+            self.m.ingest_packed_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal, sketch_only=True)
+        else:
+            self.m.sketch_device(d_bases, d_offsets, n_reads, n_bases, first_ordinal)
         self.ranges.append((int(first_ordinal), int(n_reads)))
+
+    def base_ptr(self, d_bases, a):
+        """pointer to base a (a multiple of 64, see plan_chunks) of a device batch in the engine's input format"""
+        return d_bases + (a // 4 if self.packed else a)
 
     def sketch_host(self, bases, offsets, first_ordinal):
         # host buffers: stage through the library, sketch only
@@ -383,7 +394,7 @@ class DistributedMdbg:
                 for (r0, r1, a, nb) in plan:
                     offs_c = (offsets_dev[r0:r1 + 1] - a).contiguous()
                     t.cuda.synchronize()
-                    e.sketch_device(d_bases + a, offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0)
+                    e.sketch_device(e.base_ptr(d_bases, a), offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0)
                     sent.acquire()
                     q.put(e.route_pack(self.c.world))
             except BaseException as ex:        # noqa: BLE001
@@ -504,7 +515,7 @@ class ReplicatedMdbg:
                 offs_c = (offsets_dev[r0:r1 + 1] - a).contiguous()
                 if offs_c.is_cuda:
                     t.cuda.current_stream().synchronize()
-                self._with_room(pend, lambda: e.sketch_device(d_bases + a, offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0))
+                self._with_room(pend, lambda: e.sketch_device(e.base_ptr(d_bases, a), offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0))
             pend.append(self._share_begin(len(plan), pend, have_batch=r1 > r0))     # an empty chunk still takes part in the round
         self._finish(pend)
 
@@ -555,6 +566,8 @@ class ReplicatedMdbg:
             if have_batch:
                 h, p, off, first, n = e.last_sketch()      # the store may have moved
         bufs = self._with_room(pend, lambda: e.reserve_import([int(meta[r][0]) for r in peers]))
+        if have_batch:
+            h, p, off, first, n = e.last_sketch()          # views into the resident store: taken AFTER the reservation, which may move it
         offs = [t.empty(int(meta[r][1]) + 1, dtype=t.int64, device=off.device) for r in peers]
         handle = c.exchange([(r, [h, p, off]) for r in peers], [(r, [bufs[i][0], bufs[i][1], offs[i]]) for i, r in enumerate(peers)])
         return handle, [(bufs[i][2], offs[i], int(meta[r][2]), int(meta[r][4 + c.rank]) if meta[r][3] else None) for i, r in enumerate(peers)]
@@ -592,7 +605,7 @@ class ReplicatedMdbg:
 def plan_chunks(offsets_host, n_chunks, keep_empty=False):
     """cut a batch (host copy of its offsets) into n_chunks runs of whole reads with roughly equal bases:
     -> [(r0, r1, aligned_byte, n_bytes)]: the chunk is reads [r0, r1), passed with base pointer + aligned_byte (a multiple
-    of 16 <= offsets[r0]) and offsets rebased by it; n_bytes = offsets[r1] - aligned_byte.  keep_empty: always n_chunks
+    of 64 <= offsets[r0]: 16-byte aligned in ASCII and in the 2-bit packed layout) and offsets rebased by it; n_bytes = offsets[r1] - aligned_byte.  keep_empty: always n_chunks
     entries (every rank of a collective driver must run the same number of rounds, however few reads it holds)"""
     import numpy as np
     o = np.asarray(offsets_host, dtype=np.uint64)
@@ -605,7 +618,7 @@ def plan_chunks(offsets_host, n_chunks, keep_empty=False):
     plan = []
     for r0, r1 in zip(cuts, cuts[1:]):
         if r1 > r0 or keep_empty:
-            a = int(o[r0]) // 16 * 16
+            a = int(o[r0]) // 64 * 64
             plan.append((r0, r1, a, int(o[r1]) - a))
     return plan
 
