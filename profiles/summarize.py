@@ -60,8 +60,9 @@ def per_launch(d):
 
 
 def by_input(d):
-    """HBM bytes per launch of the tile kernel by input format: with --input packed the LAST TWO launches of a bench run are the
-    ASCII side measurement, the ones before them the timed format"""
+    """HBM bytes per launch of the tile kernel by input format: with --input packed a bench run launches the tile kernel
+    warmup + steps times on packed input, twice on ASCII (roofline_ascii) and once more on packed input (the table the edge
+    stage refers to)"""
     try:
         fmt = json.load(open(d + "/bench.json"))["config"]["input_format"]
     except Exception:      # noqa: BLE001
@@ -71,9 +72,10 @@ def by_input(d):
     if not isinstance(f, list) or not isinstance(w, list) or len(f) != len(w) or not f:
         return None
     hbm = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w)]
-    if fmt != "packed" or len(hbm) < 3:
+    if fmt != "packed" or len(hbm) < 4:
         return {fmt: sum(hbm) / len(hbm)}
-    return {"packed": sum(hbm[:-2]) / len(hbm[:-2]), "ascii": sum(hbm[-2:]) / 2.0}
+    pk = hbm[:-3] + hbm[-1:]
+    return {"packed": sum(pk) / len(pk), "ascii": sum(hbm[-3:-1]) / 2.0}
 
 
 def sq_summary(d, out):
@@ -94,7 +96,7 @@ def sq_summary(d, out):
     cfg = bench["config"]
     tile = [k for k in agg if k.startswith("sketch_bs_kernel")]
     res = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes) -- python bench.py --steps 1 --warmup 1 --cpu-seconds 0; per launch; "
-                   "the FIRST launches are the timed input format, the last two (if the bench ran packed) the ASCII side measurement",
+                   "launch order of a packed bench run: warmup + steps on packed input, two on ASCII (roofline_ascii), one more on packed input",
            "config": {f: cfg[f] for f in ("k", "l", "density", "minabund", "input_format", "bases_per_gpu")}, "kernels": {}}
     for k in agg:
         if not (k.startswith("sketch_bs") or k.startswith("insert_windows") or k.startswith("fin_") or k.startswith("gather")):
