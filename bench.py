@@ -6,7 +6,8 @@ A "step" = one pass of the hot path over one batch already resident in HBM:
 Workload at N=1: BASELINE.json configs[2] (synthetic D. melanogaster: 140 Mb genome @50x, ~15 kb reads, 0.1 % errors,
 k=35 l=12 d=0.002 minabund=2).  For N>1: BASELINE.json configs[3] (synthetic human 3 Gb @52x over 8 GPUs = 375 Mb of genome
 and 19.5 Gbases of reads per GPU, k=35 l=14 d=0.003; weak scaling: the genome grows with N, coverage constant) and the
-k-min-mer occurrences are routed to their owning rank by key range with one RCCL all-to-all per step (rust_mdbg_amd/dist.py).
+table is partitioned by key range; the ranks exchange their sketches over RCCL send/recv pairs (default) or route the k-min-mer
+occurrences to their owner with one RCCL all-to-all per step (--dist-mode route; rust_mdbg_amd/dist.py).
 The reads sit in HBM in the north star's layout, packed 2 bits per base (--input ascii: one byte per base).
 
 Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_bs_kernel) as fed in the timed region and
@@ -41,8 +42,8 @@ def parse():
     ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="layout of the reads in HBM during the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
-    ap.add_argument("--dist-mode", choices=["replicate", "route"], default="route",
-                    help="multi-GPU mode: all-to-all of k-min-mer records by key range (the north star's exchange), or all-gather of sketches + partitioned table")
+    ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
+                    help="multi-GPU mode: exchange of sketches + key-partitioned table (default inside a node: 3x faster per rank, profiles/r02_notes.md), or all-to-all of k-min-mer records by key range (the north star's wording)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="multi-GPU: chunks per step; the exchange of chunk c overlaps the sketch of chunk c+1 (0 = 4 in replicate mode, 1 in route mode)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
