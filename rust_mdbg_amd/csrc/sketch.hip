@@ -233,6 +233,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         }
     } else {
         if (interior) {
+            static_assert(WPT % 2 == 0 && (HALO_BASES / 32) % 2 == 0 && ((TILE_RAW_WORDS - HALO_BASES / 32) % 2) == 0, "16-byte aligned word pairs per thread");
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4* src = (const u32x4*)(a.planes + pi0);
 #pragma unroll
@@ -281,12 +282,10 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
             }
         }
         __syncthreads();
-        const uint4* st4 = (const uint4*)(S.a.stage + 2 * WPT * tid);
 #pragma unroll
-        for (int i = 0; i < WPT / 2; ++i) {
-            const uint4 h = st4[i];
-            x0[2 * i] = (h.x & 0xFFFF0000u) | (h.y >> 16);     x1[2 * i] = (h.x << 16) | (h.y & 0xFFFFu);
-            x0[2 * i + 1] = (h.z & 0xFFFF0000u) | (h.w >> 16); x1[2 * i + 1] = (h.z << 16) | (h.w & 0xFFFFu);
+        for (int i = 0; i < WPT; ++i) {
+            const uint2 h = *(const uint2*)(S.a.stage + 2 * (WPT * tid + i));
+            x0[i] = (h.x & 0xFFFF0000u) | (h.y >> 16); x1[i] = (h.x << 16) | (h.y & 0xFFFFu);
         }
         if (tid) { const u32 hp = S.a.stage[2 * WPT * tid - 1]; pv0 = hp >> 16; pv1 = hp; }
     } else {
@@ -321,6 +320,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     }
     u32 H;
     u32 off = block_excl_scan_256(mine, S.misc, H);          // (its barriers also order the bitmap reset before the stream writes)
+    static_assert(HW % WPT == 0, "the halo is a whole number of threads");
     if (tid == HW / WPT) S.misc[11] = off;                   // kept bases of the halo words
     if (tid == TT - 1) S.rpre[RW] = (u16)H;
 #pragma unroll
