@@ -14,7 +14,7 @@ typedef uint64_t u64;
 constexpr int TILE_THREADS = 256;
 constexpr int TILE_RAW_WORDS = 1024;
 constexpr int HALO_BASES = 256;
-constexpr int TILE_STRIDE = TILE_RAW_WORDS * 32 - HALO_BASES;   // 24,384 raw bases per tile
+constexpr int TILE_STRIDE = TILE_RAW_WORDS * 32 - HALO_BASES;   // 32,512 raw bases per tile
 constexpr int MDBG_MAX_L_DEV = 32;                // = MDBG_MAX_L of the C ABI
 
 // ordinal = (global read ordinal << WIN_BITS) | window index within the read
