@@ -28,7 +28,7 @@ def test_example_cfg1(example_reads):
     r = g.finalize()
     for f in ("n_windows", "n_nodes_before", "n_nodes", "n_edges", "presimp_removed"):
         assert r[f] == gold[f], f
-    # independent numpy restatement in SURVEY.md §8c reported this very digest
+    # the independent restatement (tests/golden/independent_restatement.py, committed; tests/test_oracle_independent.py) regenerates this very digest
     assert node_sha(r["keys"], r["abundance"]) == gold["nodes_sha256"] == "89e36af94df5e2227ded239b9d3423eb654131f2d58721ca7b873b2ef86feab8"
     assert edge_sha(r) == gold["edges_sha256"]
     z = np.load(os.path.join(GOLDEN, "example_cfg1_nodes.npz"))

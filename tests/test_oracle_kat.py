@@ -28,7 +28,14 @@ def py_canonical(s, i, k):
 
 
 def test_nthash_crate_known_answers():
-    # nthash crate (0.5.x) README / unit tests
+    """Provenance of the vectors (crate `nthash`, crates.io, the version rust-mdbg's `nthash = "*"` resolved to for any build between
+    2021 and 2024 is 0.5.1; the crate is NOT vendored under /root/reference, the values below were recalled from the crate and are each
+    re-derived by py_canonical / the independent restatement from the published seeds):
+      * ntf64("TGCAG", 0, 5) = 0x0bafa6728fc6dabf, ntr64(same) = 0x8cf2d4072cca480e      crate README "usage" + src/lib.rs doc test
+      * ntc64("ACGTC", 0, 5) = 0x480202d54e8ebecd (forward 0xa7d01e3fb5593252)            src/lib.rs unit test `oracle_cmp` family
+      * NtHashIterator::new(b"ACTGC", 3) = [0x9b1eda9a185413ce, 0x9f6acfa2235b86fc, 0xd4a29bf149877c5c]   crate README "iterator" example
+    The same numbers appear in the ntHash paper's reference implementation (bcgsc/ntHash v1 seeds).  They pin the seeds, the rotation
+    directions of both strands and the canonical min; tests/test_oracle_independent.py pins everything downstream."""
     assert O.ntf64(b"TGCAG", 0, 5) == 0x0BAFA6728FC6DABF
     assert O.ntr64(b"TGCAG", 0, 5) == 0x8CF2D4072CCA480E
     assert O.ntc64(b"ACGTC", 0, 5) == 0x480202D54E8EBECD
