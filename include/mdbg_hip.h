@@ -50,8 +50,8 @@ enum {
     MDBG_E_STATE = -6     /* call not valid in the context's current state (e.g. ingest after an error) */
 };
 
-#define MDBG_MAX_L 32u         /* l-mers longer than this are rejected (reference: unbounded) */
-#define MDBG_MAX_MINABUND 8u   /* the table tracks the A smallest ordinals per node for A <= 8 */
+#define MDBG_MAX_L 255u        /* l = 2..32 run on the bit-sliced kernel, longer l-mers on its generic exact walker (reference: unbounded) */
+#define MDBG_MAX_MINABUND 65535u /* DbgAbundance is a u16 in the reference; up to 8 the table tracks the A-th sighting directly, above it is recovered at finalize */
 #define MDBG_FLAG_FORCE_GENERIC 1u /* every tile takes the generic exact sketch kernel (testing / cross-check) */
 
 typedef struct mdbg_ctx mdbg_ctx;

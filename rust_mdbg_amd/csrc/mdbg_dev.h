@@ -17,6 +17,11 @@ constexpr int HALO_BASES = 256;
 constexpr int TILE_STRIDE = TILE_RAW_WORDS * 32 - HALO_BASES;   // 32,512 raw bases per tile
 constexpr int MDBG_MAX_L_DEV = 32;                // = MDBG_MAX_L of the C ABI
 
+// the table slots keep the A smallest ordinals of a k-min-mer for A up to this; larger min_abundance values get the A-th sighting from a
+// re-scan of the windows at finalize (table.hip, wrap_list_kernel)
+constexpr u32 MDBG_CASCADE_MAX = 8;
+__host__ __device__ inline u32 cascade_of(u32 A) { return A <= MDBG_CASCADE_MAX ? A : 1u; }
+
 // ordinal = (global read ordinal << WIN_BITS) | window index within the read
 constexpr int WIN_BITS = 26;
 constexpr u64 WIN_MASK = (1ull << WIN_BITS) - 1;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(1024) void export_grouped_kernel(ExportArgs a) {
         const Slot e = a.F.tab[s];
         if (e.word != EMPTY) {
             occ = true;
-            v = slot_view(e, s, a.F.mx, a.F.A, rep_ordinal(a.F, e.word), a.F.ath_override);
+            v = slot_view(e, s, a.F.mx, a.F.casc, a.F.A, rep_ordinal(a.F, e.word), a.F.ath_override);
             g1 = span_owner(a, v.first);
             r1 = atomicAdd(&lcnt[g1], 1u);
             if (v.solid) { g2 = span_owner(a, v.ath); r2 = atomicAdd(&lcnt[a.world + g2], 1u); }

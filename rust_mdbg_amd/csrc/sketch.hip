@@ -661,7 +661,7 @@ void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_b
         MDBG_L(14) MDBG_L(15) MDBG_L(16) MDBG_L(17) MDBG_L(18) MDBG_L(19) MDBG_L(20) MDBG_L(21) MDBG_L(22) MDBG_L(23) MDBG_L(24)
         MDBG_L(25) MDBG_L(26) MDBG_L(27) MDBG_L(28) MDBG_L(29) MDBG_L(30) MDBG_L(31) MDBG_L(32)
 #undef MDBG_L
-        default: break;
+        default: launch_bs<32>(a, n_wg, s); break;      // l > 32: every tile takes the generic walker (force_slow is set by the host)
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
 }

@@ -308,7 +308,7 @@ struct BatchTab {                 // batches sorted by first_ordinal (device cop
     const u32* by_slot0; const u64* by_slot_first;   // the same batches sorted by slot0 (= call order): slot -> read ordinal
 };
 struct FinArgs {
-    const Slot* tab; u64 cap; const u64* mx; u32 A; u32 k; u32 l;
+    const Slot* tab; u64 cap; const u64* mx; u32 A; u32 casc; u32 k; u32 l;   // A: abundance filter; casc: ordinals tracked per slot (= A up to 8, else 1)
     const u64* mh; const u32* mpos; const u64* roff; const u32* mread; const u64* arena;
     BatchTab bt;
     u64* solid_list; u64* solid_count;       // compact list of solid slots (fin_mark -> fin_emit)
@@ -343,17 +343,20 @@ __device__ inline u64 rep_ordinal(const FinArgs& F, u64 word) {
 }
 struct SlotView { u32 count; u64 first, ath; bool solid; };
 // merges the claimer back in: total count, smallest ordinal, A-th smallest ordinal (valid when count >= A)
-__device__ inline SlotView slot_view(const Slot& e, u64 s, const u64* mx, u32 A, u64 r, const u64* ath_override = nullptr) {
+// casc: number of smallest ordinals the table tracked (= A for A <= MDBG_CASCADE_MAX; 1 for larger A, whose A-th sighting comes from
+// the re-scan of resolve_wrapped through ath_override)
+__device__ inline SlotView slot_view(const Slot& e, u64 s, const u64* mx, u32 casc, u32 A_filter, u64 r, const u64* ath_override = nullptr) {
     SlotView v;
     v.count = e.count + 1u;
     v.first = r < e.m1 ? r : e.m1;
+    const u32 A = casc;
     if (A == 1) v.ath = v.first;
     else {
         const u64 prev = A == 2 ? e.m1 : A == 3 ? e.m2 : mx[s * (A - 2) + (A - 4)];      // (A-1)-th smallest of the others
         const u64 last = A == 2 ? e.m2 : mx[s * (A - 2) + (A - 3)];                      // A-th smallest of the others
         v.ath = r < prev ? prev : (r < last ? r : last);
     }
-    v.solid = A == 1 || (u16)v.count >= (u16)A;                                           // src/main.rs:922-929 (u16 abundance)
+    v.solid = A_filter == 1 || (u16)v.count >= (u16)A_filter;                             // src/main.rs:922-929 (u16 abundance)
     if (e.pad && ath_override) v.ath = ath_override[e.pad - 1];                            // see wrap_list_kernel
     return v;
 }
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
     if (s < F.cap) {
         const Slot e = F.tab[s];
         if (e.word != EMPTY) {
-            const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word));
+            const SlotView v = slot_view(e, s, F.mx, F.casc, F.A, rep_ordinal(F, e.word));
             occ = true; solid = v.solid; wrapped = v.count >= 65536u;
             u64 i, D; decode_ordinal(F, v.first, i, D);
             atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
@@ -396,14 +399,15 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
 // table only knows the A smallest ordinals; for these (rare, extremely repetitive) keys the exact j*-th smallest ordinal is
 // recovered here: list them (Slot.pad = rank + 1), re-scan the resident windows (or routed records) collecting the
 // ordinals of exactly those keys, sort each list, pick element j* - 1.
-__global__ __launch_bounds__(256) void wrap_list_kernel(Slot* __restrict__ tab, u64 cap, u32 A, u64* __restrict__ w_jstar, u32* __restrict__ w_count,
+// all_solid: minabund exceeds what the slots track (MDBG_CASCADE_MAX): EVERY solid node gets its j*-th sighting this way.
+__global__ __launch_bounds__(256) void wrap_list_kernel(Slot* __restrict__ tab, u64 cap, u32 A, bool all_solid, u64* __restrict__ w_jstar, u32* __restrict__ w_count,
                                                         unsigned long long* __restrict__ counters /* [0] nodes, [1] occurrences */) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= cap) return;
     const u64 word = tab[s].word;
     if (word == EMPTY) return;
     const u32 count = tab[s].count + 1u;
-    if (count < A || count - A < 65536u || !(A == 1 || (u16)count >= (u16)A)) return;
+    if (count < A || (!all_solid && count - A < 65536u) || !(A == 1 || (u16)count >= (u16)A)) return;
     const u32 r = (u32)atomicAdd(&counters[0], 1ull);
     atomicAdd(&counters[1], (unsigned long long)count);
     w_count[r] = count; w_jstar[r] = (u64)A + 65536ull * ((count - A) / 65536u);
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
     if (q < n_solid) {
         const u64 s = F.solid_list[q];
         const Slot e = F.tab[s];
-        const SlotView v = slot_view(e, s, F.mx, F.A, rep_ordinal(F, e.word), F.ath_override);
+        const SlotView v = slot_view(e, s, F.mx, F.casc, F.A, rep_ordinal(F, e.word), F.ath_override);
         u64 i1, D; decode_ordinal(F, v.first, i1, D);
         const u64 below = (1ull << (D & 63)) - 1;
         const u64 row = F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & below);          // row of the node in index order
@@ -696,8 +700,8 @@ void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* o
 void launch_fin_mark(const FinArgs& F, hipStream_t s) {
     hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 1023) / 1024)), dim3(1024), 0, s, F);
 }
-void launch_wrap_list(Slot* tab, u64 cap, u32 A, u64* w_jstar, u32* w_count, unsigned long long* counters, hipStream_t s) {
-    hipLaunchKernelGGL(wrap_list_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, tab, cap, A, w_jstar, w_count, counters);
+void launch_wrap_list(Slot* tab, u64 cap, u32 A, bool all_solid, u64* w_jstar, u32* w_count, unsigned long long* counters, hipStream_t s) {
+    hipLaunchKernelGGL(wrap_list_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, tab, cap, A, all_solid, w_jstar, w_count, counters);
 }
 void launch_wrap_scan_windows(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
                               const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {

@@ -452,8 +452,8 @@ def test_large_and_sparse_read_ordinals():
 
 def test_param_validation():
     R = _mdbg()
-    for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=33, density=0.01),
-               dict(k=5, l=12, density=0.01, min_abundance=0), dict(k=5, l=12, density=0.01, min_abundance=9)):
+    for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=256, density=0.01),
+               dict(k=5, l=12, density=0.01, min_abundance=0), dict(k=5, l=12, density=0.01, min_abundance=65536)):
         with pytest.raises(R.MdbgError) as e:
             R.Mdbg(**kw)
         assert e.value.code == -1
@@ -476,3 +476,33 @@ def test_device_synth_matches_cpu_regenerator():
         got = m.finalize()
     exp = oracle_graph(cpu, 5, 12, 0.01, 2)
     assert_nodes_equal(got, exp)
+
+
+@pytest.mark.parametrize("A", [9, 12, 40, 300])
+def test_large_min_abundance(A):
+    """minabund above what the table slots track (8): the A-th sighting of every solid node comes from the re-scan at finalize
+    (the reference's DbgAbundance is a u16: any value up to 65535 is legal, src/main.rs:60,680)"""
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(31 + A, 3000, 6000 if A >= 40 else 900, mean_len=2500, sd_len=300, min_len=800, max_len=4000, err_ppm=3000)
+    k, l, d = 4, 8, 0.02
+    exp = oracle_graph(reads, k, l, d, A)
+    assert exp["n_nodes"] > 20 and exp["n_nodes_before"] > exp["n_nodes"]
+    got, _ = run_gpu(reads, k, l, d, A)
+    assert_nodes_equal(got, exp)
+    got2, _ = run_gpu(reads, k, l, d, A, batches=[(0, len(reads) // 3), (len(reads) // 3, len(reads))])
+    assert_nodes_equal(got2, exp)
+
+
+@pytest.mark.parametrize("l", [33, 40, 64, 100])
+def test_l_above_32_runs_on_the_generic_walker(l):
+    reads = rand_reads(l, 12, 50, 30000, hp=0.05)
+    b, o = O.concat_reads(reads)
+    exp = O.sketch(b, o, l, 0.01)
+    R = _mdbg()
+    with R.Mdbg(5, l, 0.01, 2) as m:
+        assert_sketch_equal(m.sketch(b, o), exp)
+        m.ingest(b, o, 0)
+        got = m.finalize()
+        st = m.stats()
+    assert st["n_slow_tiles"] == st["n_tiles"] > 0
+    assert_nodes_equal(got, oracle_graph(reads, 5, l, 0.01, 2))
