@@ -42,7 +42,7 @@ int mdbg_seqfile_close(mdbg_seqfile* f);
 /* ---- host ingest: FASTA / FASTQ, optionally gzip-compressed, into the batch layout of
  * mdbg_ingest_batch.  Mirrors get_reader + the seq_io readers of the reference (src/main.rs:163-178,461-467,830-839):
  * the format is decided by the FILE NAME (".fa"/".fasta" suffix or ".fa."/".fasta." inside -> FASTA, anything else ->
- * FASTQ), ".gz" is read through zlib, ".lz4" input is not supported.  Like seq_io's RefRecord::seq(), a multi-line
+ * FASTQ), ".gz" is read through zlib, ".lz4" through a built-in LZ4 frame decoder (the image has no liblz4).  Like seq_io's RefRecord::seq(), a multi-line
  * FASTA record keeps its interior line terminators unless strip_newlines is set (the reference strips them only with
  * --reference, src/main.rs:737; otherwise such a read trips the ACGTN check, as it does in the reference). */
 typedef struct mdbg_reader mdbg_reader;

@@ -203,9 +203,95 @@ int mdbg_seqfile_close(mdbg_seqfile* s) {
 
 }  // extern "C"
 
+// ---- LZ4 frame input (src/main.rs:168-172: a ".lz4" file goes through lzzzz's BufReadDecompressor) --------------------
+// Streaming decoder of the LZ4 frame format (magic 0x184D2204; linked or independent blocks, stored or compressed blocks,
+// skippable and concatenated frames); block / content checksums are read past, not verified.
+struct Lz4In {
+    FILE* f = nullptr; bool bad = false, done = false, in_frame = false, blk_sum = false, content_sum = false;
+    std::vector<u8> out;              // [history (<= 64 KiB) | bytes of the current block]; rd = next byte to hand out
+    size_t rd = 0;
+    std::vector<u8> blk;
+    bool get(void* p, size_t n) { return fread(p, 1, n, f) == n; }
+    bool header() {                   // false: clean end of input (or error, see bad)
+        for (;;) {
+            u8 m[4];
+            const size_t got = fread(m, 1, 4, f);
+            if (got == 0) return false;
+            if (got != 4) { bad = true; return false; }
+            const u32 magic = (u32)m[0] | (u32)m[1] << 8 | (u32)m[2] << 16 | (u32)m[3] << 24;
+            if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {          // skippable frame
+                u8 z[4]; if (!get(z, 4)) { bad = true; return false; }
+                const u32 n = (u32)z[0] | (u32)z[1] << 8 | (u32)z[2] << 16 | (u32)z[3] << 24;
+                if (fseek(f, (long)n, SEEK_CUR) != 0) { bad = true; return false; }
+                continue;
+            }
+            if (magic != 0x184D2204u) { bad = true; return false; }
+            u8 fb[2]; if (!get(fb, 2)) { bad = true; return false; }
+            if ((fb[0] >> 6) != 1) { bad = true; return false; }
+            blk_sum = (fb[0] >> 4) & 1; content_sum = (fb[0] >> 2) & 1;
+            size_t skip = 1;                                    // header checksum
+            if ((fb[0] >> 3) & 1) skip += 8;                    // content size
+            if (fb[0] & 1) skip += 4;                           // dictionary id
+            u8 tmp[16]; if (!get(tmp, skip)) { bad = true; return false; }
+            in_frame = true; out.clear(); rd = 0;
+            return true;
+        }
+    }
+    bool decode_block(const u8* src, size_t n) {               // appends to out
+        size_t i = 0;
+        while (i < n) {
+            const u8 tok = src[i++];
+            size_t lit = tok >> 4;
+            if (lit == 15) { u8 b; do { if (i >= n) return false; b = src[i++]; lit += b; } while (b == 255); }
+            if (i + lit > n) return false;
+            out.insert(out.end(), src + i, src + i + lit); i += lit;
+            if (i >= n) break;                                  // the last sequence holds literals only
+            if (i + 2 > n) return false;
+            const size_t off = (size_t)src[i] | (size_t)src[i + 1] << 8; i += 2;
+            size_t ml = (tok & 15u);
+            if (ml == 15) { u8 b; do { if (i >= n) return false; b = src[i++]; ml += b; } while (b == 255); }
+            ml += 4;
+            if (off == 0 || off > out.size()) return false;
+            size_t from = out.size() - off;
+            for (size_t j = 0; j < ml; ++j) out.push_back(out[from + j]);       // byte by byte: matches may overlap their own output
+        }
+        return true;
+    }
+    bool next_block() {               // false: end of all input (or error)
+        for (;;) {
+            if (!in_frame && !header()) return false;
+            u8 z[4]; if (!get(z, 4)) { bad = true; return false; }
+            const u32 w = (u32)z[0] | (u32)z[1] << 8 | (u32)z[2] << 16 | (u32)z[3] << 24;
+            if (w == 0) {                                       // end mark
+                if (content_sum) { u8 c4[4]; if (!get(c4, 4)) { bad = true; return false; } }
+                in_frame = false;
+                continue;
+            }
+            const size_t n = w & 0x7FFFFFFFu;
+            if (n > (8u << 20)) { bad = true; return false; }
+            blk.resize(n);
+            if (!get(blk.data(), n)) { bad = true; return false; }
+            if (blk_sum) { u8 c4[4]; if (!get(c4, 4)) { bad = true; return false; } }
+            if (rd > (64u << 10)) { const size_t drop = rd - (64u << 10); out.erase(out.begin(), out.begin() + (long)drop); rd -= drop; }   // keep 64 KiB of history
+            if (w & 0x80000000u) out.insert(out.end(), blk.begin(), blk.end());
+            else if (!decode_block(blk.data(), n)) { bad = true; return false; }
+            return true;
+        }
+    }
+    int read(u8* dst, size_t n) {     // like gzread: bytes delivered, 0 at the end, -1 on a malformed stream
+        size_t got = 0;
+        while (got < n) {
+            if (rd == out.size()) { if (done || !next_block()) { done = true; break; } continue; }
+            const size_t take = std::min(n - got, out.size() - rd);
+            memcpy(dst + got, out.data() + rd, take); rd += take; got += take;
+        }
+        return bad ? -1 : (int)got;
+    }
+};
+
 // ---- host ingest -------------------------------------------------------------------------------------
 struct mdbg_reader {
-    gzFile f = nullptr; bool fasta = false, strip = false, eof = false;
+    gzFile f = nullptr; Lz4In* lz = nullptr; bool fasta = false, strip = false, eof = false, io_error = false;
     std::vector<u8> buf; size_t pos = 0, len = 0;            // input window
     std::vector<u8> bases; std::vector<u64> offs;            // current batch
     std::vector<u8> pending; bool have_pending = false;      // a parsed record that did not fit the previous batch
@@ -213,7 +299,9 @@ struct mdbg_reader {
         if (eof) return false;
         if (pos > 0) { memmove(buf.data(), buf.data() + pos, len - pos); len -= pos; pos = 0; }
         if (buf.size() - len < (1u << 20)) buf.resize(buf.size() * 2);
-        const int n = gzread(f, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, 1u << 30));
+        const size_t want = std::min<size_t>(buf.size() - len, 1u << 30);
+        const int n = lz ? lz->read(buf.data() + len, want) : gzread(f, buf.data() + len, (unsigned)want);
+        if (n < 0) io_error = true;
         if (n <= 0) { eof = true; return false; }
         len += (size_t)n;
         return true;
@@ -267,12 +355,18 @@ mdbg_reader* mdbg_reader_open(const char* path, int strip_newlines, int* err) {
     if (!path) return nullptr;
     const std::string p(path);
     auto ends = [&](const char* suf) { const size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
-    if (ends(".lz4")) return nullptr;                        // src/main.rs:172: lz4 input — not supported here
-    gzFile f = gzopen(path, "rb");                           // transparent for uncompressed files
-    if (!f) return nullptr;
-    gzbuffer(f, 1u << 20);
     mdbg_reader* r = new mdbg_reader();
-    r->f = f; r->strip = strip_newlines != 0;
+    if (ends(".lz4")) {                                      // src/main.rs:168-172: LZ4 frame
+        FILE* fp = fopen(path, "rb");
+        if (!fp) { delete r; return nullptr; }
+        r->lz = new Lz4In(); r->lz->f = fp;
+    } else {
+        gzFile f = gzopen(path, "rb");                       // ".gz" and plain files alike (transparent for uncompressed input)
+        if (!f) { delete r; return nullptr; }
+        gzbuffer(f, 1u << 20);
+        r->f = f;
+    }
+    r->strip = strip_newlines != 0;
     r->fasta = p.find(".fasta.") != std::string::npos || p.find(".fa.") != std::string::npos || ends(".fa") || ends(".fasta");   // main.rs:463
     r->buf.resize(4u << 20);
     r->offs.push_back(0);
@@ -295,10 +389,10 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
         if (r->bases.size() >= max_bases) break;
     }
     *bases = r->bases.data(); *offsets = r->offs.data(); *n_reads = r->offs.size() - 1;
-    return MDBG_OK;
+    return r->io_error ? MDBG_E_PARAM : MDBG_OK;             // a malformed compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->f) gzclose(r->f); delete r; } }
+void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
 
 }  // extern "C"
 

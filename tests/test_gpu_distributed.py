@@ -66,7 +66,7 @@ def test_routed_path_matches_oracle(world, mode):
 
 
 @pytest.mark.parametrize("mode", ["route", "replicate"])
-@pytest.mark.parametrize("k,l,d,a", [(21, 12, 0.003, 2), (35, 12, 0.002, 2), (4, 10, 0.01, 1), (5, 12, 0.01, 3)])
+@pytest.mark.parametrize("k,l,d,a", [(21, 12, 0.003, 2), (35, 12, 0.002, 2), (4, 10, 0.01, 1), (5, 12, 0.01, 3), (4, 10, 0.02, 11)])
 def test_routed_path_configs(k, l, d, a, mode):
     from rust_mdbg_amd import synth
     reads = synth.synth_reads(k, 300000, 500, mean_len=15000, sd_len=1500, min_len=8000, max_len=25000, err_ppm=1000)

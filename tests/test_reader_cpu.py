@@ -48,7 +48,92 @@ def test_formats(tmp_path):
     assert collect(str(odd))[1] is True                                          # ".fa." inside the name
     with pytest.raises(OSError):
         E.Reader(str(tmp_path / "missing.fa"))
-    with pytest.raises(OSError):
-        E.Reader(str(tmp_path / "reads.fa.lz4"))
     for s in E.READER_EXPORTS:
         assert hasattr(E.load_library(), s)
+
+
+# ---- ".lz4" input (src/main.rs:168-172).  The image has no lz4 tool or module: a small greedy LZ4 block compressor written from
+# the format specification produces the test files (frames with compressed and stored blocks, linked blocks that refer into the
+# previous block, block / content checksum fields, a skippable frame, two concatenated frames). -----------------------------------
+def lz4_block(data, history=b""):
+    """LZ4 block of `data`; matches may start inside `history` (linked blocks)"""
+    buf = history + data
+    base, n = len(history), len(history) + len(data)
+    table, out, i, anchor = {}, bytearray(), base, base
+
+    def emit(lit, mlen, off):
+        tok_l, tok_m = min(len(lit), 15), (min(mlen - 4, 15) if mlen else 0)
+        out.append(tok_l << 4 | tok_m)
+        if len(lit) >= 15:
+            r = len(lit) - 15
+            out.extend(b"\xff" * (r // 255) + bytes([r % 255]))
+        out.extend(lit)
+        if mlen:
+            out.extend(bytes([off & 255, off >> 8]))
+            if mlen - 4 >= 15:
+                r = mlen - 4 - 15
+                out.extend(b"\xff" * (r // 255) + bytes([r % 255]))
+    for j in range(max(0, base - 65535), base):
+        table[buf[j:j + 4]] = j
+    while i + 4 <= n - 5:                       # the last 5 bytes of a block are literals, a match must end 5 bytes before the end
+        key = buf[i:i + 4]
+        cand = table.get(key)
+        table[key] = i
+        if cand is not None and i - cand <= 65535:
+            m = 4
+            while i + m < n - 5 and buf[cand + m] == buf[i + m]:
+                m += 1
+            emit(buf[anchor:i], m, i - cand)
+            i += m
+            anchor = i
+        else:
+            i += 1
+    emit(buf[anchor:n], 0, 0)
+    return bytes(out)
+
+
+def lz4_frame(data, block=1 << 16, linked=True, block_checksum=False, content_checksum=False, store_every=0):
+    import struct
+    flg = 0x40 | (0 if linked else 0x20) | (0x10 if block_checksum else 0) | (0x04 if content_checksum else 0)
+    out = bytearray(struct.pack("<I", 0x184D2204) + bytes([flg, 0x40, 0]))       # BD: 64 KiB blocks; header checksum byte is not verified
+    for bi, a in enumerate(range(0, len(data), block)):
+        chunk = data[a:a + block]
+        comp = lz4_block(chunk, data[max(0, a - 65535):a] if linked else b"")
+        if (store_every and bi % store_every == 0) or len(comp) >= len(chunk):
+            out += struct.pack("<I", len(chunk) | 0x80000000) + chunk
+        else:
+            out += struct.pack("<I", len(comp)) + comp
+        if block_checksum:
+            out += b"\0\0\0\0"
+    out += struct.pack("<I", 0)
+    if content_checksum:
+        out += b"\0\0\0\0"
+    return bytes(out)
+
+
+def test_lz4_input(tmp_path, example_reads):
+    import struct
+    text = b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(example_reads[:40]))        # ~0.9 MB of FASTA: 14 blocks
+    # a repeat across the block boundary makes the linked mode matter
+    text = text[:60000] + text[1000:9000] + text[60000:]
+    for kw in (dict(), dict(linked=False), dict(block_checksum=True, content_checksum=True, store_every=3)):
+        p = tmp_path / "reads.fa.lz4"
+        p.write_bytes(lz4_frame(text, **kw))
+        reads, fasta = collect(str(p))
+        plain = tmp_path / "plain.fa"
+        plain.write_bytes(text)
+        assert fasta and reads == collect(str(plain))[0] and len(reads) == 40
+        assert len(p.read_bytes()) < 0.7 * len(text) or kw.get("store_every")                # the blocks really are compressed
+    # skippable frame + two concatenated frames
+    half = text.index(b">r20\n")
+    p = tmp_path / "two.fa.lz4"
+    p.write_bytes(struct.pack("<II", 0x184D2A50, 5) + b"hello" + lz4_frame(text[:half]) + lz4_frame(text[half:], linked=False))
+    assert collect(str(p))[0] == collect(str(tmp_path / "plain.fa"))[0]
+    # FASTQ by name, and a truncated stream is an error, not a silent short read
+    fq = tmp_path / "r.fastq.lz4"
+    fq.write_bytes(lz4_frame(b"@a\nACGT\n+\nIIII\n@b\nGG\n+\nII\n"))
+    assert collect(str(fq)) == ([b"ACGT", b"GG"], False)
+    bad = tmp_path / "bad.fa.lz4"
+    bad.write_bytes(lz4_frame(text)[:-30000])
+    with pytest.raises(Exception):
+        collect(str(bad))
