@@ -133,7 +133,7 @@ class Reader:
         err = C.c_int()
         self.h = L.mdbg_reader_open(path.encode(), int(strip_newlines), C.byref(err))
         if not self.h:
-            raise OSError("cannot open %s (err %d; .lz4 input is not supported)" % (path, err.value))
+            raise OSError("cannot open %s (err %d)" % (path, err.value))
         self.is_fasta = bool(L.mdbg_reader_is_fasta(self.h))
 
     def batches(self, max_bases=256 << 20):
