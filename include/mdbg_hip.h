@@ -17,6 +17,7 @@
  *   mdbg_finalize          abundance filter + read-only view of dbg_nodes              src/main.rs:922-929,1014-1016
  *                          + what the .sequences line of a node is built from          src/main.rs:693-708
  *   mdbg_graph_edges       km_index + orientation tests + presimp + overlaps           src/main.rs:1017-1117
+ *   mdbg_query_batch       --read_stats: abundance of every k-min-mer of a query read  src/main.rs:939-1004
  *   mdbg_reset             a new k over the same reads (utils/multik:69-78 re-runs the binary per k)
  *   mdbg_destroy           process exit
  *
@@ -155,6 +156,15 @@ int mdbg_pack_device(mdbg_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, ui
 int mdbg_sketch_only(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
                      const uint64_t** hashes, const uint64_t** positions, const uint64_t** per_read_offsets,
                      uint64_t* n_minimizers);
+
+/* --read_stats (src/main.rs:939-1004, src/read_stats.rs): for every read of the batch (HOST buffers, as mdbg_ingest_batch) and every
+ * k-min-mer window of it (reads with MORE than k minimizers only), the abundance of that k-min-mer in the table as it stands after the
+ * abundance filter: DbgEntry.abundance (u16) of a node that passes --minabund, else 0.  counts[per_read_offsets[r] ..
+ * per_read_offsets[r+1]) are the values of read r in window order - one ".read_stats" line "{id}: c0 c1 ... ".  The batch is sketched
+ * on the device and looked up there; neither the table nor the resident sketches change.  Library-owned HOST arrays, valid until the
+ * next call on ctx.  Not available on a context that holds routed records. */
+int mdbg_query_batch(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, const uint32_t** counts,
+                     const uint64_t** per_read_offsets, uint64_t* n_windows);
 
 int mdbg_finalize(mdbg_ctx* ctx, mdbg_nodes* out);
 /* Same node table, but every pointer in *out is DEVICE memory (no copy to the host). */

@@ -81,7 +81,7 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
            "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
-           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device"]
+           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch"]
 
 
 def lib_path():
@@ -119,6 +119,8 @@ def load_library():
     L.mdbg_ingest_batch_packed_device.argtypes = [vp, C.POINTER(PackedBatch), u64, u64]
     L.mdbg_sketch_packed_device.argtypes = [vp, C.POINTER(PackedBatch), u64, u64]
     L.mdbg_pack_device.argtypes = [vp, vp, u64, vp, vp, vp, u64, C.POINTER(u64)]
+    L.mdbg_query_batch.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(u32)), C.POINTER(C.POINTER(u64)), C.POINTER(u64)]
+    L.mdbg_query_batch.restype = C.c_int
     L.mdbg_sketch_only.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(u64)]
     L.mdbg_finalize.argtypes = [vp, C.POINTER(Nodes)]
     L.mdbg_finalize_device.argtypes = [vp, C.POINTER(Nodes)]
@@ -230,6 +232,15 @@ class Mdbg:
         n = C.c_uint64()
         self._chk(self.L.mdbg_pack_device(self.h, d_bases, n_bases, d_words, d_exc_pos, d_exc_val, exc_cap, C.byref(n)))
         return n.value
+
+    def query(self, bases, offsets):
+        """--read_stats: (counts u32[n_windows], per-read offsets u64[n_reads + 1])"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        pc, po, nw = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), C.c_uint64()
+        self._chk(self.L.mdbg_query_batch(self.h, bases.ctypes.data, offsets.ctypes.data, n, C.byref(pc), C.byref(po), C.byref(nw)))
+        return _np(pc, nw.value, np.uint32), _np(po, n + 1, np.uint64)
 
     def store_sketch(self):
         """host copy of the whole resident sketch store: hashes, positions, per-read offsets"""

@@ -452,6 +452,44 @@ __global__ __launch_bounds__(256) void wrap_scan_windows_kernel(TableArgs T, con
     const u32 pad = T.tab[s].pad;
     if (pad) occ[w_start[pad - 1] + atomicAdd(&w_fill[pad - 1], 1u)] = ord;
 }
+// --read_stats (src/main.rs:939-1004): abundance of the k-min-mer that starts at minimizer i in the FILTERED table, 0 when it
+// is absent or below the abundance filter; NO_WINDOW where no window starts (fewer than k minimizers left in the read, or
+// a read with at most k minimizers: src/main.rs:950, strictly more than k).
+constexpr u32 NO_WINDOW = 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void query_windows_kernel(TableArgs T, u32 A_filter, const u64* __restrict__ mh, const u32* __restrict__ mread,
+                                                            const u64* __restrict__ roff, u64 i0, u64 i1, u32* __restrict__ out) {
+    extern __shared__ u64 sh_keys[];
+    const u32 k = T.ks.k;
+    const u64 b0 = i0 + (u64)blockIdx.x * 256;
+    const u64 lim = b0 + 256 + k - 1 < i1 ? b0 + 256 + k - 1 : i1;
+    for (u64 t = b0 + threadIdx.x; t < lim; t += 256) sh_keys[t - b0] = mh[t];
+    const u64 i = b0 + threadIdx.x;
+    bool active = i < i1;
+    if (active) {
+        const u32 slot = mread[i];
+        const u64 rs = roff[slot], re = roff[slot + 1];
+        active = re - rs > k && i + k <= re;
+        if (!active) out[i - i0] = NO_WINDOW;
+    }
+    __syncthreads();
+    if (!active) return;
+    const u64* w = sh_keys + threadIdx.x;
+    const bool rev = window_reversed(w, k);
+    u32 ab = 0;
+    if (T.cap) {
+        const u64 s = find_slot(T, key_hash_window(w, k, rev), [&](u64 word) { return same_key_window(T.ks, word, w, rev); });
+        if (s != ~0ull) {
+            const u32 count = T.tab[s].count + 1u;
+            if (A_filter == 1 || (u16)count >= (u16)A_filter) ab = (u16)count;      // dbg_nodes.retain (main.rs:927), u16 abundance
+        }
+    }
+    out[i - i0] = ab;
+}
+void launch_query_windows(const TableArgs& T, u32 A_filter, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32* out, hipStream_t s) {
+    if (i1 <= i0) return;
+    const u64 n = i1 - i0;
+    hipLaunchKernelGGL(query_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (256 + T.ks.k) * 8, s, T, A_filter, mh, mread, roff, i0, i1, out);
+}
 __global__ __launch_bounds__(256) void wrap_scan_records_kernel(TableArgs T, u64 n_records, const u32* __restrict__ w_start, u32* __restrict__ w_fill, u64* __restrict__ occ) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_records) return;

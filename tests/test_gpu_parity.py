@@ -506,3 +506,35 @@ def test_l_above_32_runs_on_the_generic_walker(l):
         st = m.stats()
     assert st["n_slow_tiles"] == st["n_tiles"] > 0
     assert_nodes_equal(got, oracle_graph(reads, 5, l, 0.01, 2))
+
+
+@pytest.mark.parametrize("k,l,d,A", [(5, 10, 0.01, 2), (9, 12, 0.004, 1), (3, 8, 0.05, 3), (4, 8, 0.02, 12)])
+def test_read_stats_query(k, l, d, A):
+    """--read_stats (src/main.rs:939-1004): abundance of every k-min-mer of a query read in the FILTERED table, 0 when absent"""
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(5 + k, 150000, 260, mean_len=9000, sd_len=1500, min_len=2000, max_len=16000, err_ppm=3000)
+    query = synth.synth_reads(5 + k, 150000, 60, mean_len=9000, sd_len=1500, min_len=2000, max_len=16000, err_ppm=20000, first_read=100)
+    query += [b"", b"ACGT" * 3, rand_reads(1, 1, 30000, 30000)[0], reads[0]]
+    exp_nodes = oracle_graph(reads, k, l, d, A)
+    table = {tuple(int(x) for x in exp_nodes["keys"][i]): int(exp_nodes["abundance"][i]) for i in range(exp_nodes["n_nodes"])}
+    qb, qo = O.concat_reads(query)
+    sk = O.sketch(qb, qo, l, d)
+    exp_counts, exp_off = [], [0]
+    for r in range(len(query)):
+        h = [int(x) for x in sk["hashes"][int(sk["off"][r]):int(sk["off"][r + 1])]]
+        if len(h) > k:
+            for i in range(len(h) - k + 1):
+                w = tuple(h[i:i + k]); rv = w[::-1]
+                exp_counts.append(table.get(w if w < rv else rv, 0))
+        exp_off.append(len(exp_counts))
+    R = _mdbg()
+    with R.Mdbg(k, l, d, A) as m:
+        m.ingest_reads(reads, 0)
+        before = m.finalize()
+        counts, off = m.query(qb, qo)
+        st = m.stats()
+        after = m.finalize()
+    assert off.tolist() == exp_off and counts.tolist() == exp_counts
+    assert sum(1 for c in exp_counts if c) > 50 and sum(1 for c in exp_counts if c == 0) > 50
+    assert st["n_reads"] == len(reads)                       # the query left the resident sketches and the table alone
+    assert_nodes_equal(after, exp_nodes) and assert_nodes_equal(before, exp_nodes) is None
