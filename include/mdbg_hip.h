@@ -54,6 +54,10 @@ enum {
 #define MDBG_MAX_L 255u        /* l = 2..32 run on the bit-sliced kernel, longer l-mers on its generic exact walker (reference: unbounded) */
 #define MDBG_MAX_MINABUND 65535u /* DbgAbundance is a u16 in the reference; up to 8 the table tracks the A-th sighting directly, above it is recovered at finalize */
 #define MDBG_FLAG_FORCE_GENERIC 1u /* every tile takes the generic exact sketch kernel (testing / cross-check) */
+#define MDBG_SCHEME_DENSITY 0u   /* canonical ntHash <= density * 2^64           Read::extract_density   src/read.rs:176-211 */
+#define MDBG_SCHEME_SYNCMERS 1u  /* --syncmers: open syncmers (smallest s-mer in the middle), down-sampled by hash(l-mer) <= density * 4^l;
+                                  * 2-bit codes, A/a C/c G/g T/t/U/u, any other byte resets (no alphabet error); l <= 31
+                                  *                                              Read::extract_syncmers  src/read.rs:215-352 */
 
 typedef struct mdbg_ctx mdbg_ctx;
 
@@ -67,7 +71,9 @@ typedef struct mdbg_params {
     int32_t device;             /* HIP device ordinal, -1 = current device */
     uint32_t flags;             /* MDBG_FLAG_* */
     uint64_t table_capacity_hint; /* expected number of distinct k-min-mers, 0 = size from the data */
-    uint64_t reserved[4];
+    uint32_t scheme;            /* MDBG_SCHEME_*: how minimizers are selected (Read::extract, src/read.rs:85-90) */
+    uint32_t syncmer_s;         /* MDBG_SCHEME_SYNCMERS: s-mer length, 0..min(l, 16) with l - s + 1 <= 32 (-s, default 4 in the reference) */
+    uint64_t reserved[3];
 } mdbg_params;
 
 /* Read-only view of the abundance-filtered node table (what src/main.rs:1014-1117 iterates).

@@ -178,8 +178,93 @@ struct Entry { u32 index; u16 abundance; u32 seqlen; u16 shift0, shift1;
 struct SeqLine { u32 index; Kmer key; u64 read, start, end; u8 reversed; u64 s0, s1; };   // main.rs:702
 struct Edge { u32 n1; char o1; u32 n2; char o2; u32 overlap; };
 
+// src/read.rs:43-52 — the integer hash of the syncmer scheme (wrapping u64 arithmetic of a release build)
+static u64 sync_hash(u64 key, u64 mask) {
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+// src/read.rs:23-39 SEQ_NT4_TABLE: A/a 0, C/c 1, G/g 2, T/t/U/u 3, bytes 0..3 themselves, everything else 4
+static int nt4(u8 c) {
+    switch (c) {
+        case 0: case 'A': case 'a': return 0;
+        case 1: case 'C': case 'c': return 1;
+        case 2: case 'G': case 'g': return 2;
+        case 3: case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+// src/read.rs:215-352 — Read::extract_syncmers: an l-mer is kept when the smallest of its l-s+1 canonical s-mer hashes sits at
+// the middle s-mer (position t-1, t = ceil((l-s+1)/2)) AND hash(canonical l-mer) <= density * 4^l.  The minimum is TRACKED by the
+// reference's sliding deque (update_window, read.rs:55-80): leftmost minimum of the first full window, afterwards a new element
+// replaces it only when strictly smaller, and when the tracked element leaves, the window is rescanned from the back (rightmost
+// minimum).  A byte outside ACGTU (either case) resets everything.  s = 0: every l-mer is a candidate (read.rs:319-333).
+static int extract_syncmers(const u8* inp, size_t n, size_t l, size_t sm, double density, bool already_hpc, Sketch& out) {
+    out.transformed.clear(); out.pos.clear();
+    if (l < 1 || l > 31 || sm > l) return ORC_E_PARAM;
+    const u64 hash_bound_l = (u64)(density * (double)(1ull << (2 * l)));     // read.rs:218 (density as f64 * 4^l as f64) as u64, saturating
+    const double vb = density * (double)(1ull << (2 * l));
+    const u64 bound = !(vb > 0.0) ? 0 : (vb >= 18446744073709551616.0 ? UINT64_MAX : hash_bound_l);
+    std::string hpc; std::vector<u64> posvec;
+    const u8* seq; size_t len;
+    if (!already_hpc) { encode_rle(inp, n, hpc, posvec); seq = (const u8*)hpc.data(); len = hpc.size(); }
+    else { seq = inp; len = n; }
+    if (len < l) return ORC_OK;
+    const u64 smask = sm ? ((1ull << 2 * sm) - 1) : 0, lmask = (1ull << 2 * l) - 1;
+    const size_t t = (l - sm + 1 + 1) / 2;
+    std::vector<u64> qs; std::vector<size_t> qs_pos;        // the deque (front = index 0)
+    size_t qs_size = 0; u64 min_val = UINT64_MAX; long min_pos = -1;
+    u64 xl[2] = {0, 0}, xs[2] = {0, 0}; size_t lp = 0;
+    const u64 lshift = (l - 1) * 2, sshift = sm ? (sm - 1) * 2 : 0;
+    auto emit = [&](size_t i) {
+        const u64 yl = xl[0] < xl[1] ? xl[0] : xl[1];
+        const u64 h = sync_hash(yl, lmask);
+        if (h <= bound) { out.transformed.push_back(h); out.pos.push_back(already_hpc ? (u64)(i - l + 1) : posvec[i - l + 1]); }
+    };
+    for (size_t i = 0; i < len; ++i) {
+        const int c = nt4(seq[i]);
+        if (c < 4) {
+            xl[0] = (xl[0] << 2 | (u64)c) & lmask;
+            xl[1] = xl[1] >> 2 | (u64)(3 - c) << lshift;
+            if (sm) { xs[0] = (xs[0] << 2 | (u64)c) & smask; xs[1] = xs[1] >> 2 | (u64)(3 - c) << sshift; }
+            ++lp;
+            if (sm != 0) {
+                if (lp >= sm) {
+                    const u64 ys = xs[0] < xs[1] ? xs[0] : xs[1];
+                    const u64 hs = sync_hash(ys, smask);
+                    if (qs_size < l - sm) { qs.push_back(hs); qs_pos.push_back(i - sm + 1); ++qs_size; }
+                    else if (qs_size == l - sm) {
+                        qs.push_back(hs); qs_pos.push_back(i - sm + 1); ++qs_size;
+                        for (size_t j = 0; j < qs_size; ++j) if (qs[j] < min_val) { min_val = qs[j]; min_pos = (long)qs_pos[j]; }
+                        if (min_pos == (long)qs_pos[t - 1]) emit(i);
+                    } else {
+                        // update_window (read.rs:55-80)
+                        const size_t popped = qs_pos.front();
+                        qs.erase(qs.begin()); qs_pos.erase(qs_pos.begin());
+                        qs.push_back(hs); qs_pos.push_back(i - sm + 1);
+                        if (min_pos == (long)popped) {
+                            min_val = UINT64_MAX; min_pos = (long)(i - sm + 1);
+                            for (size_t j = qs.size(); j-- > 0;) if (qs[j] < min_val) { min_val = qs[j]; min_pos = (long)qs_pos[j]; }
+                        } else if (hs < min_val) { min_val = hs; min_pos = (long)(i - sm + 1); }
+                        if (min_pos == (long)qs_pos[t - 1]) emit(i);
+                    }
+                }
+            } else if (lp >= l) emit(i);
+        } else {
+            min_val = UINT64_MAX; min_pos = -1; lp = 0; xs[0] = xs[1] = xl[0] = xl[1] = 0; qs_size = 0; qs.clear(); qs_pos.clear();
+        }
+    }
+    return ORC_OK;
+}
+
 struct Graph {
     size_t k, l; double density; u16 minabund; bool already_hpc; float presimp;
+    bool syncmers = false; size_t sync_s = 0;      // --syncmers / -s (src/read.rs:88)
     std::map<Kmer, Entry> nodes;                  // dbg_nodes, main.rs:595 (ordered map: deterministic, same contents)
     u64 node_index = 0;                           // NODE_INDEX, main.rs:598
     std::vector<SeqLine> seqlines;
@@ -213,7 +298,7 @@ struct Graph {
 
     // src/main.rs:730-785 (process_read_aux), window loop :756-781
     int process_read(const u8* s, size_t n, u64 read_ordinal) {
-        Sketch sk; int e = extract_density(s, n, l, density, already_hpc, sk);
+        Sketch sk; int e = syncmers ? extract_syncmers(s, n, l, sync_s, density, already_hpc, sk) : extract_density(s, n, l, density, already_hpc, sk);
         if (e) return e;
         ++n_reads; n_minimizers += sk.transformed.size();
         const auto& T = sk.transformed; const auto& P = sk.pos;
@@ -327,6 +412,17 @@ orc_sketch_t* orc_sketch(const uint8_t* bases, const uint64_t* offsets, uint64_t
     }
     return r;
 }
+orc_sketch_t* orc_sketch_syncmers(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t l, uint64_t sm, double density, int already_hpc) {
+    auto* r = new orc_sketch_t(); r->err = 0; r->err_read = 0; r->off.push_back(0);
+    for (u64 i = 0; i < n_reads; ++i) {
+        Sketch sk; int e = extract_syncmers(bases + offsets[i], offsets[i + 1] - offsets[i], l, sm, density, already_hpc != 0, sk);
+        if (e && !r->err) { r->err = e; r->err_read = i; }
+        r->hashes.insert(r->hashes.end(), sk.transformed.begin(), sk.transformed.end());
+        r->pos.insert(r->pos.end(), sk.pos.begin(), sk.pos.end());
+        r->off.push_back(r->hashes.size());
+    }
+    return r;
+}
 int orc_sketch_err(orc_sketch_t* s) { return s->err; }
 uint64_t orc_sketch_n(orc_sketch_t* s) { return s->hashes.size(); }
 const uint64_t* orc_sketch_hashes(orc_sketch_t* s) { return s->hashes.data(); }
@@ -345,6 +441,7 @@ orc_graph_t* orc_graph_new(uint64_t k, uint64_t l, double density, uint32_t mina
     if (minabund == 0 || minabund > 65535 || k < 2 || l < 1) h->err = ORC_E_PARAM;
     return h;
 }
+void orc_graph_set_syncmers(orc_graph_t* h, uint64_t sm) { h->g.syncmers = true; h->g.sync_s = sm; if (h->g.l > 31 || sm > h->g.l) h->err = ORC_E_PARAM; }
 int orc_graph_ingest(orc_graph_t* h, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t first_read_ordinal) {
     if (h->err) return h->err;
     for (u64 i = 0; i < n_reads; ++i) {

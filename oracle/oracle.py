@@ -44,6 +44,9 @@ def lib():
     L.orc_revcomp.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p]
     L.orc_sketch.restype = C.c_void_p
     L.orc_sketch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int]
+    L.orc_sketch_syncmers.restype = C.c_void_p
+    L.orc_sketch_syncmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_int]
+    L.orc_graph_set_syncmers.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_sketch_err.restype = C.c_int
     L.orc_sketch_err.argtypes = [C.c_void_p]
     L.orc_sketch_n.restype = C.c_uint64
@@ -144,13 +147,16 @@ def concat_reads(reads):
     return bases, offs
 
 
-def sketch(bases, offsets, l, density, already_hpc=False):
-    """-> dict(hashes u64[m], pos u64[m], off u64[n+1], err int)"""
+def sketch(bases, offsets, l, density, already_hpc=False, syncmer_s=None):
+    """-> dict(hashes u64[m], pos u64[m], off u64[n+1], err int); syncmer_s: --syncmers -s (src/read.rs:215-352) instead of the density scheme"""
     L = lib()
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
-    h = L.orc_sketch(bases.ctypes.data, offsets.ctypes.data, n, l, density, int(already_hpc))
+    if syncmer_s is None:
+        h = L.orc_sketch(bases.ctypes.data, offsets.ctypes.data, n, l, density, int(already_hpc))
+    else:
+        h = L.orc_sketch_syncmers(bases.ctypes.data, offsets.ctypes.data, n, l, syncmer_s, density, int(already_hpc))
     try:
         m = L.orc_sketch_n(h)
         return dict(hashes=_arr(L.orc_sketch_hashes(h), m, np.uint64), pos=_arr(L.orc_sketch_pos(h), m, np.uint64),
@@ -162,10 +168,12 @@ def sketch(bases, offsets, l, density, already_hpc=False):
 class Graph:
     """Sequential reference semantics (= rust-mdbg --threads 1, no --bf)."""
 
-    def __init__(self, k, l, density, minabund=2, already_hpc=False, presimp=0.01):
+    def __init__(self, k, l, density, minabund=2, already_hpc=False, presimp=0.01, syncmer_s=None):
         self.L = lib()
         self.k = k
         self.h = self.L.orc_graph_new(k, l, density, minabund, int(already_hpc), presimp)
+        if syncmer_s is not None:
+            self.L.orc_graph_set_syncmers(self.h, syncmer_s)
         self.n_ingested = 0
 
     def ingest(self, bases, offsets, first_read_ordinal=None):

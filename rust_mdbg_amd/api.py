@@ -25,7 +25,7 @@ class MdbgError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("k", C.c_uint32), ("l", C.c_uint32), ("density", C.c_double), ("min_abundance", C.c_uint32),
                 ("reads_already_hpc", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("table_capacity_hint", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("table_capacity_hint", C.c_uint64), ("scheme", C.c_uint32), ("syncmer_s", C.c_uint32), ("reserved", C.c_uint64 * 3)]
 
 
 class Nodes(C.Structure):
@@ -182,10 +182,11 @@ def concat_reads(reads):
 class Mdbg:
     """One context = one device-resident sketch store + k-min-mer table (dbg_nodes, src/main.rs:595)."""
 
-    def __init__(self, k, l, density, min_abundance=2, reads_already_hpc=False, device=-1, flags=0, table_capacity_hint=0):
+    def __init__(self, k, l, density, min_abundance=2, reads_already_hpc=False, device=-1, flags=0, table_capacity_hint=0, syncmer_s=None):
         self.L = load_library()
         self.params = Params(k=k, l=l, density=density, min_abundance=min_abundance, reads_already_hpc=int(reads_already_hpc),
-                             device=device, flags=flags, table_capacity_hint=table_capacity_hint)
+                             device=device, flags=flags, table_capacity_hint=table_capacity_hint,
+                             scheme=0 if syncmer_s is None else 1, syncmer_s=0 if syncmer_s is None else syncmer_s)      # syncmer_s: --syncmers -s
         err = C.c_int(0)
         self.h = self.L.mdbg_create(C.byref(self.params), C.byref(err))
         if not self.h:

@@ -601,6 +601,156 @@ __global__ void tile_flags_kernel(const u64* __restrict__ exc_pos, u32 n_exc, u3
     if (t + 1 < n_tiles && p + HALO_BASES >= (t + 1) * (u64)TILE_STRIDE) flags[t + 1] = 1;      // falls into the next tile's look-back window
 }
 
+// ---- syncmer scheme (src/read.rs:215-352, --syncmers -s) -----------------------------------------------------------------
+// An l-mer of the (homopolymer-compressed) read is kept when the smallest of its w = l-s+1 canonical s-mer hashes sits at the middle
+// s-mer (index t-1, t = ceil(w/2)) and hash(canonical 2-bit l-mer) <= density * 4^l.  "Smallest" is the minimum TRACKED by the
+// reference's sliding deque (update_window, read.rs:55-80): leftmost minimum of the first full window; later a new s-mer replaces it
+// only when strictly smaller, and when the tracked s-mer leaves the window the window is rescanned from the back (rightmost minimum).
+// With s = 4 there are only 136 canonical s-mers, so tied minima are common and the history matters.  The state machine is
+// sequential, but it FORGETS: at any window whose minimum is unique the tracked position is that minimum whatever happened before.
+// One thread per 256 raw positions: it starts the machine some distance in front of its segment and runs until a unique-minimum
+// window (or a reset: read start / a byte outside ACGTU) has been seen — from there on its state is the reference's — looking
+// further back (96, 384, ... positions, at most to the read start) in the rare case that it reaches its segment unconverged.
+constexpr int SYNC_SEG = 256;                       // raw positions per thread
+constexpr int SYNC_TILE = TT * SYNC_SEG;            // raw positions per workgroup
+constexpr int SYNC_KEEP = 4;                        // records a thread keeps in registers between the count and the write
+struct SyncArgs {
+    const u8* bases; const uint2* planes; u32 fmt; const u64* exc_pos; const u8* exc_val; u32 n_exc;
+    u64 n_bases; const u64* offsets; u32 n_reads;
+    u32 tile0; Rec* slab; u32 slab_cap; u32* n_valid; u32* over_max;
+    u32 read_base; u32 l, s, hpc; u64 bound;        // bound = floor(density * 4^l), saturating (read.rs:218)
+};
+__device__ inline u64 sync_hash(u64 key, u64 mask) {          // src/read.rs:43-52
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+__device__ inline u32 nt4_code(u8 c) {                         // src/read.rs:23-39 (SEQ_NT4_TABLE)
+    switch (c) {
+        case 0: case 'A': case 'a': return 0;
+        case 1: case 'C': case 'c': return 1;
+        case 2: case 'G': case 'g': return 2;
+        case 3: case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+template <bool HPC, class Src>
+__global__ __launch_bounds__(TT) void syncmer_tile_kernel(SyncArgs a, Src src) {
+    __shared__ u32 dq[32][TT];                     // per-thread ring of the last <= 32 s-mer hashes (s <= 16: 32 bits), column = thread
+    __shared__ u32 sc_tmp[8];
+    __shared__ u32 any_over;
+    const int tid = threadIdx.x;
+    const u32 gt = a.tile0 + blockIdx.x;
+    Rec* const slab = a.slab + (size_t)blockIdx.x * a.slab_cap;
+    const u32 l = a.l, sm = a.s, w = l - sm + 1, t = (w + 1) / 2;
+    const u64 smask = sm ? ((1ull << (2 * sm)) - 1) : 0, lmask = (1ull << (2 * l)) - 1;
+    const u64 lshift = (u64)(l - 1) * 2, sshift = sm ? (u64)(sm - 1) * 2 : 0;
+    const u64 first_base = a.offsets[0];
+    u64 own_lo = (u64)gt * SYNC_TILE + (u64)tid * SYNC_SEG, own_hi = own_lo + SYNC_SEG;
+    if (own_lo < first_base) own_lo = first_base;
+    if (own_hi > a.n_bases) own_hi = a.n_bases;
+    if (tid == 0) any_over = 0;
+    __syncthreads();
+
+    // one run of the state machine over my segment; WRITE: records go to the slab from rank `base`, else up to SYNC_KEEP are kept
+    Rec keep[SYNC_KEEP]; u32 n_mine = 0;
+    auto run = [&](bool write, u32 base) {
+        n_mine = 0;
+        if (own_lo >= own_hi) return;
+        u32 r = find_read(a.offsets, 0, a.n_reads - 1, own_lo);
+        for (u64 look = 96;; look *= 4) {
+            // start: `look` positions in front of my segment, not before my first position's read (state is exact from a read start)
+            u64 rlo = a.offsets[r], rhi = a.offsets[r + 1];
+            u64 q = own_lo > rlo + look ? own_lo - look : rlo;
+            bool conv = q == rlo;                                 // the machine's state equals the reference's
+            u32 rr = r;
+            u64 xl0 = 0, xl1 = 0, xs0 = 0, xs1 = 0, min_val = ~0ull; u32 lp = 0, cnt = 0, min_idx = 0, warm = 0;
+            u8 prev = q > rlo ? src.at(q - 1) : 0;
+            bool restart = false;
+            for (; q < own_hi; ++q) {
+                while (q >= rhi) { ++rr; rlo = rhi; rhi = a.offsets[rr + 1]; lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; }   // next read: reset
+                if (q == own_lo && !conv) { restart = true; break; }
+                const u8 c = src.at(q);
+                const bool kept = !HPC || q == rlo || !(c == prev && in_hpc_set(c));
+                prev = c;
+                if (!kept) continue;
+                const u32 code = nt4_code(c);
+                if (code >= 4) { lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; continue; }      // read.rs:334-341
+                xl0 = (xl0 << 2 | code) & lmask; xl1 = xl1 >> 2 | (u64)(3 - code) << lshift;
+                if (sm) { xs0 = (xs0 << 2 | code) & smask; xs1 = xs1 >> 2 | (u64)(3 - code) << sshift; }
+                ++lp; ++warm;
+                bool cand = false;
+                if (sm == 0) cand = lp >= l;
+                else if (lp >= sm) {
+                    const u32 hs = (u32)sync_hash(xs0 < xs1 ? xs0 : xs1, smask);
+                    ++cnt;
+                    dq[cnt & 31][tid] = hs;
+                    if (cnt >= w) {
+                        if (cnt == w) {                            // first full window: leftmost minimum (read.rs:283-289)
+                            min_val = ~0ull;
+                            for (u32 j = cnt - w + 1; j <= cnt; ++j) { const u32 v = dq[j & 31][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
+                        } else if (min_idx == cnt - w) {           // the tracked s-mer left: rescan from the back (read.rs:63-72)
+                            min_val = ~0ull;
+                            for (u32 j = cnt; j + w > cnt; --j) { const u32 v = dq[j & 31][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
+                        } else if (hs < min_val) { min_val = hs; min_idx = cnt; }
+                        if (!conv && warm > l) {                   // everything in the window comes from bases behind my start: a unique minimum pins the state
+                            u32 ties = 0;
+                            for (u32 j = cnt - w + 1; j <= cnt; ++j) ties += dq[j & 31][tid] == (u32)min_val;
+                            conv = ties == 1;
+                        }
+                        cand = min_idx == cnt - w + t;
+                    }
+                }
+                if (sm == 0 && !conv && warm > l) conv = true;    // no tracked minimum in this mode: l genuine bases are all the state there is
+                if (cand && q >= own_lo) {
+                    const u64 hl = sync_hash(xl0 < xl1 ? xl0 : xl1, lmask);
+                    if (hl <= a.bound) {
+                        // raw position of the l-mer's first base: l-1 run starts back
+                        u64 st = q;
+                        for (u32 j = 1; j < l; ++j) {
+                            u64 q2 = st - 1;
+                            if (HPC) { const u8 c2 = src.at(q2); if (in_hpc_set(c2)) while (q2 > rlo && src.at(q2 - 1) == c2) --q2; }
+                            st = q2;
+                        }
+                        Rec rec; rec.hash = hl; rec.pos = (u32)(st - rlo); rec.read = rr + a.read_base;
+                        if (write) { if (base + n_mine < a.slab_cap) slab[base + n_mine] = rec; }
+                        else if (n_mine < SYNC_KEEP) keep[n_mine] = rec;
+                        ++n_mine;
+                    }
+                }
+            }
+            if (!restart) break;
+            n_mine = 0;
+        }
+    };
+    run(false, 0);
+    if (n_mine > SYNC_KEEP) any_over = 1;
+    u32 total;
+    const u32 base = block_excl_scan_256(n_mine, sc_tmp, total);          // (its barriers publish any_over)
+    if (!any_over) {
+        for (u32 i = 0; i < n_mine; ++i) if (base + i < a.slab_cap) slab[base + i] = keep[i];
+    } else run(true, base);
+    if (tid == 0) { a.n_valid[gt] = total; if (total > a.slab_cap) atomicMax(a.over_max, total); }
+}
+
+template <class Src> static void launch_sync_src(const SyncArgs& a, u32 n_wg, const Src& src, hipStream_t s) {
+    if (a.hpc) hipLaunchKernelGGL((syncmer_tile_kernel<true, Src>), dim3(n_wg), dim3(TT), 0, s, a, src);
+    else hipLaunchKernelGGL((syncmer_tile_kernel<false, Src>), dim3(n_wg), dim3(TT), 0, s, a, src);
+}
+void launch_syncmers(const SyncArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+    if (!n_wg) return;
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    if (a.fmt == FMT_ASCII) launch_sync_src(a, n_wg, AsciiSrc{a.bases}, s);
+    else launch_sync_src(a, n_wg, PlaneSrc{a.planes, a.exc_pos, a.exc_val, a.n_exc}, s);
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+}
+
 // ---- ASCII -> 2-bit planes on the device (mdbg_pack_device) -------------------------------------------------------
 // one thread per 32 bases; bytes outside ACGT are appended (unordered) to the exception list
 __global__ __launch_bounds__(256) void pack_planes_kernel(const u8* __restrict__ bases, u64 n_bases, uint2* __restrict__ words,

@@ -106,11 +106,92 @@ def sketch_read(seq, l, density, already_hpc=False):
     return h[sel], pos[sel]
 
 
+def wang_hash(key, mask):
+    """src/read.rs:43-52 (u64 arithmetic wraps in a release build)"""
+    M = (1 << 64) - 1
+    key = ((~key & M) + ((key << 21) & M)) & M & mask
+    key = key ^ (key >> 24)
+    key = (key + ((key << 3) & M) + ((key << 8) & M)) & M & mask
+    key = key ^ (key >> 14)
+    key = (key + ((key << 2) & M) + ((key << 4) & M)) & M & mask
+    key = key ^ (key >> 28)
+    key = (key + ((key << 31) & M)) & M & mask
+    return key
+
+
+NT4 = {**{c: i for i, cs in enumerate(("Aa", "Cc", "Gg", "TtUu")) for c in cs.encode()}, 0: 0, 1: 1, 2: 2, 3: 3}
+
+
+def sketch_read_syncmers(seq, l, s, density, already_hpc=False):
+    """src/read.rs:215-352 written as a plain state machine over the (HPC) text: canonical 2-bit l-mer / s-mer values are recomputed
+    from the text for every position (no rolling), the tracked minimum follows update_window (read.rs:55-80)"""
+    if already_hpc:
+        text = np.frombuffer(seq, dtype=np.uint8)
+        pos = np.arange(len(text), dtype=np.int64)
+    else:
+        text, pos = run_starts(seq)
+    if len(seq) == 0 and not already_hpc:
+        return [], []
+    hs, ps = [], []
+    if len(text) < l:
+        return hs, ps
+    v = float(density) * float(4 ** l)
+    bound = 0 if not v > 0.0 else ((1 << 64) - 1 if v >= 18446744073709551616.0 else int(v))
+    codes = [NT4.get(int(c), 4) for c in text]
+
+    def canon(i, n):                     # canonical value of the n-mer ending at i
+        f = r = 0
+        for j in range(i - n + 1, i + 1):
+            f = (f << 2) | codes[j]
+        for j in range(i, i - n, -1):
+            r = (r << 2) | (3 - codes[j])
+        return min(f, r)
+    w = l - s + 1                        # s-mers per l-mer
+    t = (w + 1) // 2
+    run = 0                              # valid bases since the last reset
+    window = []                          # [(hash, position)] of the last <= w s-mers, oldest first
+    tracked = None                       # position of the tracked minimum
+    for i, c in enumerate(codes):
+        if c == 4:
+            run, window, tracked = 0, [], None
+            continue
+        run += 1
+        emit = False
+        if s == 0:
+            emit = run >= l
+        elif run >= s:
+            h = wang_hash(canon(i, s), (1 << (2 * s)) - 1)
+            if len(window) < w - 1:
+                window.append((h, i - s + 1))
+            elif len(window) == w - 1:
+                window.append((h, i - s + 1))
+                best = min(x[0] for x in window)
+                tracked = next(p for x, p in window if x == best)            # first full window: leftmost minimum
+                emit = tracked == window[t - 1][1]
+            else:
+                gone = window.pop(0)[1]
+                window.append((h, i - s + 1))
+                cur = dict((p, x) for x, p in window).get(tracked)
+                if tracked == gone:
+                    best = min(x[0] for x in window)
+                    tracked = [p for x, p in window if x == best][-1]       # rescan from the back: rightmost minimum
+                elif h < cur:
+                    tracked = i - s + 1
+                emit = tracked == window[t - 1][1]
+        if emit:
+            hl = wang_hash(canon(i, l), (1 << (2 * l)) - 1)
+            if hl <= bound:
+                hs.append(hl)
+                ps.append(int(pos[i - l + 1]))
+    return hs, ps
+
+
 class Graph:
     """src/main.rs:632-709,756-781 with --threads 1 and without --bf"""
 
-    def __init__(self, k, l, density, minabund, already_hpc=False):
+    def __init__(self, k, l, density, minabund, already_hpc=False, syncmer_s=None):
         self.k, self.l, self.d, self.A, self.hpc_in = k, l, density, minabund, already_hpc
+        self.sync_s = syncmer_s
         self.nodes = {}          # key tuple -> [index, abundance(u16), seqlen(u32), shift(u16,u16), reversed, src_read, src_start, src_end, shift_full]
         self.next_index = 0
         self.n_minimizers = 0
@@ -118,7 +199,11 @@ class Graph:
         self.sketches = []
 
     def add_read(self, ordinal, seq):
-        sk = sketch_read(seq, self.l, self.d, self.hpc_in)
+        if self.sync_s is not None:
+            hs_, ps_ = sketch_read_syncmers(seq, self.l, self.sync_s, self.d, self.hpc_in)
+            sk = (np.array(hs_, dtype=U64), np.array(ps_, dtype=np.int64))
+        else:
+            sk = sketch_read(seq, self.l, self.d, self.hpc_in)
         if sk is None:
             return False
         h, p = sk
@@ -285,12 +370,59 @@ def random_cases(seed=20260927, n_cases=48):
     return cases
 
 
+def syncmer_cases(seed=20260928, n_cases=20):
+    """--syncmers -s (src/read.rs:215-352): small s makes ties between s-mer hashes frequent, which is what exercises the tracked minimum"""
+    rnd = random.Random(seed)
+    cases = []
+    for ci in range(n_cases):
+        genome = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([400, 1500, 5000])))
+        if ci % 4 == 1:                                   # tandem repeats: every window has tied minima
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([2, 3, 5, 7])))
+            genome = genome[:200] + unit * 120 + genome[200:600]
+        if ci % 5 == 2:
+            genome = "".join(ch * rnd.choice([1, 1, 2, 3, 8]) for ch in genome[:600])
+        reads = []
+        for _ in range(rnd.randint(1, 10)):
+            a = rnd.randrange(len(genome))
+            r = genome[a:min(len(genome), a + rnd.choice([0, 8, 60, 400, 1500, 4000]))]
+            if rnd.random() < 0.3:
+                r = "".join(COMPLEMENT[c] for c in reversed(r))
+            if rnd.random() < 0.3 and r:
+                p = rnd.randrange(len(r))
+                r = r[:p] + rnd.choice(["N", "NN", "n", "X", "acgu"]) + r[p + 1:]
+            reads.append(r)
+        l = rnd.choice([5, 8, 10, 12, 14, 17, 24, 31])
+        sm = rnd.choice([0, 1, 2, 3, 4, 5, 8, l])
+        sm = min(sm, l, 16)
+        if l - sm + 1 > 32:
+            sm = l - 31
+        k = rnd.choice([2, 3, 4, 6])
+        d = rnd.choice([0.01, 0.1, 0.5, 1.0])
+        A = rnd.choice([1, 2, 2, 3])
+        hpc_in = rnd.random() < 0.25
+        presimp = rnd.choice([0.0, 0.01])
+        g = Graph(k, l, d, A, hpc_in, syncmer_s=sm)
+        for i, r in enumerate(reads):
+            assert g.add_read(i, r.encode())
+        res = g.finalize(presimp)
+        case = dict(reads=reads, k=k, l=l, density=d, minabund=A, already_hpc=hpc_in, presimp=presimp, syncmer_s=sm)
+        case["sketch"] = [[[int(x) for x in s_[1]], [int(x) for x in s_[0]]] for s_ in g.sketches]
+        case.update({f: res[f] for f in ("n_minimizers", "n_windows", "n_nodes_before", "n_nodes", "presimp_removed")})
+        case["nodes"] = res["nodes"]
+        case["edges"] = [list(e) for e in res["edges"]]
+        cases.append(case)
+    return cases
+
+
 if __name__ == "__main__":
     c1 = config1()
     json.dump(c1, open(os.path.join(HERE, "independent_cfg1.json"), "w"), indent=1)
     print("config 1:", {f: c1[f] for f in ("n_minimizers", "n_windows", "n_nodes_before", "n_nodes", "n_edges")}, c1["nodes_sha256"][:16])
     cs = random_cases()
     json.dump(dict(generator="tests/golden/independent_restatement.py", seed=20260927, cases=cs), open(os.path.join(HERE, "independent_cases.json"), "w"))
+    sc = syncmer_cases()
+    json.dump(dict(generator="tests/golden/independent_restatement.py", seed=20260928, cases=sc), open(os.path.join(HERE, "independent_syncmer_cases.json"), "w"))
+    print(len(sc), "syncmer cases,", sum(c["n_minimizers"] for c in sc), "minimizers,", sum(c["n_nodes"] for c in sc), "nodes")
     print(len(cs), "cases,", sum("error_read" in c for c in cs), "with the alphabet error,", sum(c.get("n_nodes", 0) for c in cs), "nodes,",
           sum(len(c.get("edges", [])) for c in cs), "edges")
     sys.exit(0)

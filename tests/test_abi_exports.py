@@ -38,7 +38,7 @@ def test_emit_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     import ctypes as C
     from rust_mdbg_amd import api
-    assert C.sizeof(api.Params) == 4 + 4 + 8 + 4 + 4 + 4 + 4 + 8 + 32
+    assert C.sizeof(api.Params) == 4 + 4 + 8 + 4 + 4 + 4 + 4 + 8 + 4 + 4 + 24
     assert C.sizeof(api.Stats) == 8 * 8 + 4 * 8 + 2 * 8 + 5 * 8
     assert C.sizeof(api.SynthParams) == 3 * 8 + 6 * 4
     assert api.Nodes.keys.offset == 16 and api.Nodes.n_distinct.offset == 16 + 10 * 8

@@ -69,3 +69,34 @@ def test_oracle_equals_independent_restatement_case(ci):
     got = sorted([int(a), chr(b), int(cc), chr(d), int(e)] for a, b, cc, d, e in
                  zip(r["edge_n1"], r["edge_o1"], r["edge_n2"], r["edge_o2"], r["edge_overlap"]))
     assert got == sorted(c["edges"])
+
+
+SYNC_CASES = json.load(open(os.path.join(GOLDEN, "independent_syncmer_cases.json")))["cases"]
+
+
+def test_syncmer_fixtures_are_what_the_restatement_generates_today():
+    from golden import independent_restatement as I
+    assert json.loads(json.dumps(I.syncmer_cases())) == SYNC_CASES
+
+
+@pytest.mark.parametrize("ci", range(len(SYNC_CASES)))
+def test_oracle_syncmers_equal_independent_restatement(ci):
+    c = SYNC_CASES[ci]
+    reads = [r.encode() for r in c["reads"]]
+    bases, offs = O.concat_reads(reads)
+    sk = O.sketch(bases, offs, c["l"], c["density"], c["already_hpc"], syncmer_s=c["syncmer_s"])
+    assert sk["err"] == 0
+    o = sk["off"]
+    for i, (pos, hs) in enumerate(c["sketch"]):
+        assert sk["pos"][int(o[i]):int(o[i + 1])].tolist() == pos and sk["hashes"][int(o[i]):int(o[i + 1])].tolist() == hs, ("sketch of read", i)
+    g = O.Graph(c["k"], c["l"], c["density"], c["minabund"], c["already_hpc"], c["presimp"], syncmer_s=c["syncmer_s"])
+    assert g.ingest(bases, offs) == 0
+    r = g.finalize()
+    for f in ("n_minimizers", "n_windows", "n_nodes_before", "n_nodes", "presimp_removed"):
+        assert r[f] == c[f], f
+    for row, n in enumerate(c["nodes"]):
+        assert r["keys"][row].tolist() == n["key"] and int(r["index"][row]) == n["index"] and int(r["abundance"][row]) == n["abundance"]
+        assert int(r["seqlen"][row]) == n["seqlen"] and r["shift"][row].tolist() == n["shift"] and int(r["src_start"][row]) == n["src_start"]
+    got = sorted([int(a), chr(b), int(cc), chr(d), int(e)] for a, b, cc, d, e in
+                 zip(r["edge_n1"], r["edge_o1"], r["edge_n2"], r["edge_o2"], r["edge_overlap"]))
+    assert got == sorted(c["edges"])
