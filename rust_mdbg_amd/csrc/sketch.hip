@@ -66,6 +66,12 @@ __global__ void bread_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bas
 struct AsciiSrc {
     const u8* b;
     __device__ u8 at(u64 q) const { return b[q]; }
+    // the 16 bytes at q0 (a multiple of 16) as two little-endian words; bytes past n_bases are never looked at by the caller
+    __device__ void chunk16(u64 q0, u64 n_bases, u64& lo, u64& hi) const {
+        if (q0 + 16 <= n_bases) { const uint4 v = *(const uint4*)(b + q0); lo = (u64)v.x | (u64)v.y << 32; hi = (u64)v.z | (u64)v.w << 32; return; }
+        lo = hi = 0;
+        for (int i = 0; i < 16 && q0 + i < n_bases; ++i) { const u64 c = b[q0 + i]; if (i < 8) lo |= c << (8 * i); else hi |= c << (8 * (i - 8)); }
+    }
 };
 struct PlaneSrc {
     const uint2* w; const u64* exc_pos; const u8* exc_val; u32 n_exc;
@@ -78,6 +84,18 @@ struct PlaneSrc {
         const uint2 p = w[q >> 5];
         const u32 c = ((p.x >> (q & 31)) & 1u) | (((p.y >> (q & 31)) & 1u) << 1);
         return (u8)(0x47544341u >> (8 * c));           // "ACTG"[code]
+    }
+    __device__ void chunk16(u64 q0, u64 n_bases, u64& lo, u64& hi) const {
+        lo = hi = 0;
+        if (n_exc) { for (int i = 0; i < 16 && q0 + i < n_bases; ++i) { const u64 c = at(q0 + i); if (i < 8) lo |= c << (8 * i); else hi |= c << (8 * (i - 8)); } return; }
+        const uint2 p = w[q0 >> 5];
+        const u32 sh = (u32)(q0 & 31), p0 = p.x >> sh, p1 = p.y >> sh;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const u32 c = ((p0 >> i) & 1u) | (((p1 >> i) & 1u) << 1);
+            const u64 ch = (0x47544341u >> (8 * c)) & 0xFFu;
+            if (i < 8) lo |= ch << (8 * i); else hi |= ch << (8 * (i - 8));
+        }
     }
 };
 
@@ -613,7 +631,7 @@ __global__ void tile_flags_kernel(const u64* __restrict__ exc_pos, u32 n_exc, u3
 // further back (96, 384, ... positions, at most to the read start) in the rare case that it reaches its segment unconverged.
 constexpr int SYNC_SEG = 256;                       // raw positions per thread
 constexpr int SYNC_TILE = TT * SYNC_SEG;            // raw positions per workgroup
-constexpr int SYNC_KEEP = 4;                        // records a thread keeps in registers between the count and the write
+constexpr int SYNC_KEEP = 8;                        // records a thread keeps between the count and the write (more: the tile runs a second time)
 struct SyncArgs {
     const u8* bases; const uint2* planes; u32 fmt; const u64* exc_pos; const u8* exc_val; u32 n_exc;
     u64 n_bases; const u64* offsets; u32 n_reads;
@@ -621,6 +639,17 @@ struct SyncArgs {
     u32 read_base; u32 l, s, hpc; u64 bound;        // bound = floor(density * 4^l), saturating (read.rs:218)
 };
 __device__ inline u64 sync_hash(u64 key, u64 mask) {          // src/read.rs:43-52
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+// the same function on 32-bit values: with a mask of at most 32 bits every step only looks at the low 32 bits of its operands
+__device__ inline u32 sync_hash32(u32 key, u32 mask) {
     key = (~key + (key << 21)) & mask;
     key = key ^ key >> 24;
     key = ((key + (key << 3)) + (key << 8)) & mask;
@@ -670,25 +699,28 @@ __global__ __launch_bounds__(TT) void syncmer_tile_kernel(SyncArgs a, Src src) {
             u64 q = own_lo > rlo + look ? own_lo - look : rlo;
             bool conv = q == rlo;                                 // the machine's state equals the reference's
             u32 rr = r;
-            u64 xl0 = 0, xl1 = 0, xs0 = 0, xs1 = 0, min_val = ~0ull; u32 lp = 0, cnt = 0, min_idx = 0, warm = 0;
+            u64 xl0 = 0, xl1 = 0, min_val = ~0ull; u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, min_idx = 0, warm = 0;      // s <= 16: the s-mer fits 32 bits
             u8 prev = q > rlo ? src.at(q - 1) : 0;
             bool restart = false;
+            u64 clo = 0, chi = 0, cbase = ~0ull;                  // the 16 input bytes around q (one load per 16 positions instead of one per position)
             for (; q < own_hi; ++q) {
                 while (q >= rhi) { ++rr; rlo = rhi; rhi = a.offsets[rr + 1]; lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; }   // next read: reset
                 if (q == own_lo && !conv) { restart = true; break; }
-                const u8 c = src.at(q);
+                if ((q & ~15ull) != cbase) { cbase = q & ~15ull; src.chunk16(cbase, a.n_bases, clo, chi); }
+                const u32 bi = (u32)(q & 15);
+                const u8 c = (u8)(((bi & 8) ? chi : clo) >> (8 * (bi & 7)));
                 const bool kept = !HPC || q == rlo || !(c == prev && in_hpc_set(c));
                 prev = c;
                 if (!kept) continue;
                 const u32 code = nt4_code(c);
                 if (code >= 4) { lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; continue; }      // read.rs:334-341
                 xl0 = (xl0 << 2 | code) & lmask; xl1 = xl1 >> 2 | (u64)(3 - code) << lshift;
-                if (sm) { xs0 = (xs0 << 2 | code) & smask; xs1 = xs1 >> 2 | (u64)(3 - code) << sshift; }
+                if (sm) { xs0 = (xs0 << 2 | code) & (u32)smask; xs1 = xs1 >> 2 | (3 - code) << (u32)sshift; }
                 ++lp; ++warm;
                 bool cand = false;
                 if (sm == 0) cand = lp >= l;
                 else if (lp >= sm) {
-                    const u32 hs = (u32)sync_hash(xs0 < xs1 ? xs0 : xs1, smask);
+                    const u32 hs = sync_hash32(xs0 < xs1 ? xs0 : xs1, (u32)smask);
                     ++cnt;
                     dq[cnt & 31][tid] = hs;
                     if (cnt >= w) {
