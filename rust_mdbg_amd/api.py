@@ -81,7 +81,7 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
            "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
-           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch"]
+           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed"]
 
 
 def lib_path():
@@ -143,6 +143,10 @@ def load_library():
     L.mdbg_sketch_reserve.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.mdbg_sketch_commit.argtypes = [vp, u64, u64, vp, u64, u64, u64]
     L.mdbg_owner_counts.argtypes = [vp, u32, vp]
+    L.mdbg_owner_lists.argtypes = [vp, u32, vp, C.POINTER(vp)]
+    L.mdbg_owner_lists.restype = C.c_int
+    L.mdbg_sketch_commit_listed.argtypes = [vp, u64, u64, vp, u64, u64, vp, u64]
+    L.mdbg_sketch_commit_listed.restype = C.c_int
     L.mdbg_last_batch.argtypes = [vp, C.POINTER(BatchInfo)]
     L.mdbg_graph_edges.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
     L.mdbg_graph_edges_device.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
@@ -362,6 +366,16 @@ class Mdbg:
         """owned_windows: number of windows of this batch the context owns (from the sender's owner_counts), None = unknown"""
         ow = 0xFFFFFFFFFFFFFFFF if owned_windows is None else int(owned_windows)
         self._chk(self.L.mdbg_sketch_commit(self.h, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal, ow))
+
+    def owner_lists(self, world):
+        """-> (counts per owning rank, DEVICE pointer to the window lists bucketed by owner) for the batch registered last"""
+        out = (C.c_uint64 * world)()
+        p = C.c_void_p()
+        self._chk(self.L.mdbg_owner_lists(self.h, world, out, C.byref(p)))
+        return [int(x) for x in out], (p.value or 0)
+
+    def sketch_commit_listed(self, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal, d_list, n_list):
+        self._chk(self.L.mdbg_sketch_commit_listed(self.h, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal, d_list, n_list))
 
     def owner_counts(self, world):
         """windows of the batch registered last per owning rank -> list of `world` ints"""

@@ -253,6 +253,86 @@ __global__ __launch_bounds__(256) void insert_owned_windows_kernel(TableArgs T, 
     }
 }
 
+// ---- owner lists (replicated-sketch mode) -----------------------------------------------------------------------------------------
+// The rank that sketched a batch also lists, per owning rank, the windows that rank owns (u32 index of the window's first minimizer,
+// relative to the batch): 4 bytes per window shipped with the sketch, so that a receiver inserts exactly its windows instead of
+// scanning every foreign sketch for them — the per-rank work no longer grows with the number of ranks.
+// Two passes with per-block counts and a scan in between (deterministic bucket sizes, no same-address atomics on global counters).
+constexpr int OWNL_SPAN = 4096;               // window starts per block (the per-block counts are scanned by one workgroup per owner: keep them few)
+constexpr u32 OWNL_MAX_WORLD = 64;
+struct OwnerBases { u64 b[OWNL_MAX_WORLD]; }; // start of every owner's bucket in the list
+__device__ inline bool window_starts_at(const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i, u64 i1, u32 k) {
+    if (i >= i1) return false;
+    const u32 slot = mread[i];
+    const u64 rs = roff[slot], re = roff[slot + 1];
+    return re - rs > k && i + k <= re;
+}
+__global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
+                                                               u32 k, u32 world, u32* __restrict__ blk_cnt) {
+    __shared__ u32 hist[OWNL_MAX_WORLD];
+    if (threadIdx.x < world) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
+#pragma unroll
+    for (int u = 0; u < OWNL_SPAN / 256; ++u) {
+        const u64 i = b0 + u * 256 + threadIdx.x;
+        if (window_starts_at(mread, roff, i, i1, k)) atomicAdd(&hist[window_owner(mh + i, k, world)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < world) blk_cnt[(size_t)blockIdx.x * world + threadIdx.x] = hist[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
+                                                               u32 k, u32 world, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list) {
+    __shared__ u32 lcnt[OWNL_MAX_WORLD];
+    if (threadIdx.x < world) lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
+#pragma unroll
+    for (int u = 0; u < OWNL_SPAN / 256; ++u) {
+        const u64 i = b0 + u * 256 + threadIdx.x;
+        if (window_starts_at(mread, roff, i, i1, k)) {
+            const u32 o = window_owner(mh + i, k, world);
+            const u32 r = atomicAdd(&lcnt[o], 1u);
+            list[bases.b[o] + blk_off[(size_t)blockIdx.x * world + o] + r] = (u32)(i - i0);
+        }
+    }
+}
+// inserts exactly the listed windows of the batch whose minimizers start at m0 (keys are read from the resident store)
+__global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff,
+                                                                    u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u64 first_ordinal,
+                                                                    u32* __restrict__ cap_err) {
+    if (cap_err[1]) return;
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 k = T.ks.k;
+    bool ok = j < n;
+    u64 i = 0;
+    if (ok) { i = m0 + list[j]; ok = window_starts_at(mread, roff, i, m1, k) && window_owner(mh + i, k, T.own_world) == T.own_rank; }      // a wrong list is caught by the count check
+    wave_count_add(ok, T.own_inserted);
+    if (!ok) return;
+    const u32 slot = mread[i];
+    const u64 win = i - roff[slot];
+    if (win > WIN_MASK) { *cap_err = 1; return; }
+    const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
+    const u64* w = mh + i;
+    const bool rev = window_reversed(w, k);
+    const u64 h = key_hash_window(w, k, rev);
+    bool claimed;
+    const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+    if (claimed || s == ~0ull) return;
+    atomicAdd(&T.tab[s].count, 1u);
+    push_ordinal(T, s, ord);
+}
+void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32* blk_cnt, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, blk_cnt);
+}
+void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* blk_off, const OwnerBases& bases, u32* list, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, blk_off, bases, list);
+}
+void launch_insert_listed(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, u64 n, u32 slot0, u64 first_ordinal,
+                          u32* cap_err, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, first_ordinal, cap_err);
+}
+
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch
 // the insert speculatively and needs one round trip per batch instead of two.  Same rule as slots_for() in api.inc.
 __global__ void reserve_check_kernel(const u64* __restrict__ n_distinct, const u64* __restrict__ batch_windows, u64 cap, u32* __restrict__ too_small) {

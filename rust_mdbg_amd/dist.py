@@ -264,11 +264,22 @@ class GpuEngine:
     def owner_counts(self, world):
         return self.m.owner_counts(world)
 
-    def commit_import(self, token, rel_off, first_ordinal, owned=None):
+    def owner_lists(self, world):
+        """-> (windows of the batch sketched last per owning rank, their lists bucketed by owner as one int32 view)"""
+        counts, p = self.m.owner_lists(world)
+        return counts, self._view(p, (sum(counts),), i32=True)
+
+    def commit_import(self, token, rel_off, first_ordinal, owned=None, window_list=None):
         rel_off = rel_off.contiguous()
         self._keep = getattr(self, "_keep", [])
         self._keep.append(rel_off)             # the call is stream-ordered: keep the offsets alive until insert_owned()
-        self.m.sketch_commit(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal, owned)
+        if window_list is not None:            # the sender listed this rank's windows (copied by the library)
+            window_list = window_list.contiguous()
+            self._keep.append(window_list)
+            self.m.sketch_commit_listed(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal,
+                                        window_list.data_ptr() if window_list.shape[0] else 0, int(window_list.shape[0]))
+        else:
+            self.m.sketch_commit(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal, owned)
 
     def insert_owned(self):
         self.m.insert_resident()
@@ -552,8 +563,15 @@ class ReplicatedMdbg:
             h, p, off, first, n = (t.empty(0, dtype=t.int64, device=dev), t.empty(0, dtype=t.int32, device=dev),
                                    t.zeros(1, dtype=t.int64, device=dev), 0, 0)
         # every rank counts the windows of its own batch per owner once and ships the counts with the sizes, so that no
-        # rank has to re-count a foreign sketch to size its table
-        counts = e.owner_counts(c.world) if (have_batch and c.world > 1 and hasattr(e, "owner_counts")) else None
+        # rank has to re-count a foreign sketch to size its table; engines that can, also list them per owner (4 bytes per
+        # window travel with the sketch), so that no rank has to scan a foreign sketch for its windows either
+        use_lists = hasattr(e, "owner_lists") and 1 < c.world <= 64
+        counts, lists = None, None
+        if have_batch and c.world > 1:
+            if use_lists:
+                counts, lists = e.owner_lists(c.world)
+            elif hasattr(e, "owner_counts"):
+                counts = e.owner_counts(c.world)
         meta = c.allgather_i64([h.shape[0], n, first, 0 if counts is None and n else 1] + (counts if counts is not None else [0] * c.world))
         peers = [r for r in range(c.world) if r != c.rank]
         if not peers:
@@ -563,21 +581,34 @@ class ReplicatedMdbg:
             self._drain(pend)
             e.store_reserve(int(sum(x[0] for x in meta) * n_chunks * 1.2) + (1 << 20), int(sum(x[1] for x in meta) * n_chunks * 1.2) + 4096 * n_chunks * c.world)
             self.sized = True
-            if have_batch:
-                h, p, off, first, n = e.last_sketch()      # the store may have moved
         bufs = self._with_room(pend, lambda: e.reserve_import([int(meta[r][0]) for r in peers]))
         if have_batch:
             h, p, off, first, n = e.last_sketch()          # views into the resident store: taken AFTER the reservation, which may move it
         offs = [t.empty(int(meta[r][1]) + 1, dtype=t.int64, device=off.device) for r in peers]
-        handle = c.exchange([(r, [h, p, off]) for r in peers], [(r, [bufs[i][0], bufs[i][1], offs[i]]) for i, r in enumerate(peers)])
-        return handle, [(bufs[i][2], offs[i], int(meta[r][2]), int(meta[r][4 + c.rank]) if meta[r][3] else None) for i, r in enumerate(peers)]
+        sends = [(r, [h, p, off]) for r in peers]
+        recvs = [(r, [bufs[i][0], bufs[i][1], offs[i]]) for i, r in enumerate(peers)]
+        wl = [None] * len(peers)
+        if use_lists:
+            base = [0]
+            for x in (counts if counts is not None else [0] * c.world):
+                base.append(base[-1] + x)
+            empty = t.empty(0, dtype=t.int32, device=off.device)
+            for i, r in enumerate(peers):
+                sends[i][1].append(lists[base[r]:base[r + 1]] if lists is not None else empty)
+                wl[i] = t.empty(int(meta[r][4 + c.rank]) if meta[r][3] else 0, dtype=t.int32, device=off.device)
+                recvs[i][1].append(wl[i])
+        handle = c.exchange(sends, recvs)
+        return handle, [(bufs[i][2], offs[i], int(meta[r][2]), int(meta[r][4 + c.rank]) if meta[r][3] else None, wl[i] if (use_lists and meta[r][3]) else None)
+                        for i, r in enumerate(peers)]
 
     def _drain(self, pend):
         for item in pend:
             if item is not None and item[0] is not None:
                 item[0].wait()
-                for token, off, first, owned in item[1]:
-                    if owned is None:
+                for token, off, first, owned, wlist in item[1]:
+                    if wlist is not None:
+                        self.e.commit_import(token, off, first, owned, wlist)
+                    elif owned is None:
                         self.e.commit_import(token, off, first)
                     else:
                         self.e.commit_import(token, off, first, owned)

@@ -1,7 +1,7 @@
 """W ranks as threads on ONE GPU (ThreadComm: the exchange is device copies): total GPU work of a W-rank weak-scaling step.
 Per-rank compute cost at world W ~= step time / W (the ranks share the GPU); the xGMI transfer is NOT part of it."""
 import sys, time, json, threading
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rust_mdbg_amd as R
 from rust_mdbg_amd import dist as D
