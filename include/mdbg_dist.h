@@ -1,0 +1,77 @@
+/* mdbg_dist.h — multi-GPU layer of libmdbg_hip.so behind a plain C ABI: one process (or thread) per GPU, reads sharded by record,
+ * the k-min-mer table partitioned by key, exchanges done by the library itself over RCCL.
+ *
+ * What it replaces: rust-mdbg has no multi-process path (one process, --threads workers, one DashMap: src/main.rs:834); the
+ * partitioning is the north star's: every rank sketches its own reads (mdbg_hip.h), the ranks exchange what the owners of the
+ * k-min-mers need, every rank counts the keys it owns, and DbgEntry.index (NODE_INDEX, src/main.rs:598,661) is made global by
+ * summing the ranks' first-sighting bitmaps.  Mode implemented here: the SKETCH exchange (profiles/r02_notes.md: 3x faster per rank
+ * than routing expanded k-min-mer records): per round every rank sends each peer its sketch (12 bytes per minimizer) together with
+ * the list of the windows that peer owns (4 bytes per window, mdbg_owner_lists) in ONE grouped set of ncclSend / ncclRecv pairs —
+ * xGMI is point to point, every pair of GPUs uses its own link — and the receives land directly in reserved regions of the
+ * resident sketch store (mdbg_sketch_reserve: no staging copy).  Results are identical to a single context fed all reads
+ * (tests/test_gpu_dist_c.py, examples/mdbg_dist_threads.c).
+ *
+ * Every call below is COLLECTIVE: all ranks call it the same number of times, in the same order (a rank that has run out of reads
+ * passes n_reads = 0).  Error codes and conventions are those of mdbg_hip.h.
+ */
+#ifndef MDBG_DIST_H
+#define MDBG_DIST_H
+
+#include <stdint.h>
+
+#include "mdbg_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one transfer of a grouped exchange: `bytes` bytes of DEVICE memory to / from rank `peer` */
+typedef struct mdbg_xfer { uint32_t peer; void* d_ptr; uint64_t bytes; } mdbg_xfer;
+
+/* Communicator.  mdbg_comm_rccl fills it with direct RCCL calls; a host with another transport (or a test that runs several ranks
+ * as threads of one process on one GPU) supplies its own three functions.  All functions return 0 or a negative MDBG_E_* code and
+ * block the calling host thread until the data has landed. */
+typedef struct mdbg_comm {
+    void* self;
+    uint32_t rank, world;
+    /* every rank contributes n values (HOST memory); recv (HOST, world * n values) receives them ordered by rank */
+    int (*allgather_u64)(void* self, const uint64_t* send, uint32_t n, uint64_t* recv);
+    /* all transfers of one round at once; transfers between a pair of ranks are matched in the order they are listed; zero-byte
+     * transfers are never listed */
+    int (*exchange)(void* self, const mdbg_xfer* sends, uint32_t n_sends, const mdbg_xfer* recvs, uint32_t n_recvs);
+    /* in-place element-wise sum over the ranks of n u64 values in DEVICE memory */
+    int (*allreduce_sum_u64)(void* self, uint64_t* d_buf, uint64_t n);
+} mdbg_comm;
+
+/* RCCL transport: nccl_comm is an initialised ncclComm_t of `world` ranks whose rank `rank` is this process' GPU (rccl.h:220
+ * ncclCommInitRank).  The library resolves ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd / ncclAllGather / ncclAllReduce from the
+ * RCCL already loaded into the process (or librccl.so.1) at run time, so libmdbg_hip.so itself does not depend on RCCL.
+ * The communicator stays the caller's (destroy it after mdbg_dist_destroy). */
+int mdbg_comm_rccl(void* nccl_comm, uint32_t rank, uint32_t world, mdbg_comm* out);
+
+typedef struct mdbg_dist mdbg_dist;
+
+/* p as for mdbg_create (p->device = this rank's GPU).  The comm table is copied. */
+mdbg_dist* mdbg_dist_create(const mdbg_params* p, const mdbg_comm* comm, int* err);
+void mdbg_dist_destroy(mdbg_dist* d);
+/* the rank's local context: for mdbg_get_stats, mdbg_sync, mdbg_last_error, mdbg_synth_reads_device ... (do not ingest through it) */
+mdbg_ctx* mdbg_dist_ctx(mdbg_dist* d);
+
+/* One round: sketch this rank's batch (DEVICE buffers, as mdbg_ingest_batch_device / mdbg_ingest_batch_packed_device), exchange
+ * sketches and window lists with every peer, insert the windows this rank owns.  first_read_ordinal is GLOBAL (position of the
+ * batch's first record in the whole input), ordinal ranges of different ranks and rounds must not overlap. */
+int mdbg_dist_ingest_batch_device(mdbg_dist* d, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
+                                  uint64_t first_read_ordinal);
+int mdbg_dist_ingest_batch_packed_device(mdbg_dist* d, const mdbg_packed_batch* batch, uint64_t n_bases, uint64_t first_read_ordinal);
+
+/* This rank's partition of the node table (DEVICE arrays as mdbg_finalize_device, in table order): d_row[i] = position of node i in
+ * the global table (= rank in DbgEntry.index order), so concatenating the partitions of all ranks and ordering by d_row gives the
+ * single-GPU table; out->index holds the GLOBAL DbgEntry.index; out->n_distinct and *n_nodes_global are totals over all ranks. */
+int mdbg_dist_finalize(mdbg_dist* d, mdbg_nodes* out, const uint64_t** d_row, uint64_t* n_nodes_global);
+/* new_k = 0: drop everything; else re-window the resident GLOBAL sketch with new_k (no exchange needed: every rank holds it). */
+int mdbg_dist_reset(mdbg_dist* d, uint32_t new_k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDBG_DIST_H */

@@ -4,3 +4,4 @@
 #include "synth.hip"
 #include "route.hip"
 #include "api.inc"
+#include "dist_api.inc"

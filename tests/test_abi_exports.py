@@ -68,3 +68,22 @@ def test_headers_are_plain_c_and_the_example_links(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "examples", "mdbg_cli.c"), "-L" + lib, "-lmdbg_hip", "-lmdbg_emit", "-Wl,-rpath," + lib, "-o", exe], check=True)
     assert os.path.exists(exe)
+
+
+def test_dist_header_symbols_and_c_example_link(tmp_path):
+    """include/mdbg_dist.h: every declared entry point is exported, and the plain-C multi-rank example compiles as C99 and links
+    (running it needs a GPU: tests/test_gpu_dist_c.py)"""
+    import subprocess
+    from rust_mdbg_amd import api
+    h = open(os.path.join(ROOT, "include", "mdbg_dist.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mdbg_(?:dist|comm)_[a-z_0-9]+)\s*\(", h)))
+    assert syms == ["mdbg_comm_rccl", "mdbg_dist_create", "mdbg_dist_ctx", "mdbg_dist_destroy", "mdbg_dist_finalize", "mdbg_dist_ingest_batch_device",
+                    "mdbg_dist_ingest_batch_packed_device", "mdbg_dist_reset"]
+    L = api.load_library()
+    for s in syms:
+        assert hasattr(L, s), s
+    lib = os.path.join(ROOT, "rust_mdbg_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "mdbg_dist_threads.c"), "-L" + lib, "-lmdbg_hip", "-lpthread", "-Wl,-rpath," + lib,
+                    "-o", str(tmp_path / "mdbg_dist_threads")], check=True)

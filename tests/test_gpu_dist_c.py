@@ -1,0 +1,85 @@
+"""The multi-GPU layer behind the C ABI (include/mdbg_dist.h): a plain C program drives several ranks (threads sharing the GPU, its own
+communicator), and the RCCL transport is exercised with a real one-rank ncclComm_t."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+LIB = os.path.join(ROOT, "rust_mdbg_amd")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("distc") / "mdbg_dist_threads")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "mdbg_dist_threads.c"),
+                    "-L" + LIB, "-lmdbg_hip", "-lpthread", "-Wl,-rpath," + LIB, "-o", out], check=True)
+    return out
+
+
+@pytest.mark.parametrize("world,reads,rounds,packed", [(1, 300, 1, 0), (2, 300, 2, 0), (3, 300, 3, 1), (4, 200, 1, 0), (8, 160, 2, 1)])
+def test_c_program_drives_ranks_through_mdbg_dist(exe, world, reads, rounds, packed):
+    r = subprocess.run([exe, str(world), str(reads), str(rounds), str(packed)], capture_output=True, text=True, timeout=90)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "EQUAL to the single-context table" in r.stdout
+
+
+class Comm(C.Structure):
+    _fields_ = [("self", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("allgather_u64", C.c_void_p), ("exchange", C.c_void_p),
+                ("allreduce_sum_u64", C.c_void_p)]
+
+
+def test_rccl_transport_with_a_one_rank_communicator():
+    """mdbg_comm_rccl on a real ncclComm_t (1 rank: all-gather, an empty send/recv group and the all-reduce run through RCCL); the table
+    equals the plain single-GPU one"""
+    import torch  # noqa: F401  (brings torch's RCCL into the process: the library resolves the nccl* symbols from it)
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import api
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+    class UniqueId(C.Structure):            # ncclUniqueId is passed BY VALUE (rccl.h:220)
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    L = api.load_library()
+    vt = Comm()
+    L.mdbg_comm_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Comm)]
+    assert L.mdbg_comm_rccl(comm, 0, 1, C.byref(vt)) == 0
+    k, l, d, a, n_reads = 15, 12, 0.004, 2, 3000
+    P = api.Params(k=k, l=l, density=d, min_abundance=a, reads_already_hpc=0, device=-1, flags=0, table_capacity_hint=0)
+    err = C.c_int()
+    L.mdbg_dist_create.restype = C.c_void_p
+    L.mdbg_dist_create.argtypes = [C.POINTER(api.Params), C.POINTER(Comm), C.POINTER(C.c_int)]
+    dd = L.mdbg_dist_create(C.byref(P), C.byref(vt), C.byref(err))
+    assert dd and err.value == 0
+    L.mdbg_dist_ingest_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.mdbg_dist_finalize.argtypes = [C.c_void_p, C.POINTER(api.Nodes), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.mdbg_dist_destroy.argtypes = [C.c_void_p]
+    with R.Mdbg(k, l, d, a) as m:
+        db, do, nb = m.synth_reads_device(seed=3, genome_len=4_000_000, n_reads=n_reads)
+        m.ingest_device(db, do, n_reads, nb, 0)
+        ref = m.finalize()
+        half = n_reads // 2
+        offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
+        cut = int(offs[half]) // 16 * 16
+        o2 = torch.from_numpy((offs[half:] - cut).astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        assert L.mdbg_dist_ingest_batch_device(dd, db, do, half, int(offs[half]), 0) == 0           # two rounds
+        assert L.mdbg_dist_ingest_batch_device(dd, db + cut, o2.data_ptr(), n_reads - half, nb - cut, half) == 0
+        nd, row, ng = api.Nodes(), C.c_void_p(), C.c_uint64()
+        assert L.mdbg_dist_finalize(dd, C.byref(nd), C.byref(row), C.byref(ng)) == 0
+        n = int(nd.n)
+        assert n == ng.value == ref["n_nodes"] > 1000 and int(nd.n_distinct) == ref["n_nodes_before"]
+        keys = m.to_host(C.cast(nd.keys, C.c_void_p).value, n * k * 8, np.uint64).reshape(n, k)
+        rows = m.to_host(row.value, n * 8, np.uint64)
+        index = m.to_host(C.cast(nd.index, C.c_void_p).value, n * 4, np.uint32)
+        assert np.array_equal(keys[np.argsort(rows)], ref["keys"]) and np.array_equal(index[np.argsort(rows)], ref["index"])
+    L.mdbg_dist_destroy(dd)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
