@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
                     help="multi-GPU mode: exchange of sketches + key-partitioned table (default inside a node: 3x faster per rank, profiles/r02_notes.md), or all-to-all of k-min-mer records by key range (the north star's wording)")
+    ap.add_argument("--dist-impl", choices=["py", "c"], default="py",
+                    help="multi-GPU driver: rust_mdbg_amd/dist.py over torch.distributed (chunked, exchange overlapped with the next chunk's sketch), or the "
+                         "library's own C layer (include/mdbg_dist.h: direct RCCL send/recv groups, one round per step)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="multi-GPU: chunks per step; the exchange of chunk c overlaps the sketch of chunk c+1 (0 = 4 in replicate mode, 1 in route mode)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
@@ -122,6 +125,16 @@ def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
                       % (r1, float(offs[r1]) / 1e9, cores, dt, cores)}
 
 
+def api_stats_of(cdist):
+    """mdbg_get_stats of the context inside an mdbg_dist"""
+    import ctypes as C
+    from rust_mdbg_amd import api
+    s = api.Stats()
+    L = api.load_library()
+    L.mdbg_get_stats(C.c_void_p(L.mdbg_dist_ctx(cdist.h)), C.byref(s))
+    return {f: getattr(s, f) for f, _ in api.Stats._fields_ if f != "reserved"}
+
+
 def main():
     args = parse()
     # stdout carries exactly one JSON line: native libraries (RCCL prints a version banner) write to file descriptor 1
@@ -160,7 +173,12 @@ def main():
         d_words = words.data_ptr()
     d_in = d_words if packed else d_bases
 
-    if routed:
+    cdist = None
+    replicate = args.dist_mode == "replicate"
+    if routed and args.dist_impl == "c":
+        from rust_mdbg_amd import dist_c
+        cdist = dist_c.DistMdbg(args.k, args.l, args.density, args.minabund, rank, world, dist, device=local_rank)
+    if routed and cdist is None:
         from rust_mdbg_amd import dist as D
         dev = torch.device("cuda", local_rank)
         replicate = args.dist_mode == "replicate"
@@ -177,6 +195,15 @@ def main():
             offs_t = engine._view(d_off, (reads_per_gpu + 1,))
 
     def step():
+        if cdist is not None:
+            cdist.reset(0)
+            if packed:
+                cdist.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
+            else:
+                cdist.ingest_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
+            nd, _, ng = cdist.finalize()
+            cdist.last_local = int(nd.n)
+            return ng
         if routed:
             runner.reset() if replicate else engine.reset()
         else:
@@ -202,7 +229,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if routed and not replicate:
+    if routed and cdist is None and not replicate:
         runner.times = {}
     t0 = time.perf_counter()
     n_nodes = 0
@@ -221,16 +248,21 @@ def main():
         total_bases = n_bases
     consistent = None
     if routed:               # outside the timed region: the ranks' partitions must add up to the global node count
-        loc = torch.tensor([runner.last_local], device="cuda", dtype=torch.int64)
+        loc = torch.tensor([(cdist if cdist is not None else runner).last_local], device="cuda", dtype=torch.int64)
         dist.all_reduce(loc)
         consistent = bool(int(loc.item()) == int(n_nodes))
     st = m.stats()          # stats of the last step only (reset clears the timers)
-    if routed and engine.tm is not m:
+    if cdist is not None:
+        m_stats = api_stats_of(cdist)
+        for f in ("n_minimizers", "n_windows", "n_distinct", "table_capacity", "n_slow_tiles", "n_tiles", "ms_sketch", "ms_sketch_tile", "ms_insert", "ms_finalize",
+                  "n_sketch_tile_launches", "n_sketch_tile_bases", "n_bases"):
+            st[f] = m_stats[f]
+    if routed and cdist is None and engine.tm is not m:
         st2 = engine.tm.stats()
         st["n_distinct"], st["table_capacity"] = st2["n_distinct"], st2["table_capacity"]
         st["ms_insert"] += st2["ms_insert"]
         st["ms_finalize"] += st2["ms_finalize"]
-    if routed and not replicate and args.profile_dist and rank == 0:
+    if routed and cdist is None and not replicate and args.profile_dist and rank == 0:
         n = args.steps
         print("[dist profile, ms per step] " + ", ".join("%s=%.2f" % (k, v / n) for k, v in runner.times.items()), file=sys.stderr)
     if rank == 0:
@@ -286,7 +318,7 @@ def main():
                                       "synthetic D. melanogaster %.0f Mb @%.0fx per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1%% errors" % (args.genome_mb, args.coverage),
                           "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
                           "bases_per_gpu": n_bases, "input_format": args.input,
-                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records")) if routed else "single GPU"},
+                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, "sketches + window lists exchanged by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h)" if cdist is not None else (("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records"))) if routed else "single GPU"},
                "roofline": roof, "roofline_ascii": roof_ascii, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
@@ -295,7 +327,9 @@ def main():
                "edges_after_timed_region": edges}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
-    if routed and engine.tm is not m:
+    if cdist is not None:
+        cdist.close()
+    if routed and cdist is None and engine.tm is not m:
         engine.tm.close()
     if dist is not None:
         dist.destroy_process_group()
