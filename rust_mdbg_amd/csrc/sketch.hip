@@ -22,6 +22,7 @@
 #include "bs_core.h"
 
 enum { FMT_ASCII = 0, FMT_PLANES = 1 };
+struct TileRec;
 
 struct SketchArgs {
     const u8* bases;             // FMT_ASCII: one byte per base
@@ -30,6 +31,7 @@ struct SketchArgs {
     u64 n_bases;                 // positions >= n_bases do not exist
     const u64* offsets; u32 n_reads;
     const u32* bread;            // read containing the first staged base of tile t, [n_tiles + 2]
+    const TileRec* recs;         // [n_tiles] (tile_rec_kernel)
     u32 n_tiles;
     u32 tile0;                   // workgroup b runs tile tile0 + b
     Rec* slab; u32 slab_cap;     // records of workgroup b: slab[b * slab_cap ..), in position order
@@ -60,6 +62,25 @@ __global__ void bread_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bas
     if (p < 0) p = 0;
     if ((u64)p >= n_bases) p = n_bases ? (int64_t)n_bases - 1 : 0;
     bread[t] = find_read(off, 0, n_reads - 1, (u64)p);
+}
+
+// What a tile needs to know about the reads it touches, prepared once per batch so that the tile kernel reads ONE record instead of
+// chasing bread[] -> offsets[]: the reads [rl, rh] that overlap the staged range and, when there are at most TREC_N of them, their
+// starts relative to the first staged position.
+constexpr int TREC_N = 7;
+struct __attribute__((aligned(16))) TileRec { u32 rl, rh; int64_t start0; int32_t rel[TREC_N - 1]; };     // start0: read rl (may lie far in front); rel[i]: read rl+1+i
+__global__ void tile_rec_kernel(const u64* __restrict__ off, const u32* __restrict__ bread, u32 n_tiles, TileRec* __restrict__ recs) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t raw0 = (int64_t)t * TILE_STRIDE - HALO_BASES;
+    TileRec r;
+    r.rl = bread[t]; r.rh = bread[t + 2];
+    r.start0 = (int64_t)off[r.rl] - raw0;
+    for (int i = 0; i < TREC_N - 1; ++i) {
+        int64_t v = r.rl + 1 + i <= r.rh ? (int64_t)off[r.rl + 1 + i] - raw0 : 0x7FFFFFFF;
+        r.rel[i] = (int32_t)(v > 0x7FFFFFFF ? 0x7FFFFFFF : v);
+    }
+    recs[t] = r;
 }
 
 // ---- input accessors of the generic walker -------------------------------------------------------------
@@ -223,37 +244,41 @@ __device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab
 // ---- fast tile kernel ---------------------------------------------------------------------------------------------
 struct CandOut { u64 hash; u32 pos, read; };
 
+// One tile per workgroup.  (A persistent variant — workgroups looping over tiles with the next tile's words prefetched — was measured
+// and dropped: the loop makes the compiler keep ~100 more values live across the phases, 3-4 instead of 6 waves per SIMD, 3.4-4.9 ms
+// instead of 2.2 ms; capped to 80 registers it spills and is no better.  profiles/r02_notes.md.)
 template <int L>
 __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     __shared__ TileLds S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 gt = a.tile0 + blockIdx.x;
-    Rec* const slab = a.slab + (size_t)blockIdx.x * a.slab_cap;
+    const int64_t nb = (int64_t)a.n_bases;
+    const int64_t n_pairs = (nb + 31) >> 5;
+    const bool hpc = a.hpc != 0;
+    const int64_t first_base = (int64_t)a.offsets[0];      // positions in front of it belong to no read
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    static_assert(WPT % 2 == 0 && (HALO_BASES / 32) % 2 == 0 && ((TILE_RAW_WORDS - HALO_BASES / 32) % 2) == 0, "16-byte aligned word pairs per thread");
+    const u32 wg = blockIdx.x, gt = a.tile0 + wg;
+    Rec* const slab = a.slab + (size_t)wg * a.slab_cap;
 #define MDBG_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(size_t)gt * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
     MDBG_STAMP(0);
     const int64_t raw0 = (int64_t)gt * TILE_STRIDE - HALO_BASES;      // first staged raw position (negative for tile 0)
-    const int64_t nb = (int64_t)a.n_bases;
-    const bool hpc = a.hpc != 0;
     const bool interior = raw0 >= 0 && raw0 + RW * 32 <= nb;
+    const TileRec* const rec = a.recs + gt;
 
     // ---- phase 1: load (issued first: everything below hides under its latency), read starts, planes -------------------
     u32 x0[WPT], x1[WPT], pv0 = 0, pv1 = 0;          // my raw words (MSB first); pv*: bit 0 = the base in front of them
     constexpr int CPT = RW * 2 / TT;                  // FMT_ASCII: 16-base chunks per thread
     uint4 av[CPT]; uint2 pr[WPT];
     const int64_t pi0 = raw0 / 32 + (int64_t)WPT * tid;       // FMT_PLANES: my first word pair (raw0 is a multiple of 32, also when negative)
-    const int64_t n_pairs = (nb + 31) >> 5;
     if (a.fmt == FMT_ASCII) {
         if (interior) {
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4* src = (const u32x4*)(a.bases + raw0);
 #pragma unroll
             for (int g = 0; g < CPT; ++g) { const u32x4 q = __builtin_nontemporal_load(src + tid + TT * g); av[g] = make_uint4(q.x, q.y, q.z, q.w); }
         }
     } else {
         if (interior) {
-            static_assert(WPT % 2 == 0 && (HALO_BASES / 32) % 2 == 0 && ((TILE_RAW_WORDS - HALO_BASES / 32) % 2) == 0, "16-byte aligned word pairs per thread");
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4* src = (const u32x4*)(a.planes + pi0);
+            const u32x4* src = (const u32x4*)(a.planes + pi0);       // two 16-byte streaming loads
 #pragma unroll
             for (int i = 0; i < WPT / 2; ++i) { const u32x4 q = __builtin_nontemporal_load(src + i); pr[2 * i] = make_uint2(q.x, q.y); pr[2 * i + 1] = make_uint2(q.z, q.w); }
         } else {
@@ -262,13 +287,18 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         }
         if (tid && pi0 - 1 >= 0 && pi0 - 1 < n_pairs) { const uint2 q = a.planes[pi0 - 1]; pv0 = q.x >> 31; pv1 = q.y >> 31; }
     }
-    const u32 rl = a.bread[gt], rh_ = a.bread[gt + 2];
-    const int64_t first_base = (int64_t)a.offsets[0];      // positions in front of it belong to no read
+    const u32 rl = rec->rl, rh_ = rec->rh;
     for (int i = tid; i < 2 * (DPAD + RW + 4); i += TT) S.dense[i] = 0;
     if (tid < (2 << (2 * BS_GS))) S.t3[tid] = a.t4[tid];
     if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[11] = 0; S.misc[17] = 0; }
     __syncthreads();
-    for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) {
+    if (rh_ - rl < (u32)TREC_N) {                       // the usual case: the read starts come with the tile's record
+        if ((u32)tid <= rh_ - rl) {
+            const int64_t rel = tid == 0 ? rec->start0 : (int64_t)rec->rel[tid - 1];
+            S.rs_rel[tid] = rel;
+            if (rel >= 0 && rel < RW * 32) atomicOr(&S.dense[rel >> 5], 0x80000000u >> (rel & 31));
+        }
+    } else for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) {
         const int64_t rel = (int64_t)a.offsets[r] - raw0;
         if (r - rl < RS_CAP) S.rs_rel[r - rl] = rel;
         if (rel >= 0 && rel < RW * 32) atomicOr(&S.dense[rel >> 5], 0x80000000u >> (rel & 31));
@@ -818,9 +848,10 @@ void launch_pack_planes(const u8* bases, u64 n_bases, uint2* words, u64* exc_pos
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
-void launch_bread(const u64* offsets, u32 n_reads, u64 n_bases, u32 n_tiles, u32* bread, hipStream_t s) {
+void launch_bread(const u64* offsets, u32 n_reads, u64 n_bases, u32 n_tiles, u32* bread, TileRec* recs, hipStream_t s) {
     const u32 n = n_tiles + 2;
     hipLaunchKernelGGL(bread_kernel, dim3((n + 255) / 256), dim3(256), 0, s, offsets, n_reads, n_bases, n, bread);
+    hipLaunchKernelGGL(tile_rec_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, offsets, bread, n_tiles, recs);
 }
 void launch_tile_flags(const u64* exc_pos, u32 n_exc, u32 n_tiles, u8* flags, hipStream_t s) {
     if (n_exc) hipLaunchKernelGGL(tile_flags_kernel, dim3((n_exc + 255) / 256), dim3(256), 0, s, exc_pos, n_exc, n_tiles, flags);
@@ -832,7 +863,9 @@ void launch_alphabet_rule(const SketchArgs& a, unsigned long long* which, hipStr
     else hipLaunchKernelGGL(alphabet_rule_kernel<PlaneSrc>, g, b, 0, s, PlaneSrc{a.planes, a.exc_pos, a.exc_val, a.n_exc}, a.offsets, a.n_reads, a.l, a.hpc, which);
 }
 
-template <int L> static void launch_bs(const SketchArgs& a, u32 n_wg, hipStream_t s) { hipLaunchKernelGGL(sketch_bs_kernel<L>, dim3(n_wg), dim3(TT), 0, s, a); }
+template <int L> static void launch_bs(const SketchArgs& a, u32 n_wg, hipStream_t s) {
+    hipLaunchKernelGGL(sketch_bs_kernel<L>, dim3(n_wg), dim3(TT), 0, s, a);
+}
 // one launch covers the whole batch (launch boundaries would only re-synchronise the workgroups' phases); n_wg = tiles to run
 void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (!n_wg) return;
