@@ -169,6 +169,7 @@ def main():
     if packed:          # outside the timed region: the batch as the host packer (mdbg_pack_reads) would have delivered it
         words = torch.zeros((n_bases + 31) // 32 + 2, dtype=torch.int64, device="cuda")
         exc = (torch.zeros(64, dtype=torch.int64, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda"))
+        torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
         assert m.pack_device(d_bases, n_bases, words.data_ptr(), exc[0].data_ptr(), exc[1].data_ptr(), 64) == 0      # synthetic reads are pure ACGT
         d_words = words.data_ptr()
     d_in = d_words if packed else d_bases

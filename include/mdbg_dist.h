@@ -6,7 +6,7 @@
  * k-min-mers need, every rank counts the keys it owns, and DbgEntry.index (NODE_INDEX, src/main.rs:598,661) is made global by
  * summing the ranks' first-sighting bitmaps.  Mode implemented here: the SKETCH exchange (profiles/r02_notes.md: 3x faster per rank
  * than routing expanded k-min-mer records): per round every rank sends each peer its sketch (12 bytes per minimizer) together with
- * the list of the windows that peer owns (4 bytes per window, mdbg_owner_lists) in ONE grouped set of ncclSend / ncclRecv pairs —
+ * the list of the windows that peer owns (8 bytes per window, mdbg_owner_lists) in ONE grouped set of ncclSend / ncclRecv pairs —
  * xGMI is point to point, every pair of GPUs uses its own link — and the receives land directly in reserved regions of the
  * resident sketch store (mdbg_sketch_reserve: no staging copy).  Results are identical to a single context fed all reads
  * (tests/test_gpu_dist_c.py, examples/mdbg_dist_threads.c).

@@ -295,11 +295,14 @@ int mdbg_sketch_commit(mdbg_ctx* ctx, uint64_t region, uint64_t n_minimizers, co
  * inserted (MDBG_E_PARAM from mdbg_insert_resident on a mismatch). */
 int mdbg_owner_counts(mdbg_ctx* ctx, uint32_t world, uint64_t* counts);
 /* Owner LISTS: like mdbg_owner_counts, and in addition the windows themselves, bucketed by owning rank: d_lists (DEVICE, library-owned
- * until the next call of this function) holds counts[0] entries for rank 0, then counts[1] for rank 1, ...; an entry is the index of
- * the window's first minimizer relative to the batch.  The sender ships bucket r to rank r with the sketch (4 bytes per window) and
- * the receiver registers it with mdbg_sketch_commit_listed: it then inserts exactly its windows instead of scanning the foreign sketch,
- * so the per-rank work does not grow with the number of ranks.  world <= 64.  The entries are verified at insertion (ownership and
- * count; MDBG_E_PARAM from mdbg_insert_resident on a mismatch).  The list is copied: the caller's buffer may be reused at once. */
+ * until the next call of this function) holds counts[0] entries for rank 0, then counts[1] for rank 1, ...; an ENTRY is a pair of
+ * uint32_t: the index of the window's first minimizer and the index of its read, both relative to the batch (so rank r's bucket starts
+ * at d_lists + 2 * (counts[0] + ... + counts[r-1]) and is 8 * counts[r] bytes).  The sender ships bucket r to rank r with the sketch
+ * (8 bytes per window) and the receiver registers it with mdbg_sketch_commit_listed (n_list = number of entries): it then inserts
+ * exactly its windows — no scan of the foreign sketch, no minimizer -> read map built for it — so the per-rank work does not grow with
+ * the number of ranks.  world <= 64.  Buckets are ordered by spans of 2048 window starts (any order inside a span); every entry is
+ * verified at insertion (range, read, ownership, and the total count: MDBG_E_PARAM from mdbg_insert_resident on a mismatch).  The list
+ * is copied by mdbg_sketch_commit_listed: the caller's buffer may be reused once the context's stream has passed the call (mdbg_sync). */
 int mdbg_owner_lists(mdbg_ctx* ctx, uint32_t world, uint64_t* counts, const uint32_t** d_lists);
 int mdbg_sketch_commit_listed(mdbg_ctx* ctx, uint64_t region, uint64_t n_minimizers, const uint64_t* d_read_offsets, uint64_t n_reads,
                               uint64_t first_read_ordinal, const uint32_t* d_list, uint64_t n_list);

@@ -368,7 +368,8 @@ class Mdbg:
         self._chk(self.L.mdbg_sketch_commit(self.h, region, n_minimizers, d_read_offsets, n_reads, first_read_ordinal, ow))
 
     def owner_lists(self, world):
-        """-> (counts per owning rank, DEVICE pointer to the window lists bucketed by owner) for the batch registered last"""
+        """-> (counts per owning rank, DEVICE pointer to the window lists bucketed by owner; an entry = two uint32: window start, read) for the
+        batch registered last"""
         out = (C.c_uint64 * world)()
         p = C.c_void_p()
         self._chk(self.L.mdbg_owner_lists(self.h, world, out, C.byref(p)))

@@ -255,10 +255,11 @@ __global__ __launch_bounds__(256) void insert_owned_windows_kernel(TableArgs T, 
 
 // ---- owner lists (replicated-sketch mode) -----------------------------------------------------------------------------------------
 // The rank that sketched a batch also lists, per owning rank, the windows that rank owns (u32 index of the window's first minimizer,
-// relative to the batch): 4 bytes per window shipped with the sketch, so that a receiver inserts exactly its windows instead of
-// scanning every foreign sketch for them — the per-rank work no longer grows with the number of ranks.
+// relative to the batch, and the index of its read in the batch: a pair of u32): 8 bytes per window shipped with the sketch, so that a
+// receiver inserts exactly its windows instead of scanning every foreign sketch for them, and needs no minimizer -> read map of the
+// foreign sketch either — the per-rank work no longer grows with the number of ranks.
 // Two passes with per-block counts and a scan in between (deterministic bucket sizes, no same-address atomics on global counters).
-constexpr int OWNL_SPAN = 4096;               // window starts per block (the per-block counts are scanned by one workgroup per owner: keep them few)
+constexpr int OWNL_SPAN = 2048;               // window starts per block: the span of hashes a receiving workgroup stages in LDS (16 KB + k values)
 constexpr u32 OWNL_MAX_WORLD = 64;
 struct OwnerBases { u64 b[OWNL_MAX_WORLD]; }; // start of every owner's bucket in the list
 __device__ inline bool window_starts_at(const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i, u64 i1, u32 k) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __rest
     if (threadIdx.x < world) blk_cnt[(size_t)blockIdx.x * world + threadIdx.x] = hist[threadIdx.x];
 }
 __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                               u32 k, u32 world, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list) {
+                                                               u32 k, u32 world, u32 slot0, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list) {
     __shared__ u32 lcnt[OWNL_MAX_WORLD];
     if (threadIdx.x < world) lcnt[threadIdx.x] = 0;
     __syncthreads();
@@ -290,27 +291,37 @@ __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __rest
 #pragma unroll
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
         const u64 i = b0 + u * 256 + threadIdx.x;
-        if (window_starts_at(mread, roff, i, i1, k)) {
+        if (i >= i1) continue;
+        const u32 slot = mread[i];
+        const u64 rs = roff[slot], re = roff[slot + 1];
+        if (re - rs > k && i + k <= re) {
             const u32 o = window_owner(mh + i, k, world);
             const u32 r = atomicAdd(&lcnt[o], 1u);
-            list[bases.b[o] + blk_off[(size_t)blockIdx.x * world + o] + r] = (u32)(i - i0);
+            uint2* const e = (uint2*)list + (bases.b[o] + blk_off[(size_t)blockIdx.x * world + o] + r);
+            *e = make_uint2((u32)(i - i0), slot - slot0);        // window start and its read, both relative to the batch
         }
     }
 }
 // inserts exactly the listed windows of the batch whose minimizers start at m0 (keys are read from the resident store)
-__global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff,
-                                                                    u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u64 first_ordinal,
+__global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
+                                                                    u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
                                                                     u32* __restrict__ cap_err) {
     if (cap_err[1]) return;
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 k = T.ks.k;
     bool ok = j < n;
-    u64 i = 0;
-    if (ok) { i = m0 + list[j]; ok = window_starts_at(mread, roff, i, m1, k) && window_owner(mh + i, k, T.own_world) == T.own_rank; }      // a wrong list is caught by the count check
+    u64 i = 0, rs = 0; u32 slot = 0;
+    if (ok) {
+        const uint2 e = ((const uint2*)list)[j];
+        i = m0 + e.x; slot = slot0 + e.y; ok = e.y < n_reads && i + k <= m1;
+    }
+    if (ok) {                                      // a wrong list is caught by the count check
+        rs = roff[slot]; const u64 re = roff[slot + 1];
+        ok = i >= rs && re - rs > k && i + k <= re && window_owner(mh + i, k, T.own_world) == T.own_rank;
+    }
     wave_count_add(ok, T.own_inserted);
     if (!ok) return;
-    const u32 slot = mread[i];
-    const u64 win = i - roff[slot];
+    const u64 win = i - rs;
     if (win > WIN_MASK) { *cap_err = 1; return; }
     const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
     const u64* w = mh + i;
@@ -318,19 +329,87 @@ __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T,
     const u64 h = key_hash_window(w, k, rev);
     bool claimed;
     const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+    if (claimed) mread[i] = slot;
     if (claimed || s == ~0ull) return;
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
 }
+// The lists are written span by span (owner_list_write_kernel: the entries of one OWNL_SPAN of window starts are contiguous, in any order
+// inside it), so the receiver can work span-wise too: seg[q] = first list entry of span q or later (seg[] is pre-filled with n).
+__global__ __launch_bounds__(256) void list_segments_kernel(const u32* __restrict__ list, u64 n, u32 n_spans, u32* __restrict__ seg) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 last = n_spans - 1;
+    u32 b = list[2 * j] / OWNL_SPAN; if (b > last) b = last;                 // entries out of range are rejected by the insert kernel
+    int pb = -1;
+    if (j) { u32 q = list[2 * j - 2] / OWNL_SPAN; if (q > last) q = last; pb = (int)q; }
+    for (int q = pb + 1; q <= (int)b; ++q) seg[q] = (u32)j;                 // all spans' loops together: n_spans stores
+}
+// inserts exactly the listed windows, one workgroup per span of window starts: the span's hashes are staged in LDS once (coalesced) and
+// orientation, key hash and the own side of the key comparison read them from there — a rank's share of a foreign sketch is one window in
+// `world`, read straight from HBM every one of them would fetch its k values over again
+__global__ __launch_bounds__(256) void insert_listed_span_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
+                                                                 u64 m0, u64 m1, const u32* __restrict__ list, const u32* __restrict__ seg, u64 n, u32 slot0,
+                                                                 u32 n_reads, u64 first_ordinal, u32* __restrict__ cap_err) {
+    extern __shared__ u64 sh_keys[];           // [OWNL_SPAN + k - 1]
+    if (cap_err[1]) return;
+    const u32 q = blockIdx.x, k = T.ks.k;
+    const u32 s0 = seg[q], s1 = seg[q + 1];
+    if (s0 >= s1 || s1 > n) return;
+    const u64 b0 = m0 + (u64)q * OWNL_SPAN;
+    const u64 lim = b0 + OWNL_SPAN + k - 1 < m1 ? b0 + OWNL_SPAN + k - 1 : m1;
+    for (u64 t = b0 + threadIdx.x; t < lim; t += 256) sh_keys[t - b0] = mh[t];
+    __syncthreads();
+    for (u32 base = s0; base < s1; base += 256) {
+        const u32 j = base + threadIdx.x;
+        bool ok = j < s1;
+        u32 li = 0; u64 i = 0;
+        u32 slot = 0; u64 rs = 0;
+        if (ok) {
+            const uint2 e = ((const uint2*)list)[j];
+            li = e.x; ok = li / OWNL_SPAN == q && e.y < n_reads; li -= q * OWNL_SPAN; i = b0 + li; slot = slot0 + e.y;
+        }
+        if (ok) {                                  // a wrong list is caught by the count check
+            rs = roff[slot]; const u64 re = roff[slot + 1];
+            ok = i >= rs && re - rs > k && i + k <= re && window_owner(sh_keys + li, k, T.own_world) == T.own_rank;
+        }
+        wave_count_add(ok, T.own_inserted);
+        if (!ok) continue;
+        const u64 win = i - rs;
+        if (win > WIN_MASK) { *cap_err = 1; continue; }
+        const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
+        const u64* w = sh_keys + li;
+        const bool rev = window_reversed(w, k);
+        const u64 h = key_hash_window(w, k, rev);
+        bool claimed;
+        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+        if (claimed) mread[i] = slot;              // rep_ordinal() finds the representative's read through it; the rest of a listed batch's map is filled on demand
+        if (claimed || s == ~0ull) continue;
+        atomicAdd(&T.tab[s].count, 1u);
+        push_ordinal(T, s, ord);
+    }
+}
+u32 owner_list_spans(u64 n_minimizers) { return (u32)((n_minimizers + OWNL_SPAN - 1) / OWNL_SPAN); }
+// list: n pairs of u32; seg: owner_list_spans(m1 - m0) + 1 entries
+void launch_list_segments(const u32* list, u64 n, u32 n_spans, u32* seg, hipStream_t s) {
+    (void)hipMemsetD32Async((hipDeviceptr_t)seg, (int)(u32)n, (size_t)n_spans + 1, s);
+    if (n && n_spans) hipLaunchKernelGGL(list_segments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, list, n, n_spans, seg);
+}
 void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32* blk_cnt, hipStream_t s) {
     if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, blk_cnt);
 }
-void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* blk_off, const OwnerBases& bases, u32* list, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, blk_off, bases, list);
+void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, slot0, blk_off, bases, list);
 }
-void launch_insert_listed(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, u64 n, u32 slot0, u64 first_ordinal,
-                          u32* cap_err, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, first_ordinal, cap_err);
+// list: n pairs (window start, read), seg: launch_list_segments of it
+void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, const u32* seg, u64 n, u32 slot0,
+                          u32 n_reads, u64 first_ordinal, u32* cap_err, hipStream_t s) {
+    if (!n) return;
+    const size_t lds = ((size_t)OWNL_SPAN + T.ks.k) * sizeof(u64);
+    if (seg && lds <= 64 * 1024)
+        hipLaunchKernelGGL(insert_listed_span_kernel, dim3(owner_list_spans(m1 - m0)), dim3(256), lds, s, T, mh, mread, roff, m0, m1, list, seg, n, slot0, n_reads, first_ordinal, cap_err);
+    else       // very long k: the span does not fit the default LDS window, every window reads its values from HBM
+        hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err);
 }
 
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch

@@ -267,7 +267,7 @@ class GpuEngine:
     def owner_lists(self, world):
         """-> (windows of the batch sketched last per owning rank, their lists bucketed by owner as one int32 view)"""
         counts, p = self.m.owner_lists(world)
-        return counts, self._view(p, (sum(counts),), i32=True)
+        return counts, self._view(p, (2 * sum(counts),), i32=True)          # pairs (window, read) of int32
 
     def commit_import(self, token, rel_off, first_ordinal, owned=None, window_list=None):
         rel_off = rel_off.contiguous()
@@ -277,7 +277,7 @@ class GpuEngine:
             window_list = window_list.contiguous()
             self._keep.append(window_list)
             self.m.sketch_commit_listed(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal,
-                                        window_list.data_ptr() if window_list.shape[0] else 0, int(window_list.shape[0]))
+                                        window_list.data_ptr() if window_list.shape[0] else 0, int(window_list.shape[0]) // 2)
         else:
             self.m.sketch_commit(token[0], token[1], rel_off.data_ptr(), rel_off.shape[0] - 1, first_ordinal, owned)
 
@@ -594,8 +594,8 @@ class ReplicatedMdbg:
                 base.append(base[-1] + x)
             empty = t.empty(0, dtype=t.int32, device=off.device)
             for i, r in enumerate(peers):
-                sends[i][1].append(lists[base[r]:base[r + 1]] if lists is not None else empty)
-                wl[i] = t.empty(int(meta[r][4 + c.rank]) if meta[r][3] else 0, dtype=t.int32, device=off.device)
+                sends[i][1].append(lists[2 * base[r]:2 * base[r + 1]] if lists is not None else empty)
+                wl[i] = t.empty(2 * int(meta[r][4 + c.rank]) if meta[r][3] else 0, dtype=t.int32, device=off.device)
                 recvs[i][1].append(wl[i])
         handle = c.exchange(sends, recvs)
         return handle, [(bufs[i][2], offs[i], int(meta[r][2]), int(meta[r][4 + c.rank]) if meta[r][3] else None, wl[i] if (use_lists and meta[r][3]) else None)

@@ -64,6 +64,7 @@ def body(r):
             if packed:
                 words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
                 ep = torch.zeros(16, dtype=torch.int64, device="cuda"); ev = torch.zeros(16, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()          # the fills run on torch's stream, the packer on the context's
                 assert m.pack_device(db, nb, words.data_ptr(), ep.data_ptr(), ev.data_ptr(), 16) == 0
                 eng.packed = True; src = words.data_ptr()
             else: src = db

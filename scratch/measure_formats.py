@@ -11,6 +11,7 @@ m = R.Mdbg(k, l, d, a)
 db, do, nb = m.synth_reads_device(seed=1, genome_len=140_000_000, n_reads=n_reads)
 words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
 ep = torch.zeros(16, dtype=torch.int64, device="cuda"); ev = torch.zeros(16, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
 assert m.pack_device(db, nb, words.data_ptr(), ep.data_ptr(), ev.data_ptr(), 16) == 0
 out = {}
 for name in ("ascii", "packed", "ascii", "packed"):

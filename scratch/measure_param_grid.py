@@ -10,6 +10,7 @@ for l in (12, 20, 31):
         m = R.Mdbg(10, l, d, 2)
         db, do, nb = m.synth_reads_device(seed=1, genome_len=140_000_000, n_reads=n_reads)
         words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
         assert m.pack_device(db, nb, words.data_ptr()) == 0
         r = dict(l=l, density=d, gbases=nb / 1e9)
         for name in ("packed", "ascii"):

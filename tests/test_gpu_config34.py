@@ -27,6 +27,7 @@ def test_config4_params_oracle_parity_1gbase():
         # the same reads through the packed path
         import torch
         words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
         assert m.pack_device(db, nb, words.data_ptr()) == 0
         m.reset(0)
         m.ingest_packed_device(words.data_ptr(), do, n_reads, nb, 0)
@@ -77,6 +78,7 @@ def test_config4_full_shard_properties_and_multik_sweep():
         db, do, nb = m.synth_reads_device(seed=1, genome_len=SHARD_GENOME, n_reads=SHARD_READS)
         assert 19.0e9 < nb < 20.0e9
         words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
         assert m.pack_device(db, nb, words.data_ptr()) == 0
         offs = _dev(torch, do, SHARD_READS + 1, torch.int64).clone()     # the synthetic buffers belong to this context: keep what outlives it
         m.ingest_packed_device(words.data_ptr(), do, SHARD_READS, nb, 0)

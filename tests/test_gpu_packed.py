@@ -97,6 +97,7 @@ def test_pack_device_equals_host_packer_and_feeds_the_kernel():
         db, do, nb = m.synth_reads_device(seed=3, genome_len=5_000_000, n_reads=n_reads)
         words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
         ep = torch.zeros(16, dtype=torch.int64, device="cuda"); ev = torch.zeros(16, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
         assert m.pack_device(db, nb, words.data_ptr(), ep.data_ptr(), ev.data_ptr(), 16) == 0
         bases = m.to_host(db, nb); offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
         pk = E.pack_reads(bases, offs, threads=4)
