@@ -48,7 +48,8 @@ enum {
     MDBG_E_CAPACITY = -3, /* a fixed limit was exceeded (e.g. more than 2^26 minimizers in one read) */
     MDBG_E_DEVICE = -4,   /* HIP runtime failure; text via mdbg_last_error */
     MDBG_E_NOMEM = -5,    /* device or host allocation failed */
-    MDBG_E_STATE = -6     /* call not valid in the context's current state (e.g. ingest after an error) */
+    MDBG_E_STATE = -6,    /* call not valid in the context's current state (e.g. ingest after an error) */
+    MDBG_E_IO = -7        /* libmdbg_emit: a file could not be opened, or a write / close failed (disk full ...) */
 };
 
 #define MDBG_MAX_L 255u        /* l = 2..32 run on the bit-sliced kernel, longer l-mers on its generic exact walker (reference: unbounded) */

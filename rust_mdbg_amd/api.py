@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-MDBG_OK, MDBG_E_PARAM, MDBG_E_ALPHABET, MDBG_E_CAPACITY, MDBG_E_DEVICE, MDBG_E_NOMEM, MDBG_E_STATE = 0, -1, -2, -3, -4, -5, -6
+MDBG_OK, MDBG_E_PARAM, MDBG_E_ALPHABET, MDBG_E_CAPACITY, MDBG_E_DEVICE, MDBG_E_NOMEM, MDBG_E_STATE, MDBG_E_IO = 0, -1, -2, -3, -4, -5, -6, -7
 FLAG_FORCE_GENERIC = 1   # mdbg_params.flags bit 0: every tile takes the generic exact kernel (testing)
 
 

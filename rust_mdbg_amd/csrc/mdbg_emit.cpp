@@ -147,21 +147,23 @@ int mdbg_emit_edges(mdbg_emit* E, const mdbg_nodes* nd, float presimp, mdbg_edge
 int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nd, const mdbg_edges* ed) {
     if (!path || !nd) return MDBG_E_PARAM;
     FILE* f = fopen(path, "wb");
-    if (!f) return MDBG_E_PARAM;
-    fprintf(f, "H\tVN:Z:1.0\n");                                                                   // main.rs:1011
-    for (u64 i = 0; i < nd->n; ++i) fprintf(f, "S\t%u\t*\tLN:i:%u\tKC:i:%u\n", nd->index[i], nd->seqlen[i], (unsigned)nd->abundance[i]);   // :1021
-    if (ed) for (u64 i = 0; i < ed->n; ++i) fprintf(f, "L\t%u\t%c\t%u\t%c\t%uM\n", ed->n1[i], ed->o1[i], ed->n2[i], ed->o2[i], ed->overlap[i]);   // :1095
-    return fclose(f) == 0 ? MDBG_OK : MDBG_E_PARAM;
+    if (!f) return MDBG_E_IO;
+    bool ok = fprintf(f, "H\tVN:Z:1.0\n") > 0;                                                     // main.rs:1011
+    for (u64 i = 0; ok && i < nd->n; ++i) ok = fprintf(f, "S\t%u\t*\tLN:i:%u\tKC:i:%u\n", nd->index[i], nd->seqlen[i], (unsigned)nd->abundance[i]) > 0;   // :1021
+    if (ed) for (u64 i = 0; ok && i < ed->n; ++i) ok = fprintf(f, "L\t%u\t%c\t%u\t%c\t%uM\n", ed->n1[i], ed->o1[i], ed->n2[i], ed->o2[i], ed->overlap[i]) > 0;   // :1095
+    ok = ok && !ferror(f);                     // a short write (disk full) must not pass for a complete graph
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MDBG_OK : MDBG_E_IO;
 }
 
 mdbg_seqfile* mdbg_seqfile_open(const char* path, uint32_t k, uint32_t l, int* err) {
     FILE* f = path ? fopen(path, "wb") : nullptr;
-    if (!f) { if (err) *err = MDBG_E_PARAM; return nullptr; }
+    if (!f) { if (err) *err = path ? MDBG_E_IO : MDBG_E_PARAM; return nullptr; }
     mdbg_seqfile* s = new mdbg_seqfile(); s->f = f; s->k = k; s->l = l;
     // LZ4 frame header: magic, FLG (version 01, independent blocks), BD (4 MiB blocks), header checksum
     u8 hdr[7] = {0x04, 0x22, 0x4D, 0x18, 0x60, 0x70, 0};
     hdr[6] = (u8)((xxh32(hdr + 4, 2, 0) >> 8) & 0xFF);
-    fwrite(hdr, 1, 7, f);
+    if (fwrite(hdr, 1, 7, f) != 7) { fclose(f); delete s; if (err) *err = MDBG_E_IO; return nullptr; }
     char b[256];
     snprintf(b, sizeof b, "# k = %u\n# l = %u\n", k, l); s->buf += b;                               // main.rs:625-628
     s->buf += "# Structure of remaining of the file:\n";
@@ -186,7 +188,7 @@ int mdbg_seqfile_write_batch(mdbg_seqfile* s, const mdbg_nodes* nd, const uint8_
         else s->buf.append((const char*)bases + ro + a, b - a);
         snprintf(num, sizeof num, "\t*\t*\t(%llu, %llu)\n", (unsigned long long)nd->shift_full[2 * i], (unsigned long long)nd->shift_full[2 * i + 1]);
         s->buf += num;
-        if (s->buf.size() >= (4u << 20) && !s->flush_block()) return MDBG_E_PARAM;
+        if (s->buf.size() >= (4u << 20) && !s->flush_block()) return MDBG_E_IO;
     }
     return MDBG_OK;
 }
@@ -196,9 +198,10 @@ int mdbg_seqfile_close(mdbg_seqfile* s) {
     bool ok = s->flush_block();
     const u32 endmark = 0;
     ok = ok && fwrite(&endmark, 4, 1, s->f) == 1;
+    ok = ok && !ferror(s->f);
     ok = (fclose(s->f) == 0) && ok;
     delete s;
-    return ok ? MDBG_OK : MDBG_E_PARAM;
+    return ok ? MDBG_OK : MDBG_E_IO;
 }
 
 }  // extern "C"

@@ -307,6 +307,10 @@ class GpuEngine:
         ptr, counts = self.m.route_pack(world)
         return self._view(ptr, (sum(counts), self.k + 2)), counts
 
+    def route_empty(self, world):
+        """what a rank with nothing to send contributes to a round"""
+        return self._view(0, (0, self.k + 2)), [0] * world
+
     def alloc_records(self, n):
         """receive buffer for n routed records inside the library's arena (zero-copy insert)"""
         return self._view(self.tm.arena_reserve(n), (n, self.k + 2))
@@ -398,6 +402,7 @@ class DistributedMdbg:
         t, e = self.t, self.e
         q = queue.Queue()
         sent = threading.Semaphore(1)          # route_out of the engine is reused: pack chunk c+1 only after chunk c was sent
+        stop = threading.Event()               # consumer failed: the producer must not stay blocked on `sent`
         err = []
 
         def producer():
@@ -406,7 +411,11 @@ class DistributedMdbg:
                     offs_c = (offsets_dev[r0:r1 + 1] - a).contiguous()
                     t.cuda.synchronize()
                     e.sketch_device(e.base_ptr(d_bases, a), offs_c.data_ptr(), r1 - r0, nb, first_ordinal + r0)
-                    sent.acquire()
+                    while not sent.acquire(timeout=0.2):
+                        if stop.is_set():
+                            return
+                    if stop.is_set():
+                        return
                     q.put(e.route_pack(self.c.world))
             except BaseException as ex:        # noqa: BLE001
                 err.append(ex)
@@ -414,16 +423,19 @@ class DistributedMdbg:
 
         th = threading.Thread(target=producer)
         th.start()
-        for _ in plan:
-            item = q.get()
-            if item is None:
-                break
-            recs, counts = item
-            recv, _ = self.c.alltoallv(recs, counts, getattr(e, "alloc_records", None))
-            t.cuda.synchronize()
-            sent.release()
-            e.insert_records(recv)
-        th.join()
+        try:
+            for _ in plan:
+                item = q.get()
+                # a rank whose producer failed still takes part in the round (with nothing to send): the peers are inside the
+                # same collective and would otherwise wait for it forever; the error is raised once the rounds are over
+                recs, counts = item if item is not None else e.route_empty(self.c.world)
+                recv, _ = self.c.alltoallv(recs, counts, getattr(e, "alloc_records", None))
+                t.cuda.synchronize()
+                sent.release()
+                e.insert_records(recv)
+        finally:
+            stop.set()
+            th.join()
         if err:
             raise err[0]
 

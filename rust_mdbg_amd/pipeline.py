@@ -14,39 +14,53 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
              strip_newlines=False, device=-1, write_sequences=True):
     """-> dict of counters (what the reference prints: reads, nodes before/after filter, edges, presimp removals)"""
     q = queue.Queue(maxsize=2)
+    stop = threading.Event()               # set when the consumer gives up: the reader must not stay blocked in put()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def produce():
         try:
             with Reader(path, strip_newlines) as r:
                 for item in r.batches(batch_bases):
-                    q.put(item)
-            q.put(None)
+                    if not put(item):
+                        return
+            put(None)
         except BaseException as e:          # noqa: BLE001
-            q.put(e)
+            put(e)
 
     th = threading.Thread(target=produce, daemon=True)
     th.start()
     n_reads = n_bases = 0
-    with Mdbg(k, l, density, min_abundance, reads_already_hpc=reads_already_hpc, device=device) as m:
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            bases, offs = item
-            m.ingest(bases, offs, n_reads)          # ctypes releases the GIL: the reader thread parses the next batch meanwhile
-            n_reads += len(offs) - 1
-            n_bases += len(bases)
-        nodes = m.finalize()
-        stats = m.stats()
-        # edges on the GPU from the device-resident node table (the reference's single-threaded loop, src/main.rs:1017-1117);
-        # the host copy of the list goes straight into the GFA writer
-        raw = m.graph_edges(presimp, raw=True)
-        edges = dict(n1=[0] * int(raw.n), presimp_removed=int(raw.presimp_removed))
-        em = Emitter()
-        em.write_gfa(prefix + ".gfa", nodes, raw)
-    th.join()
+    try:
+        with Mdbg(k, l, density, min_abundance, reads_already_hpc=reads_already_hpc, device=device) as m:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                bases, offs = item
+                m.ingest(bases, offs, n_reads)          # ctypes releases the GIL: the reader thread parses the next batch meanwhile
+                n_reads += len(offs) - 1
+                n_bases += len(bases)
+            nodes = m.finalize()
+            stats = m.stats()
+            # edges on the GPU from the device-resident node table (the reference's single-threaded loop, src/main.rs:1017-1117);
+            # the host copy of the list goes straight into the GFA writer
+            raw = m.graph_edges(presimp, raw=True)
+            edges = dict(n1=[0] * int(raw.n), presimp_removed=int(raw.presimp_removed))
+            em = Emitter()
+            em.write_gfa(prefix + ".gfa", nodes, raw)
+    finally:
+        stop.set()                          # error or not: release the reader (it closes the file) and wait for it
+        th.join()
     if write_sequences:                              # second pass over the input for the node sequences
         def again():
             first = 0

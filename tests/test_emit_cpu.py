@@ -112,3 +112,22 @@ def test_emit_library_exports():
     L = E.load_library()
     for s in E.EXPORTS:
         assert hasattr(L, s)
+
+
+def test_write_failures_are_io_errors(example_reads, tmp_path):
+    """a short write (disk full: /dev/full) or an unopenable path is MDBG_E_IO (-7), never a truncated file reported as OK"""
+    if not os.path.exists("/dev/full"):
+        pytest.skip("/dev/full not available")
+    gold = json.load(open(os.path.join(GOLDEN, "example_cfg1.json")))
+    c = gold["config"]
+    r, b, o = oracle_run(example_reads, c["k"], c["l"], c["density"], c["minabund"])
+    em = E.Emitter()
+    em.edges(r)
+    with pytest.raises(RuntimeError, match="-7"):
+        em.write_gfa("/dev/full")
+    with pytest.raises(RuntimeError, match="-7"):
+        em.write_gfa(str(tmp_path / "no_such_dir" / "x.gfa"))
+    with pytest.raises(RuntimeError, match="-7"):
+        em.write_sequences("/dev/full", r, c["l"], [(b, o, 0)])
+    with pytest.raises(RuntimeError, match="-7"):
+        em.write_sequences(str(tmp_path / "no_such_dir" / "x.sequences"), r, c["l"], [(b, o, 0)])

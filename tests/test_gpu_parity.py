@@ -450,6 +450,22 @@ def test_large_and_sparse_read_ordinals():
     assert int(got["src_read"].max()) > (1 << 37) and exp["n_nodes"] > 500
 
 
+def test_overlapping_read_ordinals_are_an_error():
+    """two batches whose ordinal ranges overlap (a caller that always passes 0) must not yield a silently wrong table"""
+    R = _mdbg()
+    reads = rand_reads(7, 40, 3000, 6000)
+    with R.Mdbg(5, 10, 0.02, 2) as m:
+        m.ingest_reads(reads[:20], 0)
+        m.ingest_reads(reads[20:], 10)                               # [10, 30) overlaps [0, 20)
+        with pytest.raises(R.MdbgError) as ei:
+            m.finalize()
+        assert ei.value.code == -1 and "overlap" in str(ei.value)
+        m.reset(0)                                                   # the context stays usable
+        m.ingest_reads(reads[:20], 0)
+        m.ingest_reads(reads[20:], 20)
+        assert m.finalize()["n_nodes"] >= 0
+
+
 def test_param_validation():
     R = _mdbg()
     for kw in (dict(k=1, l=12, density=0.01), dict(k=5, l=1, density=0.01), dict(k=5, l=256, density=0.01),

@@ -77,3 +77,23 @@ def test_plain_c_program_over_the_two_abis(example_reads, tmp_path):
     assert read_lz4_frame(str(tmp_path / "c.0.sequences")) == read_lz4_frame(str(tmp_path / "py.0.sequences"))
     bad = subprocess.run([exe, src, "-k", "1"], capture_output=True, text=True)            # errors are codes + text, not aborts
     assert bad.returncode == 1 and "invalid parameter" in bad.stderr
+
+
+def test_reader_thread_is_released_when_the_consumer_fails(tmp_path):
+    """an error in the GPU stage (here: a byte outside ACGTN) must not leave the reader thread blocked on its queue"""
+    import threading
+    import time
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import pipeline
+    p = str(tmp_path / "bad.fa")
+    with open(p, "w") as f:
+        for i in range(400):
+            f.write(">r%d\n%s\n" % (i, ("ACGTTGCA" * 500) if i != 3 else ("ACGTTGCA" * 200 + "X" + "ACGTTGCA" * 200)))
+    before = threading.active_count()
+    with pytest.raises(R.MdbgError) as ei:
+        pipeline.run_file(p, str(tmp_path / "out"), 5, 10, 0.02, 2, batch_bases=200_000)      # many batches: the reader runs ahead
+    assert ei.value.code == -2
+    deadline = time.time() + 5
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() == before
