@@ -19,6 +19,7 @@
  *   mdbg_graph_edges       km_index + orientation tests + presimp + overlaps           src/main.rs:1017-1117
  *   mdbg_query_batch       --read_stats: abundance of every k-min-mer of a query read  src/main.rs:939-1004
  *   mdbg_reset             a new k over the same reads (utils/multik:69-78 re-runs the binary per k)
+ *   mdbg_mark / _rewind    ... with the script's contig feedback: forget the last round's contigs, keep the reads' sketches
  *   mdbg_destroy           process exit
  *
  * Conventions: every function returns 0 (MDBG_OK) or a negative error code and never aborts (the reference
@@ -179,6 +180,16 @@ int mdbg_finalize_device(mdbg_ctx* ctx, mdbg_nodes* out);
 /* Multi-k: keep every cached sketch and all allocations, clear the node table, and re-window the
  * resident sketches with new_k (new_k == 0: also drop the sketches = start over with the same parameters). */
 int mdbg_reset(mdbg_ctx* ctx, uint32_t new_k);
+/* Multi-k WITH contig feedback (utils/multik:69-78: every round's input is the original reads plus the previous round's contigs, twice):
+ * the reads are ingested once, then mdbg_mark; per round mdbg_rewind(mark) forgets everything ingested after the mark (last round's
+ * contigs) and clears the node table, mdbg_reset(k) re-windows what is resident with the round's k, and the round's contigs are
+ * ingested as ordinary batches.  The reference reads the contigs BEFORE the reads (they come first in its concatenated file), and
+ * DbgEntry.index / the A-th sighting follow the record order: give the reads a first_read_ordinal base above the number of contig
+ * records you will ever add (e.g. 1 << 32) and the contigs the ordinals below it — only the order of the ordinals matters.
+ * mdbg_rewind(mark) with the same k and no new batches restores exactly the state after the mark once mdbg_reset / mdbg_insert_resident
+ * has re-inserted the resident batches.  Not valid while reserved regions are pending (MDBG_E_STATE). */
+int mdbg_mark(mdbg_ctx* ctx, uint64_t* mark);
+int mdbg_rewind(mdbg_ctx* ctx, uint64_t mark);
 
 int mdbg_get_stats(mdbg_ctx* ctx, mdbg_stats* out);
 const char* mdbg_strerror(int err);

@@ -81,7 +81,7 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
            "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
-           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed"]
+           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed", "mdbg_mark", "mdbg_rewind"]
 
 
 def lib_path():
@@ -147,6 +147,10 @@ def load_library():
     L.mdbg_owner_lists.restype = C.c_int
     L.mdbg_sketch_commit_listed.argtypes = [vp, u64, u64, vp, u64, u64, vp, u64]
     L.mdbg_sketch_commit_listed.restype = C.c_int
+    L.mdbg_mark.argtypes = [vp, C.POINTER(u64)]
+    L.mdbg_mark.restype = C.c_int
+    L.mdbg_rewind.argtypes = [vp, u64]
+    L.mdbg_rewind.restype = C.c_int
     L.mdbg_last_batch.argtypes = [vp, C.POINTER(BatchInfo)]
     L.mdbg_graph_edges.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
     L.mdbg_graph_edges_device.argtypes = [vp, C.c_float, C.POINTER(EdgeList)]
@@ -286,6 +290,16 @@ class Mdbg:
         self._chk(self.L.mdbg_reset(self.h, new_k))
         if new_k:
             self.k = new_k
+
+    def mark(self):
+        """-> token naming what is resident now (see rewind)"""
+        mk = C.c_uint64()
+        self._chk(self.L.mdbg_mark(self.h, C.byref(mk)))
+        return int(mk.value)
+
+    def rewind(self, mark):
+        """forget every batch ingested after mark() and clear the node table; follow with reset(k) to re-window what is left"""
+        self._chk(self.L.mdbg_rewind(self.h, mark))
 
     # --- multi-GPU stage calls (raw device pointers; see rust_mdbg_amd/dist.py for the driver) ---
     def route_pack(self, world):

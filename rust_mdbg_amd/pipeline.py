@@ -74,28 +74,58 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                 presimp_removed=edges["presimp_removed"])
 
 
+READ_ORDINAL_BASE = 1 << 32     # contig feedback: the reads' ordinals start here, the contigs of a round take [0, 2 * n_contigs)
+
+
+def concat_records(seqs):
+    """list of bytes -> (uint8 bases, uint64 offsets) as the ingest calls take them"""
+    import numpy as np
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if seqs:
+        offs[1:] = np.cumsum([len(x) for x in seqs], dtype=np.uint64)
+    return np.frombuffer(b"".join(seqs), dtype=np.uint8), offs
+
+
 def run_multik(path, prefix, ks, l, density, min_abundance=2, reads_already_hpc=False, presimp=0.01, batch_bases=256 << 20,
-               strip_newlines=False, device=-1):
-    """One pass over the reads, one graph per k (the k sweep of the reference's utils/multik:69-78 without its contig
-    feedback): the reads are sketched once, the sketches stay resident on the GPU, and every k only clears and refills the
-    counting table (mdbg_reset) and rebuilds nodes and edges.  Writes <prefix>-k<k>.gfa; -> {k: counters}"""
+               strip_newlines=False, device=-1, contigs_fn=None, min_contig_len=100000):
+    """One pass over the reads, one graph per k (the k sweep of the reference's utils/multik:69-78): the reads are sketched once,
+    the sketches stay resident on the GPU, and every k only clears and refills the counting table (mdbg_reset) and rebuilds nodes
+    and edges.  Writes <prefix>-k<k>.gfa; -> {k: counters}.
+
+    contigs_fn(k, gfa_path, nodes) -> list of bytes: the script's contig feedback.  The simplification that turns a round's graph
+    into contigs is the caller's (the script shells out to magic_simplify = gfatools + to_basespace, outside this path); what it
+    returns is filtered like `seqtk seq -L 100000` (min_contig_len), taken TWICE (`zcat -f x.msimpl.fa x.msimpl.fa`, utils/multik:72)
+    and put IN FRONT of the reads for the next k: the reads keep their resident sketches and their ordinals (READ_ORDINAL_BASE + i),
+    the contigs get the ordinals 0 .. 2C-1, and the previous round's contigs are forgotten (mdbg_rewind)."""
     ks = list(ks)
     out = {}
     n_reads = n_bases = 0
+    base = READ_ORDINAL_BASE if contigs_fn is not None else 0
     with Mdbg(ks[0], l, density, min_abundance, reads_already_hpc=reads_already_hpc, device=device) as m, Reader(path, strip_newlines) as r:
         for bases, offs in r.batches(batch_bases):
-            m.ingest(bases, offs, n_reads)
+            m.ingest(bases, offs, base + n_reads)
             n_reads += len(offs) - 1
             n_bases += len(bases)
+        mark = m.mark()
         em = Emitter()
+        contigs = []
         for i, k in enumerate(ks):
             if i:
+                if contigs_fn is not None:
+                    m.rewind(mark)                       # last round's contigs go, the reads' sketches stay
                 m.reset(k)                               # sketches stay; windows of the new k are inserted again
+                if contigs:
+                    twice = contigs + contigs
+                    cb, co = concat_records(twice)
+                    m.ingest(cb, co, 0)
             nodes = m.finalize()
             raw = m.graph_edges(presimp, raw=True)
-            em.write_gfa("%s-k%d.gfa" % (prefix, k), nodes, raw)
+            gfa = "%s-k%d.gfa" % (prefix, k)
+            em.write_gfa(gfa, nodes, raw)
             st = m.stats()
-            out[k] = dict(n_reads=n_reads, n_bases=n_bases, n_minimizers=st["n_minimizers"], n_windows=st["n_windows"],
+            out[k] = dict(n_reads=n_reads, n_bases=n_bases, n_contigs=len(contigs), n_minimizers=st["n_minimizers"], n_windows=st["n_windows"],
                           n_nodes_before=nodes["n_nodes_before"], n_nodes=nodes["n_nodes"], n_edges=int(raw.n),
                           presimp_removed=int(raw.presimp_removed))
+            if contigs_fn is not None:
+                contigs = [bytes(c) for c in contigs_fn(k, gfa, nodes) if len(c) >= min_contig_len]
     return out

@@ -97,3 +97,43 @@ def test_reader_thread_is_released_when_the_consumer_fails(tmp_path):
     while threading.active_count() > before and time.time() < deadline:
         time.sleep(0.05)
     assert threading.active_count() == before
+
+
+def test_multik_with_contig_feedback(tmp_path):
+    """utils/multik:69-78 with its feedback loop: round i+1 sees [contigs of round i, twice] + reads, in that order.  The GPU side
+    keeps the reads' sketches, forgets the previous contigs (mdbg_rewind) and ingests the new ones below the reads' ordinals; every
+    round must equal a from-scratch oracle run over the concatenated input in the reference's file order."""
+    from rust_mdbg_amd import pipeline, synth
+    reads = synth.synth_reads(5, 400000, 120, mean_len=14000, sd_len=1500, min_len=5000, max_len=20000, err_ppm=1000)
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">r%d\n" % i + s + b"\n")
+    l, d, a = 12, 0.003, 2
+    ks = [10, 15, 20]
+    given = {}
+
+    def contigs_fn(k, gfa_path, nodes):
+        # stand-in for magic_simplify: sequences that depend on the round, one of them too short to pass `seqtk seq -L 100000`
+        assert os.path.exists(gfa_path) and nodes["n_nodes"] > 0
+        j = ks.index(k)
+        c = [b"".join(reads[10 * j:10 * j + 9]), reads[j], O.revcomp(b"".join(reads[40 + 8 * j:40 + 8 * j + 8]))]
+        given[k] = c
+        return c
+
+    out = pipeline.run_multik(fa, str(tmp_path / "mk"), ks, l, d, a, batch_bases=400_000, contigs_fn=contigs_fn)
+    prev = []
+    for k in ks:
+        kept = [c for c in prev if len(c) >= 100000]
+        assert out[k]["n_contigs"] == len(kept) and (not prev or len(kept) == 2)
+        b, o = O.concat_reads(kept + kept + reads)
+        g = O.Graph(k, l, d, a)
+        g.ingest(b, o)
+        r = g.finalize(with_edges=True)
+        c = out[k]
+        assert (c["n_nodes_before"], c["n_nodes"], c["n_edges"], c["presimp_removed"]) == (r["n_nodes_before"], r["n_nodes"], r["n_edges"], r["presimp_removed"])
+        lines = open("%s-k%d.gfa" % (str(tmp_path / "mk"), k)).read().split("\n")
+        assert [x for x in lines if x.startswith("S")] == ["S\t%d\t*\tLN:i:%d\tKC:i:%d" % (r["index"][i], r["seqlen"][i], r["abundance"][i]) for i in range(r["n_nodes"])]
+        assert sorted(x for x in lines if x.startswith("L")) == sorted("L\t%d\t%s\t%d\t%s\t%dM" % (x, chr(p), y, chr(q), ov) for x, p, y, q, ov in oracle_edges(r))
+        prev = given[k]
+    assert out[15]["n_nodes"] != out[10]["n_nodes"]
