@@ -126,9 +126,37 @@ static void encode_rle(const u8* s, size_t n, std::string& hpc, std::vector<u64>
     hpc.push_back((char)prev); pos.push_back(prev_i);
 }
 
-// src/read.rs:176-211 — density sketch (the lmer-counts/EC branch :200-205 is out of scope).
+static std::string revcomp(const std::string& s);
+
+// --lmer-counts (robust minimizers).  src/main.rs:544-566: every line "lmer count" of the counts file goes into a map keyed by
+// min(lmer, revcomp(lmer)) (later lines overwrite).  src/minimizers.rs:53-113 (minimizers_preparation, the `lmer_counts.len() > 0`
+// branch): an l-mer of the map is SELECTED iff it is not skipped (count >= lmer_counts_max or count <= lmer_counts_min, :80-83) and
+// `hash as f64 / u64::MAX as f64 <= density` in f64 (:91-98); both it and its reverse complement then map to its canonical ntHash
+// (:99-106).  `Some` map = the mode is on (params.has_lmer_counts).
+typedef std::unordered_map<std::string, u64> LmerMap;
+static int lmer_map_build(const std::vector<std::pair<std::string, u32>>& lines, size_t l, double density, u32 cmin, u32 cmax, LmerMap& out) {
+    std::unordered_map<std::string, u32> counts;                                    // main.rs:544
+    for (const auto& ln : lines) {
+        const std::string rc = revcomp(ln.first);
+        counts[ln.first < rc ? ln.first : rc] = ln.second;                          // main.rs:560-564
+    }
+    out.clear();
+    for (const auto& kv : counts) {
+        const std::string& lmer = kv.first;                                         // min(x, revcomp(x)) of a canonical key is the key (minimizers.rs:64-65)
+        if (lmer.size() < l) return ORC_E_PARAM;                                    // ntc64 would index past the string
+        const bool skip = kv.second >= cmax || kv.second <= cmin;                   // minimizers.rs:80
+        u64 h; int e = ntc64((const u8*)lmer.data(), 0, l, &h); if (e) return e;    // :88
+        double hn = (double)h / 18446744073709551616.0;                             // :89-90 (u64::MAX as f64 == 2^64)
+        if (skip) hn = 1.0;                                                         // :91-95
+        if (hn <= density) { out[lmer] = h; out[revcomp(lmer)] = h; }               // :96-106
+    }
+    return ORC_OK;
+}
+
+// src/read.rs:176-211 — density sketch; lmer_map != nullptr: the --lmer-counts branch :200-205 (an l-mer that is not in the map is
+// skipped, the stored hash replaces the computed one — it is the same value).
 struct Sketch { std::vector<u64> transformed; std::vector<u64> pos; };
-static int extract_density(const u8* s, size_t n, size_t l, double density, bool already_hpc, Sketch& out) {
+static int extract_density(const u8* s, size_t n, size_t l, double density, bool already_hpc, Sketch& out, const LmerMap* lmer_map = nullptr) {
     out.transformed.clear(); out.pos.clear();
     u64 bound = hash_bound(density);
     std::string hpc; std::vector<u64> posvec;
@@ -141,8 +169,14 @@ static int extract_density(const u8* s, size_t n, size_t l, double density, bool
     if (e) return e;
     for (size_t i = 0; i < hs.size(); ++i) {
         if (hs[i] <= bound) {                                    // inclusive, read.rs:196
+            u64 h = hs[i];
+            if (lmer_map) {                                      // read.rs:200-205
+                auto it = lmer_map->find(std::string((const char*)seq + i, l));
+                if (it == lmer_map->end()) continue;
+                h = it->second;
+            }
             out.pos.push_back(already_hpc ? (u64)i : posvec[i]); // read.rs:206-207
-            out.transformed.push_back(hs[i]);
+            out.transformed.push_back(h);
         }
     }
     return ORC_OK;
@@ -265,6 +299,7 @@ static int extract_syncmers(const u8* inp, size_t n, size_t l, size_t sm, double
 struct Graph {
     size_t k, l; double density; u16 minabund; bool already_hpc; float presimp;
     bool syncmers = false; size_t sync_s = 0;      // --syncmers / -s (src/read.rs:88)
+    bool has_lmer_counts = false; LmerMap lmer_map; // --lmer-counts (src/main.rs:499-503, 571-575)
     std::map<Kmer, Entry> nodes;                  // dbg_nodes, main.rs:595 (ordered map: deterministic, same contents)
     u64 node_index = 0;                           // NODE_INDEX, main.rs:598
     std::vector<SeqLine> seqlines;
@@ -298,7 +333,8 @@ struct Graph {
 
     // src/main.rs:730-785 (process_read_aux), window loop :756-781
     int process_read(const u8* s, size_t n, u64 read_ordinal) {
-        Sketch sk; int e = syncmers ? extract_syncmers(s, n, l, sync_s, density, already_hpc, sk) : extract_density(s, n, l, density, already_hpc, sk);
+        Sketch sk; int e = syncmers ? extract_syncmers(s, n, l, sync_s, density, already_hpc, sk)
+                                    : extract_density(s, n, l, density, already_hpc, sk, has_lmer_counts ? &lmer_map : nullptr);
         if (e) return e;
         ++n_reads; n_minimizers += sk.transformed.size();
         const auto& T = sk.transformed; const auto& P = sk.pos;
@@ -423,6 +459,34 @@ orc_sketch_t* orc_sketch_syncmers(const uint8_t* bases, const uint64_t* offsets,
     }
     return r;
 }
+// --lmer-counts: the selected l-mers of a counts file given as its lines (lmer i = bytes[offs[i], offs[i+1]), count[i])
+struct orc_lmer_map_t { LmerMap m; int err; std::vector<u8> dump; std::vector<u64> dump_hash; };
+orc_lmer_map_t* orc_lmer_map_new(const uint8_t* bytes, const uint64_t* offs, const uint32_t* counts, uint64_t n, uint64_t l, double density, uint32_t cmin, uint32_t cmax) {
+    auto* r = new orc_lmer_map_t();
+    std::vector<std::pair<std::string, u32>> lines;
+    for (u64 i = 0; i < n; ++i) lines.emplace_back(std::string((const char*)bytes + offs[i], offs[i + 1] - offs[i]), counts[i]);
+    r->err = lmer_map_build(lines, l, density, cmin, cmax, r->m);
+    std::vector<std::pair<std::string, u64>> v(r->m.begin(), r->m.end());
+    std::sort(v.begin(), v.end());
+    for (const auto& kv : v) { r->dump.insert(r->dump.end(), kv.first.begin(), kv.first.begin() + l); r->dump_hash.push_back(kv.second); }
+    return r;
+}
+int orc_lmer_map_err(orc_lmer_map_t* m) { return m->err; }
+uint64_t orc_lmer_map_n(orc_lmer_map_t* m) { return m->dump_hash.size(); }
+const uint8_t* orc_lmer_map_lmers(orc_lmer_map_t* m) { return m->dump.data(); }          // n * l bytes, sorted
+const uint64_t* orc_lmer_map_hashes(orc_lmer_map_t* m) { return m->dump_hash.data(); }
+void orc_lmer_map_free(orc_lmer_map_t* m) { delete m; }
+orc_sketch_t* orc_sketch_lmer(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t l, double density, int already_hpc, orc_lmer_map_t* map) {
+    auto* r = new orc_sketch_t(); r->err = map->err; r->err_read = 0; r->off.push_back(0);
+    for (u64 i = 0; i < n_reads; ++i) {
+        Sketch sk; int e = extract_density(bases + offsets[i], offsets[i + 1] - offsets[i], l, density, already_hpc != 0, sk, &map->m);
+        if (e && !r->err) { r->err = e; r->err_read = i; }
+        r->hashes.insert(r->hashes.end(), sk.transformed.begin(), sk.transformed.end());
+        r->pos.insert(r->pos.end(), sk.pos.begin(), sk.pos.end());
+        r->off.push_back(r->hashes.size());
+    }
+    return r;
+}
 int orc_sketch_err(orc_sketch_t* s) { return s->err; }
 uint64_t orc_sketch_n(orc_sketch_t* s) { return s->hashes.size(); }
 const uint64_t* orc_sketch_hashes(orc_sketch_t* s) { return s->hashes.data(); }
@@ -441,6 +505,7 @@ orc_graph_t* orc_graph_new(uint64_t k, uint64_t l, double density, uint32_t mina
     if (minabund == 0 || minabund > 65535 || k < 2 || l < 1) h->err = ORC_E_PARAM;
     return h;
 }
+void orc_graph_set_lmer_map(orc_graph_t* h, orc_lmer_map_t* map) { h->g.has_lmer_counts = true; h->g.lmer_map = map->m; if (map->err) h->err = map->err; }
 void orc_graph_set_syncmers(orc_graph_t* h, uint64_t sm) { h->g.syncmers = true; h->g.sync_s = sm; if (h->g.l > 31 || sm > h->g.l) h->err = ORC_E_PARAM; }
 int orc_graph_ingest(orc_graph_t* h, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t first_read_ordinal) {
     if (h->err) return h->err;

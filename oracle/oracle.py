@@ -47,6 +47,20 @@ def lib():
     L.orc_sketch_syncmers.restype = C.c_void_p
     L.orc_sketch_syncmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_int]
     L.orc_graph_set_syncmers.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_lmer_map_new.restype = C.c_void_p
+    L.orc_lmer_map_new.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_uint32, C.c_uint32]
+    L.orc_lmer_map_err.restype = C.c_int
+    L.orc_lmer_map_err.argtypes = [C.c_void_p]
+    L.orc_lmer_map_n.restype = C.c_uint64
+    L.orc_lmer_map_n.argtypes = [C.c_void_p]
+    L.orc_lmer_map_lmers.restype = u8p
+    L.orc_lmer_map_lmers.argtypes = [C.c_void_p]
+    L.orc_lmer_map_hashes.restype = u64p
+    L.orc_lmer_map_hashes.argtypes = [C.c_void_p]
+    L.orc_lmer_map_free.argtypes = [C.c_void_p]
+    L.orc_sketch_lmer.restype = C.c_void_p
+    L.orc_sketch_lmer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_void_p]
+    L.orc_graph_set_lmer_map.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_sketch_err.restype = C.c_int
     L.orc_sketch_err.argtypes = [C.c_void_p]
     L.orc_sketch_n.restype = C.c_uint64
@@ -147,13 +161,47 @@ def concat_reads(reads):
     return bases, offs
 
 
-def sketch(bases, offsets, l, density, already_hpc=False, syncmer_s=None):
-    """-> dict(hashes u64[m], pos u64[m], off u64[n+1], err int); syncmer_s: --syncmers -s (src/read.rs:215-352) instead of the density scheme"""
+class LmerMap:
+    """--lmer-counts: the selected l-mers (src/main.rs:544-566 + src/minimizers.rs:53-113) of a counts file given as its lines
+    [(lmer bytes, count)]; cmin / cmax: --lmer_counts_min / _max (defaults 2 / 100000, main.rs:447-448)"""
+
+    def __init__(self, lines, l, density, cmin=2, cmax=100000):
+        self.L = lib()
+        self.l = l
+        b, o = concat_reads([x for x, _ in lines])
+        cnt = np.ascontiguousarray([c for _, c in lines], dtype=np.uint32)
+        self.h = self.L.orc_lmer_map_new(b.ctypes.data, o.ctypes.data, cnt.ctypes.data, len(lines), l, density, cmin, cmax)
+        self.err = self.L.orc_lmer_map_err(self.h)
+
+    def selected(self):
+        """-> sorted [(lmer bytes, hash)] including both orientations"""
+        n = int(self.L.orc_lmer_map_n(self.h))
+        raw = _arr(self.L.orc_lmer_map_lmers(self.h), n * self.l, np.uint8).tobytes()
+        hs = _arr(self.L.orc_lmer_map_hashes(self.h), n, np.uint64)
+        return [(raw[i * self.l:(i + 1) * self.l], int(hs[i])) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.L.orc_lmer_map_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sketch(bases, offsets, l, density, already_hpc=False, syncmer_s=None, lmer_map=None):
+    """-> dict(hashes u64[m], pos u64[m], off u64[n+1], err int); syncmer_s: --syncmers -s (src/read.rs:215-352) instead of the density scheme;
+    lmer_map: a LmerMap = --lmer-counts"""
     L = lib()
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
-    if syncmer_s is None:
+    if lmer_map is not None:
+        h = L.orc_sketch_lmer(bases.ctypes.data, offsets.ctypes.data, n, l, density, int(already_hpc), lmer_map.h)
+    elif syncmer_s is None:
         h = L.orc_sketch(bases.ctypes.data, offsets.ctypes.data, n, l, density, int(already_hpc))
     else:
         h = L.orc_sketch_syncmers(bases.ctypes.data, offsets.ctypes.data, n, l, syncmer_s, density, int(already_hpc))
@@ -168,10 +216,12 @@ def sketch(bases, offsets, l, density, already_hpc=False, syncmer_s=None):
 class Graph:
     """Sequential reference semantics (= rust-mdbg --threads 1, no --bf)."""
 
-    def __init__(self, k, l, density, minabund=2, already_hpc=False, presimp=0.01, syncmer_s=None):
+    def __init__(self, k, l, density, minabund=2, already_hpc=False, presimp=0.01, syncmer_s=None, lmer_map=None):
         self.L = lib()
         self.k = k
         self.h = self.L.orc_graph_new(k, l, density, minabund, int(already_hpc), presimp)
+        if lmer_map is not None:
+            self.L.orc_graph_set_lmer_map(self.h, lmer_map.h)
         if syncmer_s is not None:
             self.L.orc_graph_set_syncmers(self.h, syncmer_s)
         self.n_ingested = 0

@@ -90,8 +90,36 @@ def canonical_hashes(text, l):
     return np.minimum(fh, rh)
 
 
-def sketch_read(seq, l, density, already_hpc=False):
-    """src/read.rs:176-211 -> (hashes, raw positions) or None for the nthash panic"""
+SWITCH_BASE = {"a": "t", "c": "g", "t": "a", "g": "c", "u": "a", "A": "T", "C": "G", "T": "A", "G": "C", "U": "A"}   # src/utils.rs:10-24, anything else -> N
+
+
+def revcomp_str(s):
+    return "".join(SWITCH_BASE.get(c, "N") for c in reversed(s))
+
+
+def lmer_selection(lines, l, density, cmin=2, cmax=100000):
+    """--lmer-counts.  lines: [(lmer str, count)] as in the counts file.  src/main.rs:552-565: the table is keyed by
+    min(lmer, revcomp(lmer)), a later line replaces an earlier one.  src/minimizers.rs:53-113 (branch with counts): an l-mer is
+    selected iff NOT (count >= max or count <= min) and float(hash) / 2^64 <= density, where hash is the canonical ntHash of its first l
+    characters; it and its reverse complement are then both accepted.  -> {lmer str: hash}"""
+    table = {}
+    for lmer, count in lines:
+        rc = revcomp_str(lmer)
+        table[lmer if lmer < rc else rc] = count
+    out = {}
+    for lmer, count in table.items():
+        h = canonical_hashes(np.frombuffer(lmer[:l].encode(), dtype=np.uint8), l)
+        assert h is not None and len(h) == 1
+        hv = int(h[0])
+        ratio = 1.0 if (count >= cmax or count <= cmin) else float(hv) / 18446744073709551616.0      # int -> f64 rounds to nearest, like `as f64`
+        if ratio <= float(density):
+            out[lmer] = hv
+            out[revcomp_str(lmer)] = hv
+    return out
+
+
+def sketch_read(seq, l, density, already_hpc=False, lmer_sel=None):
+    """src/read.rs:176-211 -> (hashes, raw positions) or None for the nthash panic; lmer_sel: lmer_selection() = --lmer-counts (:200-205)"""
     if already_hpc:
         text = np.frombuffer(seq, dtype=np.uint8)
         pos = np.arange(len(text), dtype=np.int64)
@@ -103,6 +131,11 @@ def sketch_read(seq, l, density, already_hpc=False):
     if h is None:
         return None
     sel = np.nonzero(h <= U64(hash_bound(density)))[0]
+    if lmer_sel is not None:
+        tb = bytes(text)
+        sel = np.array([i for i in sel if tb[i:i + l].decode("latin-1") in lmer_sel], dtype=np.int64)
+        if len(sel) == 0:
+            return np.zeros(0, dtype=U64), np.zeros(0, dtype=np.int64)
     return h[sel], pos[sel]
 
 
@@ -189,9 +222,10 @@ def sketch_read_syncmers(seq, l, s, density, already_hpc=False):
 class Graph:
     """src/main.rs:632-709,756-781 with --threads 1 and without --bf"""
 
-    def __init__(self, k, l, density, minabund, already_hpc=False, syncmer_s=None):
+    def __init__(self, k, l, density, minabund, already_hpc=False, syncmer_s=None, lmer_sel=None):
         self.k, self.l, self.d, self.A, self.hpc_in = k, l, density, minabund, already_hpc
         self.sync_s = syncmer_s
+        self.lmer_sel = lmer_sel
         self.nodes = {}          # key tuple -> [index, abundance(u16), seqlen(u32), shift(u16,u16), reversed, src_read, src_start, src_end, shift_full]
         self.next_index = 0
         self.n_minimizers = 0
@@ -203,7 +237,7 @@ class Graph:
             hs_, ps_ = sketch_read_syncmers(seq, self.l, self.sync_s, self.d, self.hpc_in)
             sk = (np.array(hs_, dtype=U64), np.array(ps_, dtype=np.int64))
         else:
-            sk = sketch_read(seq, self.l, self.d, self.hpc_in)
+            sk = sketch_read(seq, self.l, self.d, self.hpc_in, self.lmer_sel)
         if sk is None:
             return False
         h, p = sk
@@ -414,6 +448,64 @@ def syncmer_cases(seed=20260928, n_cases=20):
     return cases
 
 
+def lmer_cases(seed=20260929, n_cases=16):
+    """--lmer-counts: the counts file is what a k-mer counter would report for the (HPC) reads, perturbed: some l-mers missing, some listed
+    in the non-canonical orientation, some twice with different counts, some above / below the thresholds"""
+    rnd = random.Random(seed)
+    cases = []
+    for ci in range(n_cases):
+        genome = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([800, 3000, 8000])))
+        if ci % 4 == 1:
+            genome = "".join(ch * rnd.choice([1, 1, 2, 4]) for ch in genome[:1500])
+        reads = []
+        for _ in range(rnd.randint(2, 12)):
+            a = rnd.randrange(len(genome))
+            r = genome[a:min(len(genome), a + rnd.choice([30, 400, 1500, 4000]))]
+            if rnd.random() < 0.4:
+                r = "".join(COMPLEMENT[c] for c in reversed(r))
+            if rnd.random() < 0.25 and r:
+                p = rnd.randrange(len(r))
+                r = r[:p] + rnd.choice(["N", "NN"]) + r[p + 1:]
+            reads.append(r)
+        l = rnd.choice([5, 8, 10, 12, 14, 21, 31, 32])
+        k = rnd.choice([2, 3, 4, 6])
+        d = rnd.choice([0.05, 0.2, 0.5, 1.0])
+        A = rnd.choice([1, 2, 2, 3])
+        hpc_in = rnd.random() < 0.25
+        counts = {}
+        for r in reads:
+            text = r.encode() if hpc_in else bytes(run_starts(r.encode())[0])
+            for i in range(len(text) - l + 1):
+                w = text[i:i + l].decode()
+                if "N" not in w:
+                    counts[w] = counts.get(w, 0) + 1
+        lines = []
+        for w, c in counts.items():
+            u = rnd.random()
+            if u < 0.15:
+                continue                                  # the counter did not report it
+            if u < 0.35:
+                w = revcomp_str(w)
+            lines.append((w, c + rnd.choice([0, 0, 0, 1, 3])))
+            if u > 0.9:
+                lines.append((revcomp_str(w), rnd.choice([1, 2, 7])))     # a second line for the same canonical l-mer: the later one wins
+        rnd.shuffle(lines)
+        cmin, cmax = rnd.choice([(0, 100000), (1, 100000), (2, 100000), (1, 4), (0, 3)])
+        sel = lmer_selection(lines, l, d, cmin, cmax)
+        g = Graph(k, l, d, A, hpc_in, lmer_sel=sel)
+        for i, r in enumerate(reads):
+            assert g.add_read(i, r.encode())
+        res = g.finalize(0.01)
+        case = dict(reads=reads, k=k, l=l, density=d, minabund=A, already_hpc=hpc_in, presimp=0.01, lmer_lines=[[w, c] for w, c in lines], lmer_min=cmin, lmer_max=cmax)
+        case["selected"] = sorted([w, h] for w, h in sel.items())
+        case["sketch"] = [[[int(x) for x in s_[1]], [int(x) for x in s_[0]]] for s_ in g.sketches]
+        case.update({f: res[f] for f in ("n_minimizers", "n_windows", "n_nodes_before", "n_nodes", "presimp_removed")})
+        case["nodes"] = res["nodes"]
+        case["edges"] = [list(e) for e in res["edges"]]
+        cases.append(case)
+    return cases
+
+
 if __name__ == "__main__":
     c1 = config1()
     json.dump(c1, open(os.path.join(HERE, "independent_cfg1.json"), "w"), indent=1)
@@ -422,6 +514,9 @@ if __name__ == "__main__":
     json.dump(dict(generator="tests/golden/independent_restatement.py", seed=20260927, cases=cs), open(os.path.join(HERE, "independent_cases.json"), "w"))
     sc = syncmer_cases()
     json.dump(dict(generator="tests/golden/independent_restatement.py", seed=20260928, cases=sc), open(os.path.join(HERE, "independent_syncmer_cases.json"), "w"))
+    lc = lmer_cases()
+    json.dump(dict(generator="tests/golden/independent_restatement.py", seed=20260929, cases=lc), open(os.path.join(HERE, "independent_lmer_cases.json"), "w"))
+    print(len(lc), "lmer-counts cases,", sum(len(c["selected"]) for c in lc), "selected l-mers,", sum(c["n_minimizers"] for c in lc), "minimizers,", sum(c["n_nodes"] for c in lc), "nodes")
     print(len(sc), "syncmer cases,", sum(c["n_minimizers"] for c in sc), "minimizers,", sum(c["n_nodes"] for c in sc), "nodes")
     print(len(cs), "cases,", sum("error_read" in c for c in cs), "with the alphabet error,", sum(c.get("n_nodes", 0) for c in cs), "nodes,",
           sum(len(c.get("edges", [])) for c in cs), "edges")

@@ -100,3 +100,38 @@ def test_oracle_syncmers_equal_independent_restatement(ci):
     got = sorted([int(a), chr(b), int(cc), chr(d), int(e)] for a, b, cc, d, e in
                  zip(r["edge_n1"], r["edge_o1"], r["edge_n2"], r["edge_o2"], r["edge_overlap"]))
     assert got == sorted(c["edges"])
+
+
+LMER_CASES = json.load(open(os.path.join(GOLDEN, "independent_lmer_cases.json")))["cases"]
+
+
+def test_lmer_fixtures_are_what_the_restatement_generates_today():
+    from golden import independent_restatement as I
+    assert json.loads(json.dumps(I.lmer_cases())) == LMER_CASES
+
+
+@pytest.mark.parametrize("ci", range(len(LMER_CASES)))
+def test_oracle_lmer_counts_equal_independent_restatement(ci):
+    """--lmer-counts (src/main.rs:544-566, src/minimizers.rs:53-113, src/read.rs:200-205): selection of the l-mers, filtered sketch, graph"""
+    c = LMER_CASES[ci]
+    reads = [r.encode() for r in c["reads"]]
+    bases, offs = O.concat_reads(reads)
+    m = O.LmerMap([(w.encode(), n) for w, n in c["lmer_lines"]], c["l"], c["density"], c["lmer_min"], c["lmer_max"])
+    assert m.err == 0
+    assert [[w.decode(), h] for w, h in m.selected()] == c["selected"]
+    sk = O.sketch(bases, offs, c["l"], c["density"], c["already_hpc"], lmer_map=m)
+    assert sk["err"] == 0
+    o = sk["off"]
+    for i, (pos, hs) in enumerate(c["sketch"]):
+        assert sk["pos"][int(o[i]):int(o[i + 1])].tolist() == pos and sk["hashes"][int(o[i]):int(o[i + 1])].tolist() == hs, ("sketch of read", i)
+    g = O.Graph(c["k"], c["l"], c["density"], c["minabund"], c["already_hpc"], c["presimp"], lmer_map=m)
+    assert g.ingest(bases, offs) == 0
+    r = g.finalize()
+    for f in ("n_minimizers", "n_windows", "n_nodes_before", "n_nodes", "presimp_removed"):
+        assert r[f] == c[f], f
+    for row, n in enumerate(c["nodes"]):
+        assert r["keys"][row].tolist() == n["key"] and int(r["index"][row]) == n["index"] and int(r["abundance"][row]) == n["abundance"]
+        assert int(r["seqlen"][row]) == n["seqlen"] and r["shift"][row].tolist() == n["shift"] and int(r["src_start"][row]) == n["src_start"]
+    got = sorted([int(a), chr(b), int(cc), chr(d), int(e)] for a, b, cc, d, e in
+                 zip(r["edge_n1"], r["edge_o1"], r["edge_n2"], r["edge_o2"], r["edge_overlap"]))
+    assert got == sorted(c["edges"])
