@@ -59,6 +59,17 @@ void mdbg_reader_close(mdbg_reader* r);
  * (two 32-bit planes per 32 bases) before it crosses PCIe.  words: (n_bases + 31) / 32 entries.  Bytes outside "ACGT" go
  * to exc_pos / exc_val (ascending; room for exc_cap entries); *n_exc is their number, MDBG_E_CAPACITY if it exceeds exc_cap
  * (the words are complete either way).  threads <= 1: the calling thread only. */
+/* --lmer-counts FILE --lmer_counts_min A --lmer_counts_max B (src/main.rs:392-409, 544-575; src/minimizers.rs:53-113): reads the counts
+ * file ("lmer count" per line, as kmc_dump writes it), keys every l-mer by min(lmer, revcomp), and SELECTS an l-mer iff its count is
+ * inside (count_min, count_max) exclusive and f64(canonical ntHash) / 2^64 <= density.  *codes (malloc'ed, free with
+ * mdbg_lmer_filter_free; sorted, unique) lists the selected l-mers AND their reverse complements as 2-bit codes in the layout
+ * mdbg_set_lmer_filter takes.  Lines whose l-mer has another length than l or a byte outside ACGT cannot match any read l-mer of the
+ * density path and are counted in *n_ignored (may be NULL).  Defaults of the reference: count_min 2, count_max 100000.  l <= 32.
+ * MDBG_E_IO: the file cannot be read; MDBG_E_PARAM: a line without a valid u32 count (the reference panics). */
+int mdbg_lmer_filter_from_counts(const char* path, uint32_t l, double density, uint32_t count_min, uint32_t count_max,
+                                 uint64_t** codes, uint64_t* n_codes, uint64_t* n_ignored);
+void mdbg_lmer_filter_free(uint64_t* codes);
+
 uint64_t mdbg_packed_words(uint64_t n_bases);
 int mdbg_pack_reads(const uint8_t* bases, uint64_t n_bases, uint64_t* words, uint64_t* exc_pos, uint8_t* exc_val,
                     uint64_t exc_cap, uint64_t* n_exc, int threads);

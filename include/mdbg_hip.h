@@ -19,6 +19,7 @@
  *   mdbg_graph_edges       km_index + orientation tests + presimp + overlaps           src/main.rs:1017-1117
  *   mdbg_query_batch       --read_stats: abundance of every k-min-mer of a query read  src/main.rs:939-1004
  *   mdbg_reset             a new k over the same reads (utils/multik:69-78 re-runs the binary per k)
+ *   mdbg_set_lmer_filter   --lmer-counts: restrict the minimizers to the l-mers selected from a counts file
  *   mdbg_mark / _rewind    ... with the script's contig feedback: forget the last round's contigs, keep the reads' sketches
  *   mdbg_destroy           process exit
  *
@@ -180,6 +181,14 @@ int mdbg_finalize_device(mdbg_ctx* ctx, mdbg_nodes* out);
 /* Multi-k: keep every cached sketch and all allocations, clear the node table, and re-window the
  * resident sketches with new_k (new_k == 0: also drop the sketches = start over with the same parameters). */
 int mdbg_reset(mdbg_ctx* ctx, uint32_t new_k);
+/* --lmer-counts (robust minimizers; src/main.rs:544-575, src/minimizers.rs:53-113, src/read.rs:200-205): a minimizer that passed the density
+ * threshold is kept only if its l-mer is one of the SELECTED l-mers of a counts file.  codes: the selected l-mers, BOTH orientations
+ * listed (the reference inserts an l-mer and its reverse complement), each as a 2-bit code: first base in the highest of the 2*l bits,
+ * base code (ascii >> 1) & 3 (A 0, C 1, T 2, G 3); libmdbg_emit's mdbg_lmer_filter_from_counts builds the list from the counts file with
+ * the reference's rule.  n = 0 with a non-null pointer = an empty selection (no minimizer survives); codes = NULL switches the filter
+ * off.  Density scheme only, l <= 32; call before the first batch (the filter is part of the sketch).  The filter applies to every
+ * sketch the context computes afterwards, mdbg_query_batch included. */
+int mdbg_set_lmer_filter(mdbg_ctx* ctx, const uint64_t* codes, uint64_t n);
 /* Multi-k WITH contig feedback (utils/multik:69-78: every round's input is the original reads plus the previous round's contigs, twice):
  * the reads are ingested once, then mdbg_mark; per round mdbg_rewind(mark) forgets everything ingested after the mark (last round's
  * contigs) and clears the node table, mdbg_reset(k) re-windows what is resident with the round's k, and the round's contigs are

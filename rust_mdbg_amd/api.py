@@ -81,7 +81,7 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
            "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
-           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed", "mdbg_mark", "mdbg_rewind"]
+           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed", "mdbg_mark", "mdbg_rewind", "mdbg_set_lmer_filter"]
 
 
 def lib_path():
@@ -147,6 +147,8 @@ def load_library():
     L.mdbg_owner_lists.restype = C.c_int
     L.mdbg_sketch_commit_listed.argtypes = [vp, u64, u64, vp, u64, u64, vp, u64]
     L.mdbg_sketch_commit_listed.restype = C.c_int
+    L.mdbg_set_lmer_filter.argtypes = [vp, vp, u64]
+    L.mdbg_set_lmer_filter.restype = C.c_int
     L.mdbg_mark.argtypes = [vp, C.POINTER(u64)]
     L.mdbg_mark.restype = C.c_int
     L.mdbg_rewind.argtypes = [vp, u64]
@@ -290,6 +292,16 @@ class Mdbg:
         self._chk(self.L.mdbg_reset(self.h, new_k))
         if new_k:
             self.k = new_k
+
+    def set_lmer_filter(self, codes):
+        """--lmer-counts: codes = uint64 array of the selected l-mers' 2-bit codes, both orientations (emit.lmer_filter_from_counts);
+        None switches the filter off.  Before the first batch."""
+        if codes is None:
+            self._chk(self.L.mdbg_set_lmer_filter(self.h, None, 0))
+            return
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        keep = codes if len(codes) else np.zeros(1, dtype=np.uint64)        # a non-null pointer also for the empty selection
+        self._chk(self.L.mdbg_set_lmer_filter(self.h, keep.ctypes.data, len(codes)))
 
     def mark(self):
         """-> token naming what is resident now (see rewind)"""

@@ -4,6 +4,9 @@
 // shared with the CPU oracle.  Data structures differ from the reference (flat arrays + one hash map from a (k-1)-mer
 // to the nodes listing it), the emitted multiset of edges is the same.
 #include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -468,4 +471,83 @@ int mdbg_pack_reads(const uint8_t* bases, uint64_t n_bases, uint64_t* words, uin
     *n_exc = n;
     return n > exc_cap ? MDBG_E_CAPACITY : MDBG_OK;
 }
+// ---- --lmer-counts: the selected l-mers of a counts file ---------------------------------------------------------------------------
+// What main.rs:544-566 (the table: key = min(lmer, revcomp(lmer)), later lines win) and minimizers::minimizers_preparation
+// (minimizers.rs:53-113, the branch with counts) do, ending in the list of 2-bit codes mdbg_set_lmer_filter takes (both orientations).
+namespace {
+const u64 NTH_A = 0x3c8bfbb395c60474ull, NTH_C = 0x3193c18562a02b4cull, NTH_G = 0x20323ed082572324ull, NTH_T = 0x295549f54be24456ull;
+inline u64 rol64h(u64 x, unsigned r) { r &= 63; return r ? (x << r) | (x >> (64 - r)) : x; }
+inline u64 nth_seed(char c) { return c == 'A' ? NTH_A : c == 'C' ? NTH_C : c == 'G' ? NTH_G : c == 'T' ? NTH_T : 0; }
+// canonical ntHash of s[0..l) over ACGT: min(XOR_i rol(h(s_i), l-1-i), XOR_i rol(h(comp s_i), i))
+u64 ntc64_acgt(const std::string& s, u32 l) {
+    u64 f = 0, r = 0;
+    for (u32 i = 0; i < l; ++i) {
+        const char c = s[i], cc = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+        f ^= rol64h(nth_seed(c), l - 1 - i); r ^= rol64h(nth_seed(cc), i);
+    }
+    return f < r ? f : r;
+}
+std::string revcomp_str(const std::string& s) { std::string o(s.rbegin(), s.rend()); for (char& c : o) c = switch_base(c); return o; }
+}  // namespace
+
+int mdbg_lmer_filter_from_counts(const char* path, uint32_t l, double density, uint32_t count_min, uint32_t count_max,
+                                 uint64_t** codes, uint64_t* n_codes, uint64_t* n_ignored) {
+    if (!path || !codes || !n_codes || l < 1 || l > 32) return MDBG_E_PARAM;
+    *codes = nullptr; *n_codes = 0; if (n_ignored) *n_ignored = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return MDBG_E_IO;
+    std::unordered_map<std::string, u32> counts;                           // main.rs:544
+    u64 ignored = 0;
+    std::string line; char buf[1 << 16]; bool bad = false;
+    auto take = [&](const std::string& ln) {
+        size_t a = 0; while (a < ln.size() && isspace((unsigned char)ln[a])) ++a;
+        if (a == ln.size()) { if (!ln.empty()) bad = true; return; }       // a blank line: vec[0] panics in the reference
+        size_t b = a; while (b < ln.size() && !isspace((unsigned char)ln[b])) ++b;
+        size_t c0 = b; while (c0 < ln.size() && isspace((unsigned char)ln[c0])) ++c0;
+        size_t c1 = c0; while (c1 < ln.size() && !isspace((unsigned char)ln[c1])) ++c1;
+        if (c0 == c1) { bad = true; return; }
+        char* end = nullptr; errno = 0;
+        const std::string num = ln.substr(c0, c1 - c0);
+        const unsigned long long v = strtoull(num.c_str(), &end, 10);
+        if (errno || *end || num[0] == '-' || v > 0xFFFFFFFFull) { bad = true; return; }       // parse::<u32>().unwrap()
+        std::string lmer = ln.substr(a, b - a);
+        const std::string rc = revcomp_str(lmer);
+        counts[lmer < rc ? lmer : rc] = (u32)v;                            // main.rs:560-564
+    };
+    while (fgets(buf, sizeof buf, f)) {
+        line += buf;
+        if (!line.empty() && line.back() == '\n') { take(line); line.clear(); }
+    }
+    if (!line.empty()) take(line);
+    const bool rerr = ferror(f) != 0;
+    fclose(f);
+    if (rerr) return MDBG_E_IO;
+    if (bad) return MDBG_E_PARAM;
+    std::vector<u64> out;
+    for (const auto& kv : counts) {
+        const std::string& lmer = kv.first;
+        bool acgt = lmer.size() == l;                                      // another length can never equal a read's l-mer (read.rs:198, 202)
+        for (size_t i = 0; acgt && i < lmer.size(); ++i) acgt = lmer[i] == 'A' || lmer[i] == 'C' || lmer[i] == 'G' || lmer[i] == 'T';
+        if (!acgt) { ++ignored; continue; }                                // not representable as a 2-bit code; no k-mer counter lists such l-mers
+        const bool skip = kv.second >= count_max || kv.second <= count_min;          // minimizers.rs:80
+        double hn = (double)ntc64_acgt(lmer, l) / 18446744073709551616.0;             // :88-90 (u64::MAX as f64 == 2^64)
+        if (skip) hn = 1.0;                                                // :91-95
+        if (!(hn <= density)) continue;                                    // :96
+        const std::string rc = revcomp_str(lmer);
+        for (const std::string* w : {&lmer, &rc}) {                        // :99-105: the l-mer and its reverse complement
+            u64 code = 0;
+            for (char ch : *w) code = (code << 2) | (u64)(((unsigned char)ch >> 1) & 3);
+            out.push_back(code);
+        }
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());             // a palindromic l-mer is its own reverse complement
+    u64* mem = (u64*)malloc((out.size() + 1) * sizeof(u64));
+    if (!mem) return MDBG_E_NOMEM;
+    memcpy(mem, out.data(), out.size() * sizeof(u64));
+    *codes = mem; *n_codes = out.size(); if (n_ignored) *n_ignored = ignored;
+    return MDBG_OK;
+}
+void mdbg_lmer_filter_free(uint64_t* codes) { free(codes); }
+
 }  // extern "C"

@@ -898,6 +898,73 @@ void launch_gather(u32 tile0, u32 n, const Rec* slab, u32 slab_cap, const u32* n
     hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tile0, n, slab, slab_cap, n_valid, tile_base, out_hash, out_pos, out_read, out_cap);
 }
 
+// ---- --lmer-counts (src/read.rs:200-205, src/minimizers.rs:53-113): keep a selected minimizer only if its l-mer is in a given set ---------
+// The set is the reference's minimizer_to_int restricted to l-mers over ACGT (a read's l-mer with any other byte is in no counts file of a
+// k-mer counter), both orientations listed, as 2-bit codes: first base in the highest of the 2l bits, base code (ascii >> 1) & 3.  It lives
+// in an open-addressing table (LMERSET_EMPTY = free; the all-ones code, "G" x 32, is kept apart).  The filter runs on the (few) minimizers
+// that passed the density threshold: it re-reads the l-mer of each from the batch's bases (its HPC walk forward from the recorded raw
+// position), looks the code up, and compacts the survivors through the tile slabs + gather that the sketch uses.
+constexpr u64 LMERSET_EMPTY = ~0ull;
+struct LmerFilterArgs {
+    const u64* set; u64 set_mask; u32 has_all_ones;
+    const u64* mh; const u32* mpos; const u32* mread; u64 m0, m1;      // the batch's minimizers in the resident store
+    const u64* offsets; u32 slot0; u32 l; u32 hpc;
+    Rec* slab; u32* n_valid;                                           // [n_blocks][256], [n_blocks]
+};
+__host__ __device__ inline u64 lmerset_home(u64 code, u64 mask) { return fmix64(code) & mask; }
+template <bool HPC, class Src>
+__device__ inline bool lmer_code_at(const Src& s, u64 rlo, u64 rhi, u64 p, u32 l, u64& code) {
+    u64 q = p, c64 = 0;
+    for (u32 j = 0; j < l; ++j) {
+        if (q >= rhi) return false;
+        const u8 c = s.at(q);
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false;
+        c64 = (c64 << 2) | (u64)((c >> 1) & 3);
+        ++q;
+        if (HPC) while (q < rhi && s.at(q) == c) ++q;                  // c is in the HPC set: the rest of its run is dropped (read.rs:163-167)
+    }
+    code = c64;
+    return true;
+}
+template <bool HPC, class Src>
+__global__ __launch_bounds__(256) void lmer_filter_kernel(LmerFilterArgs a, Src src) {
+    __shared__ u32 tmp[8];
+    const u64 i = a.m0 + (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 keep = 0; Rec rec{};
+    if (i < a.m1) {
+        rec.hash = a.mh[i]; rec.pos = a.mpos[i]; rec.read = a.mread[i];
+        const u32 r = rec.read - a.slot0;
+        const u64 rlo = a.offsets[r], rhi = a.offsets[r + 1];
+        u64 code;
+        if (lmer_code_at<HPC>(src, rlo, rhi, rlo + rec.pos, a.l, code)) {
+            if (code == LMERSET_EMPTY) keep = a.has_all_ones;
+            else for (u64 h = lmerset_home(code, a.set_mask);; h = (h + 1) & a.set_mask) {
+                const u64 v = a.set[h];
+                if (v == code) { keep = 1; break; }
+                if (v == LMERSET_EMPTY) break;
+            }
+        }
+    }
+    u32 total;
+    const u32 rank = block_excl_scan_256(keep, tmp, total);
+    if (keep) a.slab[(size_t)blockIdx.x * 256 + rank] = rec;
+    if (threadIdx.x == 0) a.n_valid[blockIdx.x] = total;
+}
+u32 lmer_filter_blocks(u64 n_minimizers) { return (u32)((n_minimizers + 255) / 256); }
+void launch_lmer_filter(const LmerFilterArgs& a, u32 fmt, const u8* bases, const uint2* planes, const u64* exc_pos, const u8* exc_val, u32 n_exc, hipStream_t s) {
+    const u32 nb = lmer_filter_blocks(a.m1 - a.m0);
+    if (!nb) return;
+    if (fmt == FMT_ASCII) {
+        const AsciiSrc src{bases};
+        if (a.hpc) hipLaunchKernelGGL((lmer_filter_kernel<true, AsciiSrc>), dim3(nb), dim3(256), 0, s, a, src);
+        else hipLaunchKernelGGL((lmer_filter_kernel<false, AsciiSrc>), dim3(nb), dim3(256), 0, s, a, src);
+    } else {
+        const PlaneSrc src{planes, exc_pos, exc_val, n_exc};
+        if (a.hpc) hipLaunchKernelGGL((lmer_filter_kernel<true, PlaneSrc>), dim3(nb), dim3(256), 0, s, a, src);
+        else hipLaunchKernelGGL((lmer_filter_kernel<false, PlaneSrc>), dim3(nb), dim3(256), 0, s, a, src);
+    }
+}
+
 u64 make_hash_bound(double density) {
     const double v = density * 18446744073709551616.0;
     return !(v > 0.0) ? 0 : (v >= 18446744073709551616.0 ? ~0ull : (u64)v);

@@ -14,7 +14,7 @@ _LIB = None
 from .api import EdgeList as Edges          # one type for the host emitter's and the GPU's edge list (include/mdbg_hip.h)
 
 
-EXPORTS = ["mdbg_packed_words", "mdbg_pack_reads", "mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
+EXPORTS = ["mdbg_lmer_filter_from_counts", "mdbg_lmer_filter_free", "mdbg_packed_words", "mdbg_pack_reads", "mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
            "mdbg_seqfile_write_batch", "mdbg_seqfile_close"]
 
 
@@ -37,6 +37,10 @@ def load_library():
         L.mdbg_packed_words.restype = C.c_uint64
         L.mdbg_packed_words.argtypes = [C.c_uint64]
         L.mdbg_pack_reads.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
+        L.mdbg_lmer_filter_from_counts.argtypes = [C.c_char_p, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_uint64)),
+                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mdbg_lmer_filter_free.argtypes = [vp]
+        L.mdbg_lmer_filter_free.restype = None
         _LIB = L
     return _LIB
 
@@ -180,3 +184,18 @@ def pack_reads(bases, offsets, threads=1, exc_cap=None):
         cap = int(ne.value)
     k = int(ne.value)
     return dict(words=words, offsets=offsets, exc_pos=np.ascontiguousarray(ep[:k]), exc_val=np.ascontiguousarray(ev[:k]), n_bases=n)
+
+
+def lmer_filter_from_counts(path, l, density, count_min=2, count_max=100000):
+    """--lmer-counts FILE (src/main.rs:544-575, src/minimizers.rs:53-113) -> (uint64 codes of the selected l-mers, both orientations, for
+    Mdbg.set_lmer_filter; number of lines that cannot match any read l-mer)"""
+    L = load_library()
+    p, n, ign = C.POINTER(C.c_uint64)(), C.c_uint64(), C.c_uint64()
+    rc = L.mdbg_lmer_filter_from_counts(os.fsencode(path), l, density, count_min, count_max, C.byref(p), C.byref(n), C.byref(ign))
+    if rc:
+        raise RuntimeError("mdbg_lmer_filter_from_counts failed: %d" % rc)
+    try:
+        codes = np.ctypeslib.as_array(p, shape=(int(n.value),)).astype(np.uint64, copy=True) if n.value else np.zeros(0, dtype=np.uint64)
+    finally:
+        L.mdbg_lmer_filter_free(p)
+    return codes, int(ign.value)

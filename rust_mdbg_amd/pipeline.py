@@ -7,11 +7,19 @@ import queue
 import threading
 
 from .api import Mdbg
-from .emit import Emitter, Reader
+from .emit import Emitter, Reader, lmer_filter_from_counts
+
+
+def apply_lmer_counts(m, lmer_counts, l, density, lmer_counts_min, lmer_counts_max):
+    """--lmer-counts FILE [--lmer_counts_min A --lmer_counts_max B] (src/main.rs:392-409, 499-503): restrict the sketch of context m"""
+    if lmer_counts is None:
+        return
+    codes, _ = lmer_filter_from_counts(lmer_counts, l, density, lmer_counts_min, lmer_counts_max)
+    m.set_lmer_filter(codes)
 
 
 def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=False, presimp=0.01, batch_bases=256 << 20,
-             strip_newlines=False, device=-1, write_sequences=True):
+             strip_newlines=False, device=-1, write_sequences=True, lmer_counts=None, lmer_counts_min=2, lmer_counts_max=100000):
     """-> dict of counters (what the reference prints: reads, nodes before/after filter, edges, presimp removals)"""
     q = queue.Queue(maxsize=2)
     stop = threading.Event()               # set when the consumer gives up: the reader must not stay blocked in put()
@@ -40,6 +48,7 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
     n_reads = n_bases = 0
     try:
         with Mdbg(k, l, density, min_abundance, reads_already_hpc=reads_already_hpc, device=device) as m:
+            apply_lmer_counts(m, lmer_counts, l, density, lmer_counts_min, lmer_counts_max)
             while True:
                 item = q.get()
                 if item is None:
@@ -87,7 +96,7 @@ def concat_records(seqs):
 
 
 def run_multik(path, prefix, ks, l, density, min_abundance=2, reads_already_hpc=False, presimp=0.01, batch_bases=256 << 20,
-               strip_newlines=False, device=-1, contigs_fn=None, min_contig_len=100000):
+               strip_newlines=False, device=-1, contigs_fn=None, min_contig_len=100000, lmer_counts=None, lmer_counts_min=2, lmer_counts_max=100000):
     """One pass over the reads, one graph per k (the k sweep of the reference's utils/multik:69-78): the reads are sketched once,
     the sketches stay resident on the GPU, and every k only clears and refills the counting table (mdbg_reset) and rebuilds nodes
     and edges.  Writes <prefix>-k<k>.gfa; -> {k: counters}.
@@ -102,6 +111,7 @@ def run_multik(path, prefix, ks, l, density, min_abundance=2, reads_already_hpc=
     n_reads = n_bases = 0
     base = READ_ORDINAL_BASE if contigs_fn is not None else 0
     with Mdbg(ks[0], l, density, min_abundance, reads_already_hpc=reads_already_hpc, device=device) as m, Reader(path, strip_newlines) as r:
+        apply_lmer_counts(m, lmer_counts, l, density, lmer_counts_min, lmer_counts_max)
         for bases, offs in r.batches(batch_bases):
             m.ingest(bases, offs, base + n_reads)
             n_reads += len(offs) - 1

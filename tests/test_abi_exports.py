@@ -28,7 +28,7 @@ def test_emit_library_exports_every_declared_symbol():
     from rust_mdbg_amd import emit
     h = open(os.path.join(ROOT, "include", "mdbg_emit.h")).read()
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
-    syms = sorted(set(re.findall(r"\b(mdbg_(?:emit|seqfile|reader|pack|packed)_[a-z_0-9]+)\s*\(", h)))
+    syms = sorted(set(re.findall(r"\b(mdbg_(?:emit|seqfile|reader|pack|packed|lmer)_[a-z_0-9]+)\s*\(", h)))
     L = emit.load_library()
     assert syms == sorted(emit.EXPORTS + emit.READER_EXPORTS)
     for s in syms:

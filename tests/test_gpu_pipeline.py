@@ -137,3 +137,30 @@ def test_multik_with_contig_feedback(tmp_path):
         assert sorted(x for x in lines if x.startswith("L")) == sorted("L\t%d\t%s\t%d\t%s\t%dM" % (x, chr(p), y, chr(q), ov) for x, p, y, q, ov in oracle_edges(r))
         prev = given[k]
     assert out[15]["n_nodes"] != out[10]["n_nodes"]
+
+
+def test_file_pipeline_with_lmer_counts(example_reads, tmp_path):
+    """--lmer-counts through the file pipeline: counts file -> selection -> filtered sketch -> graph, against the oracle"""
+    import collections
+    from rust_mdbg_amd import pipeline
+    k, l, d, a = 7, 10, 0.0008 * 8, 2
+    cnt = collections.Counter()
+    for r in example_reads[:60]:
+        text = O.encode_rle(r)[0]
+        for i in range(len(text) - l + 1):
+            cnt[bytes(text[i:i + l])] += 1
+    lines = [(w, c) for w, c in cnt.items() if b"N" not in w]
+    p = str(tmp_path / "counts.txt")
+    with open(p, "w") as f:
+        for w, c in lines:
+            f.write("%s %d\n" % (w.decode(), c))
+    out = pipeline.run_file(os.path.join(GOLDEN, "reads-0.00.fa.gz"), str(tmp_path / "lc"), k, l, d, a, batch_bases=5_000_000,
+                            lmer_counts=p, lmer_counts_min=1, lmer_counts_max=50, write_sequences=False)
+    om = O.LmerMap(lines, l, d, 1, 50)
+    b, o = O.concat_reads(example_reads)
+    g = O.Graph(k, l, d, a, lmer_map=om)
+    g.ingest(b, o)
+    r = g.finalize(with_edges=True)
+    assert (out["n_minimizers"], out["n_nodes_before"], out["n_nodes"], out["n_edges"]) == (r["n_minimizers"], r["n_nodes_before"], r["n_nodes"], r["n_edges"])
+    plain = O.sketch(b, o, l, d)
+    assert 0 < out["n_minimizers"] < len(plain["hashes"])
