@@ -432,6 +432,7 @@ __global__ void rehash_kernel(const Slot* __restrict__ old, u64 old_cap, const u
 struct BatchTab {                 // batches sorted by first_ordinal (device copy)
     const u64* first_ordinal; const u32* n_reads; const u32* slot0; const u64* rank_base; u32 n;
     const u32* by_slot0; const u64* by_slot_first;   // the same batches sorted by slot0 (= call order): slot -> read ordinal
+    const u64* by_m0; const u64* by_m0_rank;         // the batches sorted by position in the store: first minimizer index and its dense rank
 };
 struct FinArgs {
     const Slot* tab; u64 cap; const u64* mx; u32 A; u32 casc; u32 k; u32 l;   // A: abundance filter; casc: ordinals tracked per slot (= A up to 8, else 1)
@@ -457,6 +458,13 @@ __device__ inline void decode_ordinal(const FinArgs& F, u64 ord, u64& i, u64& D)
     const u32 slot = s0 + (u32)(ro - F.bt.first_ordinal[lo]);
     i = F.roff[slot] + win;
     D = F.bt.rank_base[lo] + (i - F.roff[s0]);
+}
+// Dense ordered index of the minimizer at store index i (the window starting there): batches keep their order inside the store, so
+// this needs neither the read map nor the read offsets.  Dense indices are ordered like the ordinals they stand for.
+__device__ inline u64 dense_of_index(const FinArgs& F, u64 i) {
+    u32 lo = 0, hi = F.bt.n - 1;
+    while (lo < hi) { const u32 mid = lo + ((hi - lo + 1) >> 1); if (F.bt.by_m0[mid] <= i) lo = mid; else hi = mid - 1; }
+    return F.bt.by_m0_rank[lo] + (i - F.bt.by_m0[lo]);
 }
 // ordinal of the occurrence that claimed the slot (it did no count / ordinal atomics)
 __device__ inline u64 rep_ordinal(const FinArgs& F, u64 word) {
@@ -495,9 +503,16 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
     if (s < F.cap) {
         const Slot e = F.tab[s];
         if (e.word != EMPTY) {
-            const SlotView v = slot_view(e, s, F.mx, F.casc, F.A, rep_ordinal(F, e.word));
-            occ = true; solid = v.solid; wrapped = v.count >= 65536u;
-            u64 i, D; decode_ordinal(F, v.first, i, D);
+            const u32 count = e.count + 1u;
+            occ = true; solid = F.A == 1 || (u16)count >= (u16)F.A; wrapped = count >= 65536u;          // as slot_view
+            // first sighting: the claimer's window or the smallest ordinal the others pushed.  Most keys are seen once (sequencing
+            // errors), and the claimer's dense index follows from `rep` alone: no read map / offset lookups for them
+            u64 D;
+            if (e.word & (1ull << 33)) { u64 i; decode_ordinal(F, rep_ordinal(F, e.word) < e.m1 ? rep_ordinal(F, e.word) : e.m1, i, D); }   // routed record
+            else {
+                D = dense_of_index(F, (u32)e.word);
+                if (e.count) { u64 i, D1; decode_ordinal(F, e.m1, i, D1); if (D1 < D) D = D1; }
+            }
             atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
             if (solid) atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
         }
