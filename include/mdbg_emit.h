@@ -52,6 +52,15 @@ mdbg_reader* mdbg_reader_open(const char* path, int strip_newlines, int* err);
  * until the next call on it. */
 int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, const uint64_t** offsets, uint64_t* n_reads);
 int mdbg_reader_is_fasta(const mdbg_reader* r);
+/* The same reader with `threads` parser threads for UNCOMPRESSED files (seq_io's parallel readers, src/main.rs:830-839, parse records on
+ * one thread and only run the per-read work in parallel): the file is mapped, every batch is a window of about max_bases file bytes
+ * (2 * max_bases for FASTQ) cut at record starts and parsed piecewise by the same record code, so batches hold the same records in the
+ * same order with the same bytes as mdbg_reader_open's, only cut at other places (never more than max_bases bases unless a window's last
+ * record is longer).  FASTQ is taken as four-line records (as the streaming reader does).  .gz / .lz4 input and threads <= 1 fall back to
+ * the streaming reader.  When the file is read in parallel, mdbg_reader_next alternates two buffers: a batch stays valid until the call
+ * AFTER the next one, so that another thread can pack / copy batch i while batch i+1 is being parsed. */
+mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err);
+int mdbg_reader_is_parallel(const mdbg_reader* r);      /* 1: the file is mapped and parsed by several threads (two alternating batch buffers) */
 void mdbg_reader_close(mdbg_reader* r);
 
 /* ---- host packer for mdbg_ingest_batch_packed (layout: mdbg_packed_batch in mdbg_hip.h) -----------------------------

@@ -14,6 +14,11 @@
 #include <unordered_set>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "../../include/mdbg_emit.h"
@@ -147,13 +152,33 @@ int mdbg_emit_edges(mdbg_emit* E, const mdbg_nodes* nd, float presimp, mdbg_edge
     return MDBG_OK;
 }
 
+// decimal digits of v appended at p -> new end (the graph files are millions of short lines: fprintf's format parsing is most of their cost)
+static inline char* put_u32(char* p, u32 v) {
+    char t[10]; int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+}
 int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nd, const mdbg_edges* ed) {
     if (!path || !nd) return MDBG_E_PARAM;
     FILE* f = fopen(path, "wb");
     if (!f) return MDBG_E_IO;
-    bool ok = fprintf(f, "H\tVN:Z:1.0\n") > 0;                                                     // main.rs:1011
-    for (u64 i = 0; ok && i < nd->n; ++i) ok = fprintf(f, "S\t%u\t*\tLN:i:%u\tKC:i:%u\n", nd->index[i], nd->seqlen[i], (unsigned)nd->abundance[i]) > 0;   // :1021
-    if (ed) for (u64 i = 0; ok && i < ed->n; ++i) ok = fprintf(f, "L\t%u\t%c\t%u\t%c\t%uM\n", ed->n1[i], ed->o1[i], ed->n2[i], ed->o2[i], ed->overlap[i]) > 0;   // :1095
+    std::vector<char> buf((1u << 20) + 256);
+    char* p = buf.data(); char* const lim = buf.data() + (1u << 20);
+    bool ok = true;
+    auto flush = [&]() { if (p != buf.data()) { ok = ok && fwrite(buf.data(), 1, (size_t)(p - buf.data()), f) == (size_t)(p - buf.data()); p = buf.data(); } };
+    auto lit = [&](const char* s) { while (*s) *p++ = *s++; };
+    lit("H\tVN:Z:1.0\n");                                                                          // main.rs:1011
+    for (u64 i = 0; ok && i < nd->n; ++i) {                                                         // :1021  S\t{index}\t*\tLN:i:{seqlen}\tKC:i:{abundance}
+        lit("S\t"); p = put_u32(p, nd->index[i]); lit("\t*\tLN:i:"); p = put_u32(p, nd->seqlen[i]); lit("\tKC:i:"); p = put_u32(p, (u32)nd->abundance[i]); *p++ = '\n';
+        if (p >= lim) flush();
+    }
+    if (ed) for (u64 i = 0; ok && i < ed->n; ++i) {                                                 // :1095  L\t{n1}\t{o1}\t{n2}\t{o2}\t{overlap}M
+        lit("L\t"); p = put_u32(p, ed->n1[i]); *p++ = '\t'; *p++ = (char)ed->o1[i]; *p++ = '\t'; p = put_u32(p, ed->n2[i]); *p++ = '\t'; *p++ = (char)ed->o2[i]; *p++ = '\t';
+        p = put_u32(p, ed->overlap[i]); *p++ = 'M'; *p++ = '\n';
+        if (p >= lim) flush();
+    }
+    flush();
     ok = ok && !ferror(f);                     // a short write (disk full) must not pass for a complete graph
     ok = (fclose(f) == 0) && ok;
     return ok ? MDBG_OK : MDBG_E_IO;
@@ -299,10 +324,18 @@ struct Lz4In {
 struct mdbg_reader {
     gzFile f = nullptr; Lz4In* lz = nullptr; bool fasta = false, strip = false, eof = false, io_error = false;
     std::vector<u8> buf; size_t pos = 0, len = 0;            // input window
+    const u8* mem = nullptr;                                  // memory mode (a piece of a mapped file): the window is [mem, mem + len), never refilled
+    const u8* data() const { return mem ? mem : buf.data(); }
+    // whole-file mapping of an uncompressed input read by several threads (mdbg_reader_open_mt); cur = first unread byte
+    const u8* map = nullptr; size_t map_size = 0, map_cur = 0; int threads = 1;
+    u8* big = nullptr; size_t big_cap = 0;                    // batch buffer of the parallel path (not zero-filled like a vector)
+    u8* big2 = nullptr; size_t big2_cap = 0; std::vector<u64> offs2;      // ... the previous batch: the parallel path alternates two buffers, so a
+                                                              // batch stays valid while the next one is being read (a packer thread can work on it)
+    std::vector<std::vector<u8>> piece_bases; std::vector<std::vector<u64>> piece_lens;      // per-thread parse buffers, kept across batches (no fresh page faults)
     std::vector<u8> bases; std::vector<u64> offs;            // current batch
     std::vector<u8> pending; bool have_pending = false;      // a parsed record that did not fit the previous batch
     bool fill() {                                             // more input; false at EOF
-        if (eof) return false;
+        if (eof || mem) return false;
         if (pos > 0) { memmove(buf.data(), buf.data() + pos, len - pos); len -= pos; pos = 0; }
         if (buf.size() - len < (1u << 20)) buf.resize(buf.size() * 2);
         const size_t want = std::min<size_t>(buf.size() - len, 1u << 30);
@@ -315,8 +348,8 @@ struct mdbg_reader {
     // next line [start, end) without its terminator; false at EOF with nothing left
     bool line(size_t& s, size_t& e, bool& had_nl) {
         for (size_t scan = pos;;) {
-            const u8* nl = (const u8*)memchr(buf.data() + scan, '\n', len - scan);
-            if (nl) { s = pos; e = (size_t)(nl - buf.data()); pos = e + 1; had_nl = true; return true; }
+            const u8* nl = (const u8*)memchr(data() + scan, '\n', len - scan);
+            if (nl) { s = pos; e = (size_t)(nl - data()); pos = e + 1; had_nl = true; return true; }
             scan = len;
             const size_t before = pos;
             if (!fill()) { if (pos == len) return false; s = pos; e = len; pos = len; had_nl = false; return true; }
@@ -324,30 +357,32 @@ struct mdbg_reader {
         }
     }
     // parses one record's sequence into `out`; false at EOF
-    bool record(std::vector<u8>& out) {
-        out.clear();
+    bool record(std::vector<u8>& out) { out.clear(); return record_append(out); }
+    // ... appended to `out`
+    bool record_append(std::vector<u8>& out) {
+        const size_t o0 = out.size();
         size_t s, e; bool nl;
         if (fasta) {
-            do { if (!line(s, e, nl)) return false; } while (e == s || buf[s] != '>');      // header line
+            do { if (!line(s, e, nl)) return false; } while (e == s || data()[s] != '>');   // header line
             // seq_io 0.3 RefRecord::seq(): everything between the header's line end and the record's last line end, interior
             // line terminators included, one trailing '\r' trimmed
             bool first = true;
             for (;;) {
                 if (pos == len && !fill()) break;
-                if (pos < len && buf[pos] == '>') break;
+                if (pos < len && data()[pos] == '>') break;
                 if (!line(s, e, nl)) break;
                 if (!first) out.push_back('\n');
-                out.insert(out.end(), buf.begin() + s, buf.begin() + e);
+                out.insert(out.end(), data() + s, data() + e);
                 first = false;
             }
-            if (strip) { size_t w = 0; for (u8 ch : out) if (ch != '\n' && ch != '\r') out[w++] = ch; out.resize(w); }   // --reference, main.rs:737
-            else if (!out.empty() && out.back() == '\r') out.pop_back();
+            if (strip) { size_t w = o0; for (size_t i = o0; i < out.size(); ++i) { const u8 ch = out[i]; if (ch != '\n' && ch != '\r') out[w++] = ch; } out.resize(w); }   // --reference, main.rs:737
+            else if (out.size() > o0 && out.back() == '\r') out.pop_back();
             return true;
         }
         do { if (!line(s, e, nl)) return false; } while (e == s);                            // '@' header
         if (!line(s, e, nl)) return false;                                                   // sequence
-        size_t ee = e; if (ee > s && buf[ee - 1] == '\r') --ee;
-        out.assign(buf.begin() + s, buf.begin() + ee);
+        size_t ee = e; if (ee > s && data()[ee - 1] == '\r') --ee;
+        out.insert(out.end(), data() + s, data() + ee);
         if (!line(s, e, nl)) return true;                                                    // '+'
         line(s, e, nl);                                                                      // qualities
         return true;
@@ -380,10 +415,120 @@ mdbg_reader* mdbg_reader_open(const char* path, int strip_newlines, int* err) {
     return r;
 }
 
+// ---- parallel reader for uncompressed files: the file is mapped, a batch is a window of it cut at record starts, split into one piece
+// per thread (again at record starts); every piece is parsed by the SAME record() code as the streaming reader (memory mode), the pieces'
+// sequences are then copied side by side.  gzip / LZ4 input cannot be split this way: mdbg_reader_open_mt falls back to the streaming reader.
+namespace {
+size_t line_start_after(const u8* m, size_t n, size_t p) {                 // first line start >= p
+    if (p == 0 || p >= n) return p >= n ? n : 0;
+    if (m[p - 1] == '\n') return p;
+    const u8* nl = (const u8*)memchr(m + p, '\n', n - p);
+    return nl ? (size_t)(nl - m) + 1 : n;
+}
+size_t line_end(const u8* m, size_t n, size_t p) { const u8* nl = p < n ? (const u8*)memchr(m + p, '\n', n - p) : nullptr; return nl ? (size_t)(nl - m) : n; }
+// first record start >= p.  FASTA: a line that starts with '>'.  FASTQ (four-line records, as the streaming reader assumes): a line that
+// starts with '@' whose third line starts with '+' and whose second and fourth lines have the same length — a quality line that happens
+// to start with '@' fails both tests.
+size_t next_record_start(const u8* m, size_t n, size_t p, bool fasta) {
+    size_t q = line_start_after(m, n, p);
+    while (q < n) {
+        if (fasta) { if (m[q] == '>') return q; }
+        else if (m[q] == '@') {
+            const size_t e0 = line_end(m, n, q), s1 = e0 + 1, e1 = line_end(m, n, s1), s2 = e1 + 1;
+            if (s2 < n && m[s2] == '+') {
+                const size_t e2 = line_end(m, n, s2), s3 = e2 + 1, e3 = line_end(m, n, s3);
+                size_t l1 = e1 - s1, l3 = s3 <= n ? e3 - std::min(s3, n) : 0;
+                if (l1 && m[e1 - 1] == '\r') --l1;
+                if (l3 && e3 <= n && e3 > 0 && m[e3 - 1] == '\r') --l3;
+                if (l1 == l3) return q;
+            }
+        }
+        q = line_end(m, n, q) + 1;
+    }
+    return n;
+}
+}  // namespace
+
+static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases) {
+    r->offs.assign(1, 0);
+    const u8* m = r->map; const size_t n = r->map_size;
+    if (r->map_cur >= n) return MDBG_OK;
+    const size_t window = r->fasta ? (size_t)max_bases : 2 * (size_t)max_bases;      // file bytes: never more than max_bases bases unless one record is longer
+    size_t end = r->map_cur + std::max<size_t>(window, 1) >= n ? n : next_record_start(m, n, r->map_cur + std::max<size_t>(window, 1), r->fasta);
+    if (end <= r->map_cur) end = n;
+    const int T = std::max(1, r->threads);
+    std::vector<size_t> cut(T + 1);
+    cut[0] = r->map_cur; cut[T] = end;
+    for (int i = 1; i < T; ++i) {
+        const size_t guess = r->map_cur + (size_t)((double)(end - r->map_cur) * i / T);
+        cut[i] = std::min(end, std::max(cut[i - 1], next_record_start(m, end, guess, r->fasta)));
+    }
+    r->piece_bases.resize(T); r->piece_lens.resize(T);
+    struct PieceRef { std::vector<u8>& bases; std::vector<u64>& lens; };
+    std::vector<PieceRef> pc;
+    for (int i = 0; i < T; ++i) { r->piece_bases[i].clear(); r->piece_lens[i].clear(); pc.push_back(PieceRef{r->piece_bases[i], r->piece_lens[i]}); }
+    auto parse = [&](int i) {
+        if (cut[i + 1] <= cut[i]) return;
+        mdbg_reader t; t.mem = m + cut[i]; t.len = cut[i + 1] - cut[i]; t.eof = true; t.fasta = r->fasta; t.strip = r->strip;
+        pc[i].bases.reserve(t.len / (r->fasta ? 1 : 2) + 64);
+        for (size_t before = 0; t.record_append(pc[i].bases); before = pc[i].bases.size()) pc[i].lens.push_back(pc[i].bases.size() - before);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < T; ++i) th.emplace_back(parse, i);
+        parse(0);
+        for (auto& x : th) x.join();
+    }
+    size_t total = 0, reads = 0;
+    std::vector<size_t> base0(T), read0(T);
+    for (int i = 0; i < T; ++i) { base0[i] = total; read0[i] = reads; total += pc[i].bases.size(); reads += pc[i].lens.size(); }
+    if (total + 64 > r->big_cap) { free(r->big); r->big_cap = total + total / 8 + 4096; r->big = (u8*)malloc(r->big_cap); if (!r->big) { r->big_cap = 0; return MDBG_E_NOMEM; } }
+    r->offs.resize(reads + 1);
+    auto place = [&](int i) {
+        if (!pc[i].bases.empty()) memcpy(r->big + base0[i], pc[i].bases.data(), pc[i].bases.size());
+        u64 o = base0[i];
+        for (size_t j = 0; j < pc[i].lens.size(); ++j) { r->offs[read0[i] + j] = o; o += pc[i].lens[j]; }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < T; ++i) th.emplace_back(place, i);
+        place(0);
+        for (auto& x : th) x.join();
+    }
+    r->offs[reads] = total;
+    r->map_cur = end;
+    return MDBG_OK;
+}
+
 int mdbg_reader_is_fasta(const mdbg_reader* r) { return r && r->fasta ? 1 : 0; }
+int mdbg_reader_is_parallel(const mdbg_reader* r) { return r && r->map ? 1 : 0; }
+
+mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err) {
+    mdbg_reader* r = mdbg_reader_open(path, strip_newlines, err);
+    if (!r || threads <= 1 || r->lz) return r;
+    // plain file?  (gzip magic 1f 8b; ".lz4" was taken by name above)  Map it and let `threads` threads parse it.
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return r;
+    struct stat st;
+    u8 magic[2] = {0, 0};
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2 || pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) { close(fd); return r; }
+    void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (mp == MAP_FAILED) return r;
+    (void)madvise(mp, (size_t)st.st_size, MADV_SEQUENTIAL);
+    r->map = (const u8*)mp; r->map_size = (size_t)st.st_size; r->map_cur = 0; r->threads = threads;
+    return r;
+}
 
 int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, const uint64_t** offsets, uint64_t* n_reads) {
     if (!r || !bases || !offsets || !n_reads) return MDBG_E_PARAM;
+    if (r->map) {
+        int e;
+        std::swap(r->big, r->big2); std::swap(r->big_cap, r->big2_cap); r->offs.swap(r->offs2);       // the batch handed out last stays intact during this call
+        do e = reader_next_parallel(r, max_bases); while (!e && r->offs.size() == 1 && r->map_cur < r->map_size);      // a window without a record (text in front of the first header) is not the end
+        *bases = r->big; *offsets = r->offs.data(); *n_reads = r->offs.size() - 1;
+        return e;
+    }
     r->bases.clear(); r->offs.assign(1, 0);
     std::vector<u8> rec;
     for (;;) {
@@ -398,7 +543,7 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
     return r->io_error ? MDBG_E_PARAM : MDBG_OK;             // a malformed compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
+void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->map) munmap((void*)r->map, r->map_size); free(r->big); free(r->big2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
 
 }  // extern "C"
 

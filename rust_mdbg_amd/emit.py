@@ -119,29 +119,35 @@ class Emitter:
 
 
 # ---- host ingest (include/mdbg_emit.h: mdbg_reader_*) -----------------------------------------------------
-READER_EXPORTS = ["mdbg_reader_open", "mdbg_reader_next", "mdbg_reader_is_fasta", "mdbg_reader_close"]
+READER_EXPORTS = ["mdbg_reader_open", "mdbg_reader_open_mt", "mdbg_reader_next", "mdbg_reader_is_fasta", "mdbg_reader_is_parallel", "mdbg_reader_close"]
 
 
 class Reader:
     """FASTA/FASTQ(.gz) -> batches in the layout of Mdbg.ingest; format by file name like src/main.rs:461-467"""
 
-    def __init__(self, path, strip_newlines=False):
+    def __init__(self, path, strip_newlines=False, threads=1):
+        """threads > 1: uncompressed files are mapped and parsed by that many threads (mdbg_reader_open_mt)"""
         L = load_library()
         L.mdbg_reader_open.restype = C.c_void_p
         L.mdbg_reader_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+        L.mdbg_reader_open_mt.restype = C.c_void_p
+        L.mdbg_reader_open_mt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.mdbg_reader_next.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.mdbg_reader_is_fasta.argtypes = [C.c_void_p]
         L.mdbg_reader_close.argtypes = [C.c_void_p]
         L.mdbg_reader_close.restype = None
         self.L = L
         err = C.c_int()
-        self.h = L.mdbg_reader_open(path.encode(), int(strip_newlines), C.byref(err))
+        self.h = L.mdbg_reader_open_mt(path.encode(), int(strip_newlines), int(threads), C.byref(err))
         if not self.h:
             raise OSError("cannot open %s (err %d)" % (path, err.value))
         self.is_fasta = bool(L.mdbg_reader_is_fasta(self.h))
+        L.mdbg_reader_is_parallel.argtypes = [C.c_void_p]
+        self.parallel = bool(L.mdbg_reader_is_parallel(self.h))      # True: batches(copy=False) views stay valid while the NEXT batch is read
 
-    def batches(self, max_bases=256 << 20):
-        """yields (bases uint8[:], offsets uint64[n+1]) copies, whole records, <= max_bases each"""
+    def batches(self, max_bases=256 << 20, copy=True):
+        """yields (bases uint8[:], offsets uint64[n+1]), whole records, <= max_bases each; copy=False: views into the reader's buffers,
+        valid until the next batch is asked for"""
         while True:
             b, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
             rc = self.L.mdbg_reader_next(self.h, max_bases, C.byref(b), C.byref(o), C.byref(n))
@@ -149,10 +155,10 @@ class Reader:
                 raise RuntimeError("mdbg_reader_next failed: %d" % rc)
             if n.value == 0:
                 return
-            offs = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+            offs = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint64)), shape=(n.value + 1,))
             nb = int(offs[-1])
-            bases = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), shape=(max(nb, 1),))[:nb].copy()
-            yield bases, offs
+            bases = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), shape=(max(nb, 1),))[:nb] if b.value else np.zeros(0, np.uint8)
+            yield (bases.copy(), offs.copy()) if copy else (bases, offs)
 
     def close(self):
         if self.h:
@@ -166,13 +172,15 @@ class Reader:
         self.close()
 
 
-def pack_reads(bases, offsets, threads=1, exc_cap=None):
-    """ASCII batch -> mdbg_packed_batch arrays (host): dict(words, offsets, exc_pos, exc_val, n_bases)"""
+def pack_reads(bases, offsets, threads=1, exc_cap=None, words_buf=None):
+    """ASCII batch -> mdbg_packed_batch arrays (host): dict(words, offsets, exc_pos, exc_val, n_bases).  words_buf: a uint64 array to pack
+    into when it is large enough (a caller that packs batch after batch reuses it: fresh pages cost more than the packing itself)"""
     L = load_library()
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(bases)
-    words = np.zeros(int(L.mdbg_packed_words(n)), dtype=np.uint64)
+    nw = int(L.mdbg_packed_words(n))
+    words = words_buf[:nw] if words_buf is not None and len(words_buf) >= nw else np.empty(nw, dtype=np.uint64)      # the packer writes every word
     cap = 1024 if exc_cap is None else exc_cap
     while True:
         ep, ev, ne = np.zeros(cap, np.uint64), np.zeros(cap, np.uint8), C.c_uint64()

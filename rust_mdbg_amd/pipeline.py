@@ -7,7 +7,7 @@ import queue
 import threading
 
 from .api import Mdbg
-from .emit import Emitter, Reader, lmer_filter_from_counts
+from .emit import Emitter, Reader, lmer_filter_from_counts, pack_reads
 
 
 def apply_lmer_counts(m, lmer_counts, l, density, lmer_counts_min, lmer_counts_max):
@@ -19,8 +19,13 @@ def apply_lmer_counts(m, lmer_counts, l, density, lmer_counts_min, lmer_counts_m
 
 
 def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=False, presimp=0.01, batch_bases=256 << 20,
-             strip_newlines=False, device=-1, write_sequences=True, lmer_counts=None, lmer_counts_min=2, lmer_counts_max=100000):
-    """-> dict of counters (what the reference prints: reads, nodes before/after filter, edges, presimp removals)"""
+             strip_newlines=False, device=-1, write_sequences=True, lmer_counts=None, lmer_counts_min=2, lmer_counts_max=100000,
+             threads=1, packed=None):
+    """-> dict of counters (what the reference prints: reads, nodes before/after filter, edges, presimp removals).
+    threads: host threads of the reader (uncompressed input: mdbg_reader_open_mt) and of the 2-bit packer; packed: hand the GPU 2-bit
+    packed batches (a quarter of the bytes over PCIe), default: when threads > 1"""
+    if packed is None:
+        packed = threads > 1
     q = queue.Queue(maxsize=2)
     stop = threading.Event()               # set when the consumer gives up: the reader must not stay blocked in put()
 
@@ -35,10 +40,66 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
 
     def produce():
         try:
-            with Reader(path, strip_newlines) as r:
-                for item in r.batches(batch_bases):
-                    if not put(item):
-                        return
+            import numpy as np
+            ring = [np.empty(batch_bases // 32 + 64, dtype=np.uint64) for _ in range(4)] if packed else None      # queue depth 2 + one being filled + one being ingested
+            with Reader(path, strip_newlines, threads=threads) as r:
+                if packed and r.parallel:
+                    # three stages: the reader parses batch i+1 (it alternates two buffers) while this thread packs batch i and the
+                    # consumer ingests batch i-1
+                    q1 = queue.Queue(maxsize=1)
+                    free = threading.Semaphore(2)       # the reader may start call j once batch j-2 has been packed
+
+                    def read():
+                        try:
+                            it = r.batches(batch_bases, copy=False)
+                            while True:
+                                while not free.acquire(timeout=0.2):
+                                    if stop.is_set():
+                                        return
+                                item = next(it, None)
+                                while not stop.is_set():
+                                    try:
+                                        q1.put(item, timeout=0.2)
+                                        break
+                                    except queue.Full:
+                                        pass
+                                if item is None or stop.is_set():
+                                    return
+                        except BaseException as e:          # noqa: BLE001
+                            q1.put(e)
+
+                    rt = threading.Thread(target=read, daemon=True)
+                    rt.start()
+                    try:
+                        bi = 0
+                        while True:
+                            try:
+                                item = q1.get(timeout=0.2)
+                            except queue.Empty:
+                                if stop.is_set():
+                                    return
+                                continue
+                            if item is None:
+                                break
+                            if isinstance(item, BaseException):
+                                raise item
+                            bases, offs = item
+                            pk = pack_reads(bases, offs.copy(), threads=threads, words_buf=ring[bi % 4])
+                            nb = len(bases)
+                            free.release()
+                            bi += 1
+                            if not put((pk, None, nb)):
+                                return
+                    finally:
+                        stop_reader = stop.is_set()
+                        if stop_reader:
+                            free.release()
+                        rt.join(timeout=5)
+                else:
+                    for bi, (bases, offs) in enumerate(r.batches(batch_bases, copy=not packed)):       # packed: the batch is consumed here, before the next one is read
+                        item = (pack_reads(bases, offs.copy(), threads=threads, words_buf=ring[bi % 4]), None, len(bases)) if packed else (bases, offs, len(bases))
+                        if not put(item):
+                            return
             put(None)
         except BaseException as e:          # noqa: BLE001
             put(e)
@@ -46,27 +107,38 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
     th = threading.Thread(target=produce, daemon=True)
     th.start()
     n_reads = n_bases = 0
+    import time
+    tm = {}
+    t0 = time.perf_counter()
     try:
         with Mdbg(k, l, density, min_abundance, reads_already_hpc=reads_already_hpc, device=device) as m:
             apply_lmer_counts(m, lmer_counts, l, density, lmer_counts_min, lmer_counts_max)
+            tm["open"] = time.perf_counter() - t0
             while True:
                 item = q.get()
                 if item is None:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                bases, offs = item
-                m.ingest(bases, offs, n_reads)          # ctypes releases the GIL: the reader thread parses the next batch meanwhile
-                n_reads += len(offs) - 1
-                n_bases += len(bases)
+                payload, offs, nb = item
+                if packed:
+                    m.ingest_packed(payload, n_reads)
+                else:
+                    m.ingest(payload, offs, n_reads)    # ctypes releases the GIL: the reader thread parses the next batch meanwhile
+                n_reads += (len(payload["offsets"]) if packed else len(offs)) - 1
+                n_bases += nb
+            tm["ingest"] = time.perf_counter() - t0
             nodes = m.finalize()
             stats = m.stats()
+            tm["finalize"] = time.perf_counter() - t0
             # edges on the GPU from the device-resident node table (the reference's single-threaded loop, src/main.rs:1017-1117);
             # the host copy of the list goes straight into the GFA writer
             raw = m.graph_edges(presimp, raw=True)
             edges = dict(n1=[0] * int(raw.n), presimp_removed=int(raw.presimp_removed))
+            tm["edges"] = time.perf_counter() - t0
             em = Emitter()
             em.write_gfa(prefix + ".gfa", nodes, raw)
+            tm["gfa"] = time.perf_counter() - t0
     finally:
         stop.set()                          # error or not: release the reader (it closes the file) and wait for it
         th.join()
@@ -80,7 +152,7 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
         em.write_sequences(prefix + ".0.sequences", nodes, l, again())
     return dict(n_reads=n_reads, n_bases=n_bases, n_minimizers=stats["n_minimizers"], n_windows=stats["n_windows"],
                 n_nodes_before=nodes["n_nodes_before"], n_nodes=nodes["n_nodes"], n_edges=len(edges["n1"]),
-                presimp_removed=edges["presimp_removed"])
+                presimp_removed=edges["presimp_removed"], seconds_until={k_: round(v, 4) for k_, v in tm.items()})
 
 
 READ_ORDINAL_BASE = 1 << 32     # contig feedback: the reads' ordinals start here, the contigs of a round take [0, 2 * n_contigs)

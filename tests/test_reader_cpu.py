@@ -9,9 +9,9 @@ from conftest import GOLDEN
 from rust_mdbg_amd import emit as E
 
 
-def collect(path, max_bases=1 << 30, strip=False):
+def collect(path, max_bases=1 << 30, strip=False, threads=1):
     out = []
-    with E.Reader(path, strip) as r:
+    with E.Reader(path, strip, threads=threads) as r:
         fasta = r.is_fasta
         for b, o in r.batches(max_bases):
             assert o[0] == 0 and len(b) == o[-1]
@@ -137,3 +137,57 @@ def test_lz4_input(tmp_path, example_reads):
     bad.write_bytes(lz4_frame(text)[:-30000])
     with pytest.raises(Exception):
         collect(str(bad))
+
+
+# ---- parallel reader (mdbg_reader_open_mt): same records, same bytes, same order as the streaming reader ---------------------------------
+def random_records(rnd, n, fastq, crlf=False, multiline=False):
+    nl = b"\r\n" if crlf else b"\n"
+    out = bytearray()
+    for i in range(n):
+        ln = rnd.choice([0, 1, 7, 60, 300, 2000, 9000]) if rnd.random() < 0.9 else rnd.randrange(20000, 60000)
+        seq = bytes(rnd.choice(b"ACGTN") for _ in range(ln))
+        if fastq:
+            qual = bytes(rnd.choice(b"@+>!I5#") for _ in range(ln))        # quality lines that start with '@', '+' or '>'
+            out += b"@r%d %s" % (i, b"@x" if i % 3 == 0 else b"") + nl + seq + nl + b"+" + (b"r%d" % i if i % 5 == 0 else b"") + nl + qual + nl
+        else:
+            out += b">r%d some description" % i + nl
+            if multiline and ln > 80:
+                for a in range(0, ln, 70):
+                    out += seq[a:a + 70] + nl
+            else:
+                out += seq + nl
+    return bytes(out)
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fasta-crlf", "fasta-multiline", "fasta-multiline-strip", "fastq", "fastq-crlf", "fastq-noeol"])
+def test_parallel_reader_equals_streaming_reader(kind, tmp_path):
+    import random
+    rnd = random.Random(hash(kind) & 0xFFFF)
+    fastq = kind.startswith("fastq")
+    data = random_records(rnd, 700, fastq, crlf="crlf" in kind, multiline="multiline" in kind)
+    if kind == "fastq-noeol":
+        data = data.rstrip(b"\n")
+    if kind == "fasta":
+        data = b"junk before the first header\n\n" + data
+    p = tmp_path / ("r.fastq" if fastq else "r.fa")
+    p.write_bytes(data)
+    strip = kind.endswith("strip")
+    ref, is_fa = collect(str(p), strip=strip)
+    assert len(ref) == 700 and is_fa == (not fastq)
+    for threads in (2, 3, 8):
+        for max_bases in (1 << 30, 200_000, 30_000, 5_000, 1):
+            got, _ = collect(str(p), max_bases=max_bases, strip=strip, threads=threads)
+            assert got == ref, (threads, max_bases)
+
+
+def test_parallel_reader_falls_back_for_compressed_input(example_reads, tmp_path):
+    reads, fasta = collect(os.path.join(GOLDEN, "reads-0.00.fa.gz"), threads=8)
+    assert fasta and reads == example_reads
+    p = tmp_path / "plain.fa"
+    with gzip.open(os.path.join(GOLDEN, "reads-0.00.fa.gz")) as f:
+        p.write_bytes(f.read())
+    got, _ = collect(str(p), max_bases=1_000_000, threads=8)
+    assert got == example_reads
+    e = tmp_path / "empty.fa"
+    e.write_bytes(b"")
+    assert collect(str(e), threads=4) == ([], True)
