@@ -92,10 +92,14 @@ class TorchDistComm:
         sends / recvs = [(peer, [tensors])], the tensors of a (source, destination) pair are matched in order; empty
         tensors are skipped on both sides.  Returns a handle; wait() blocks the host until every receive has landed."""
         dist, ops = self.dist, []
+
+        def pieces(x):          # both sides cut a tensor the same way: at most max_bytes per message (see the class comment)
+            rows = max(1, self.max_bytes // max(1, x.element_size() * (x.numel() // max(1, x.shape[0]))))
+            return [x[a:a + rows] for a in range(0, x.shape[0], rows)] if x.numel() else []
         for peer, ts in recvs:
-            ops += [dist.P2POp(dist.irecv, x, peer) for x in ts if x.numel()]
+            ops += [dist.P2POp(dist.irecv, y, peer) for x in ts for y in pieces(x)]
         for peer, ts in sends:
-            ops += [dist.P2POp(dist.isend, x, peer) for x in ts if x.numel()]
+            ops += [dist.P2POp(dist.isend, y, peer) for x in ts for y in pieces(x)]
         reqs = dist.batch_isend_irecv(ops) if ops else []
         return _Pending(reqs, self.torch if self.device is not None and getattr(self.device, "type", "cpu") == "cuda" else None, (sends, recvs))
 
