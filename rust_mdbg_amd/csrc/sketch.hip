@@ -68,7 +68,9 @@ __global__ void bread_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bas
 // chasing bread[] -> offsets[]: the reads [rl, rh] that overlap the staged range and, when there are at most TREC_N of them, their
 // starts relative to the first staged position.
 constexpr int TREC_N = 7;
-struct __attribute__((aligned(16))) TileRec { u32 rl, rh; int64_t start0; int32_t rel[TREC_N - 1]; };     // start0: read rl (may lie far in front); rel[i]: read rl+1+i
+struct __attribute__((aligned(16))) TileRec { u32 rl, rh; int64_t start0; int32_t rel[TREC_N - 1]; int64_t first_base; };     // start0: read rl (may lie far in front); rel[i]: read rl+1+i;
+                                                                                                                                 // first_base = offsets[0] (the tile kernel would otherwise chase it through a second scalar load before it can issue its loads)
+static_assert(sizeof(TileRec) == 48, "three 16-byte words");
 __global__ void tile_rec_kernel(const u64* __restrict__ off, const u32* __restrict__ bread, u32 n_tiles, TileRec* __restrict__ recs) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
@@ -80,6 +82,7 @@ __global__ void tile_rec_kernel(const u64* __restrict__ off, const u32* __restri
         int64_t v = r.rl + 1 + i <= r.rh ? (int64_t)off[r.rl + 1 + i] - raw0 : 0x7FFFFFFF;
         r.rel[i] = (int32_t)(v > 0x7FFFFFFF ? 0x7FFFFFFF : v);
     }
+    r.first_base = (int64_t)off[0];
     recs[t] = r;
 }
 
@@ -254,7 +257,6 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     const int64_t nb = (int64_t)a.n_bases;
     const int64_t n_pairs = (nb + 31) >> 5;
     const bool hpc = a.hpc != 0;
-    const int64_t first_base = (int64_t)a.offsets[0];      // positions in front of it belong to no read
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     static_assert(WPT % 2 == 0 && (HALO_BASES / 32) % 2 == 0 && ((TILE_RAW_WORDS - HALO_BASES / 32) % 2) == 0, "16-byte aligned word pairs per thread");
     const u32 wg = blockIdx.x, gt = a.tile0 + wg;
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     const int64_t raw0 = (int64_t)gt * TILE_STRIDE - HALO_BASES;      // first staged raw position (negative for tile 0)
     const bool interior = raw0 >= 0 && raw0 + RW * 32 <= nb;
     const TileRec* const rec = a.recs + gt;
+    const int64_t first_base = rec->first_base;       // positions in front of it belong to no read
 
     // ---- phase 1: load (issued first: everything below hides under its latency), read starts, planes -------------------
     u32 x0[WPT], x1[WPT], pv0 = 0, pv1 = 0;          // my raw words (MSB first); pv*: bit 0 = the base in front of them
