@@ -179,6 +179,8 @@ def main():
     if routed and args.dist_impl == "c":
         from rust_mdbg_amd import dist_c
         cdist = dist_c.DistMdbg(args.k, args.l, args.density, args.minabund, rank, world, dist, device=local_rank)
+        n_chunks = args.chunks if args.chunks > 0 else 4
+        cdist.set_pipeline(n_chunks)          # the exchange of chunk i overlaps the tile kernel of chunk i+1 (mdbg_dist_set_pipeline)
     if routed and cdist is None:
         from rust_mdbg_amd import dist as D
         dev = torch.device("cuda", local_rank)
@@ -319,7 +321,7 @@ def main():
                                       "synthetic D. melanogaster %.0f Mb @%.0fx per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1%% errors" % (args.genome_mb, args.coverage),
                           "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
                           "bases_per_gpu": n_bases, "input_format": args.input,
-                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, "sketches + window lists exchanged by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h)" if cdist is not None else (("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records"))) if routed else "single GPU"},
+                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("sketches + window lists exchanged by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h) in %d chunks overlapping the tile kernel" % n_chunks) if cdist is not None else (("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records"))) if routed else "single GPU"},
                "roofline": roof, "roofline_ascii": roof_ascii, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),

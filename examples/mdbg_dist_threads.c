@@ -74,17 +74,19 @@ static int t_allreduce(void* self, uint64_t* d_buf, uint64_t n) {
 
 /* ---- one rank -------------------------------------------------------------------------------------------------------------- */
 typedef struct part_t { uint64_t n, n_global, n_distinct; uint64_t* keys; uint32_t* index; uint16_t* abundance; uint32_t* seqlen; uint64_t* src_read; uint64_t* row; } part_t;
-typedef struct job_t { rank_t rk; mdbg_params P; uint64_t reads_per_rank, genome; int rounds, packed; part_t out; } job_t;
+typedef struct job_t { rank_t rk; mdbg_params P; uint64_t reads_per_rank, genome; int rounds, packed, chunks; part_t out; } job_t;
 
 static void fetch(mdbg_ctx* c, void* dst, const void* src, uint64_t bytes) { if (bytes) CHECK(mdbg_copy_to_host(c, dst, src, bytes)); }
 
 static void* rank_main(void* arg) {
     job_t* j = (job_t*)arg; world_t* w = j->rk.w;
-    mdbg_comm comm; comm.self = &j->rk; comm.rank = j->rk.rank; comm.world = w->world;
+    mdbg_comm comm; memset(&comm, 0, sizeof comm);          /* exchange_begin / exchange_wait stay NULL: this transport only has the blocking form */
+    comm.self = &j->rk; comm.rank = j->rk.rank; comm.world = w->world;
     comm.allgather_u64 = t_allgather; comm.exchange = t_exchange; comm.allreduce_sum_u64 = t_allreduce;
     int err = 0;
     mdbg_dist* d = mdbg_dist_create(&j->P, &comm, &err);
     if (!d) { fprintf(stderr, "mdbg_dist_create: %d\n", err); exit(2); }
+    if (j->chunks > 1) CHECK(mdbg_dist_set_pipeline(d, (uint32_t)j->chunks));      /* every ingest call below is cut into that many rounds */
     mdbg_ctx* c = mdbg_dist_ctx(d);
     w->ctx[j->rk.rank] = c;
     pthread_barrier_wait(&w->bar);
@@ -135,6 +137,8 @@ int main(int argc, char** argv) {
     const uint64_t rpr = argc > 2 ? strtoull(argv[2], NULL, 10) : 300;
     const int rounds = argc > 3 ? atoi(argv[3]) : 2;
     const int packed = argc > 4 ? atoi(argv[4]) : 0;
+    const int chunks = argc > 5 ? atoi(argv[5]) : 1;          /* > 1: mdbg_dist_set_pipeline */
+    if (chunks < 1 || chunks > 64) { fprintf(stderr, "bad arguments\n"); return 1; }
     if (W < 1 || W > MAXW || rounds < 1 || rpr % (uint64_t)rounds) { fprintf(stderr, "bad arguments\n"); return 1; }
     mdbg_params P; memset(&P, 0, sizeof P);
     P.k = 9; P.l = 12; P.density = 0.004; P.min_abundance = 2; P.device = -1;
@@ -143,7 +147,7 @@ int main(int argc, char** argv) {
     job_t* jobs = (job_t*)calloc(W, sizeof(job_t));
     pthread_t th[MAXW];
     const uint64_t genome = 150000;
-    for (uint32_t r = 0; r < W; ++r) { jobs[r].rk.w = &w; jobs[r].rk.rank = r; jobs[r].P = P; jobs[r].reads_per_rank = rpr; jobs[r].genome = genome; jobs[r].rounds = rounds; jobs[r].packed = packed; }
+    for (uint32_t r = 0; r < W; ++r) { jobs[r].rk.w = &w; jobs[r].rk.rank = r; jobs[r].P = P; jobs[r].reads_per_rank = rpr; jobs[r].genome = genome; jobs[r].rounds = rounds; jobs[r].packed = packed; jobs[r].chunks = chunks; }
     for (uint32_t r = 0; r < W; ++r) pthread_create(&th[r], NULL, rank_main, &jobs[r]);
     for (uint32_t r = 0; r < W; ++r) pthread_join(th[r], NULL);
 
@@ -176,7 +180,7 @@ int main(int argc, char** argv) {
             if (row < ref.n) seen[row] = 1;
         }
     }
-    printf("world %u, %llu reads per rank in %d rounds, %s input: %llu nodes (%llu distinct k-min-mers); partitions", W, (unsigned long long)rpr, rounds,
+    printf("world %u, %llu reads per rank in %d rounds (x %d pipelined chunks), %s input: %llu nodes (%llu distinct k-min-mers); partitions", W, (unsigned long long)rpr, rounds, chunks,
            packed ? "packed" : "ASCII", (unsigned long long)ref.n, (unsigned long long)ref.n_distinct);
     for (uint32_t r = 0; r < W; ++r) printf(" %llu", (unsigned long long)jobs[r].out.n);
     printf(" -> %s\n", ok ? "EQUAL to the single-context table" : "MISMATCH");

@@ -41,6 +41,11 @@ typedef struct mdbg_comm {
     int (*exchange)(void* self, const mdbg_xfer* sends, uint32_t n_sends, const mdbg_xfer* recvs, uint32_t n_recvs);
     /* in-place element-wise sum over the ranks of n u64 values in DEVICE memory */
     int (*allreduce_sum_u64)(void* self, uint64_t* d_buf, uint64_t n);
+    /* optional (both or none; NULL = not available): the same exchange split in two, so that the library can keep its GPU busy while
+     * the data travels — exchange_begin starts all transfers and returns, exchange_wait blocks until every one of them has landed.
+     * At most one exchange is in flight per communicator. */
+    int (*exchange_begin)(void* self, const mdbg_xfer* sends, uint32_t n_sends, const mdbg_xfer* recvs, uint32_t n_recvs);
+    int (*exchange_wait)(void* self);
 } mdbg_comm;
 
 /* RCCL transport: nccl_comm is an initialised ncclComm_t of `world` ranks whose rank `rank` is this process' GPU (rccl.h:220
@@ -56,6 +61,12 @@ mdbg_dist* mdbg_dist_create(const mdbg_params* p, const mdbg_comm* comm, int* er
 void mdbg_dist_destroy(mdbg_dist* d);
 /* the rank's local context: for mdbg_get_stats, mdbg_sync, mdbg_last_error, mdbg_synth_reads_device ... (do not ingest through it) */
 mdbg_ctx* mdbg_dist_ctx(mdbg_dist* d);
+
+/* Pipelining inside one ingest call: the batch is cut into `chunks` runs of whole reads (every rank runs `chunks` rounds per call, so all
+ * ranks must set the same value); while chunk i travels to the peers (exchange_begin ... exchange_wait of the communicator) the tile
+ * kernel already works on chunk i+1, and the windows are inserted when the last chunk has arrived.  xGMI moves a rank's share of a
+ * round in about the time the sketch kernel needs for it, so this hides most of the exchange.  Default 1 (no cutting); 1..64. */
+int mdbg_dist_set_pipeline(mdbg_dist* d, uint32_t chunks);
 
 /* One round: sketch this rank's batch (DEVICE buffers, as mdbg_ingest_batch_device / mdbg_ingest_batch_packed_device), exchange
  * sketches and window lists with every peer, insert the windows this rank owns.  first_read_ordinal is GLOBAL (position of the

@@ -8,7 +8,7 @@ from . import api
 
 class Comm(C.Structure):                 # mdbg_comm
     _fields_ = [("self", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("allgather_u64", C.c_void_p), ("exchange", C.c_void_p),
-                ("allreduce_sum_u64", C.c_void_p)]
+                ("allreduce_sum_u64", C.c_void_p), ("exchange_begin", C.c_void_p), ("exchange_wait", C.c_void_p)]
 
 
 class UniqueId(C.Structure):             # ncclUniqueId, passed by value (rccl.h:187,220)
@@ -54,6 +54,7 @@ class DistMdbg:
         L.mdbg_dist_ingest_batch_packed_device.argtypes = [C.c_void_p, C.POINTER(api.PackedBatch), C.c_uint64, C.c_uint64]
         L.mdbg_dist_finalize.argtypes = [C.c_void_p, C.POINTER(api.Nodes), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.mdbg_dist_reset.argtypes = [C.c_void_p, C.c_uint32]
+        L.mdbg_dist_set_pipeline.argtypes = [C.c_void_p, C.c_uint32]
         L.mdbg_dist_destroy.argtypes = [C.c_void_p]
         self.comm, self.rccl = rccl_comm(rank, world, dist)
         vt = Comm()
@@ -69,6 +70,10 @@ class DistMdbg:
     def _chk(self, e):
         if e:
             raise api.MdbgError(e, self.L.mdbg_strerror(e).decode())
+
+    def set_pipeline(self, chunks):
+        """cut every ingest call into `chunks` rounds whose exchange overlaps the next chunk's sketch kernel (same value on every rank)"""
+        self._chk(self.L.mdbg_dist_set_pipeline(self.h, chunks))
 
     def ingest_device(self, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal):
         self._chk(self.L.mdbg_dist_ingest_batch_device(self.h, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal))

@@ -21,19 +21,20 @@ def exe(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("world,reads,rounds,packed", [(1, 300, 1, 0), (2, 300, 2, 0), (3, 300, 3, 1), (4, 200, 1, 0), (8, 160, 2, 1)])
-def test_c_program_drives_ranks_through_mdbg_dist(exe, world, reads, rounds, packed):
-    r = subprocess.run([exe, str(world), str(reads), str(rounds), str(packed)], capture_output=True, text=True, timeout=90)
+@pytest.mark.parametrize("world,reads,rounds,packed,chunks", [(1, 300, 1, 0, 1), (2, 300, 2, 0, 1), (3, 300, 3, 1, 1), (4, 200, 1, 0, 1), (8, 160, 2, 1, 1),
+                                                              (1, 300, 1, 0, 3), (2, 300, 2, 0, 4), (3, 300, 1, 1, 2), (8, 160, 2, 1, 5), (2, 40, 1, 0, 64)])
+def test_c_program_drives_ranks_through_mdbg_dist(exe, world, reads, rounds, packed, chunks):
+    """chunks > 1: mdbg_dist_set_pipeline cuts every ingest call into that many rounds (more chunks than reads: empty rounds)"""
+    r = subprocess.run([exe, str(world), str(reads), str(rounds), str(packed), str(chunks)], capture_output=True, text=True, timeout=90)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "EQUAL to the single-context table" in r.stdout
 
 
-class Comm(C.Structure):
-    _fields_ = [("self", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("allgather_u64", C.c_void_p), ("exchange", C.c_void_p),
-                ("allreduce_sum_u64", C.c_void_p)]
+from rust_mdbg_amd.dist_c import Comm      # noqa: E402  (mirror of mdbg_comm)
 
 
-def test_rccl_transport_with_a_one_rank_communicator():
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_rccl_transport_with_a_one_rank_communicator(chunks):
     """mdbg_comm_rccl on a real ncclComm_t (1 rank: all-gather, an empty send/recv group and the all-reduce run through RCCL); the table
     equals the plain single-GPU one"""
     import torch  # noqa: F401  (brings torch's RCCL into the process: the library resolves the nccl* symbols from it)
@@ -58,6 +59,9 @@ def test_rccl_transport_with_a_one_rank_communicator():
     L.mdbg_dist_create.argtypes = [C.POINTER(api.Params), C.POINTER(Comm), C.POINTER(C.c_int)]
     dd = L.mdbg_dist_create(C.byref(P), C.byref(vt), C.byref(err))
     assert dd and err.value == 0
+    assert vt.exchange_begin and vt.exchange_wait                      # the RCCL transport has the split form
+    L.mdbg_dist_set_pipeline.argtypes = [C.c_void_p, C.c_uint32]
+    assert L.mdbg_dist_set_pipeline(dd, chunks) == 0 and L.mdbg_dist_set_pipeline(dd, 0) == -1 and L.mdbg_dist_set_pipeline(dd, 65) == -1
     L.mdbg_dist_ingest_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
     L.mdbg_dist_finalize.argtypes = [C.c_void_p, C.POINTER(api.Nodes), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.mdbg_dist_destroy.argtypes = [C.c_void_p]
