@@ -51,7 +51,8 @@ typedef struct mdbg_comm {
 /* RCCL transport: nccl_comm is an initialised ncclComm_t of `world` ranks whose rank `rank` is this process' GPU (rccl.h:220
  * ncclCommInitRank).  The library resolves ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd / ncclAllGather / ncclAllReduce from the
  * RCCL already loaded into the process (or librccl.so.1) at run time, so libmdbg_hip.so itself does not depend on RCCL.
- * The communicator stays the caller's (destroy it after mdbg_dist_destroy). */
+ * The ncclComm_t stays the caller's (destroy it after mdbg_dist_destroy); the transport object behind out->self (a stream and two
+ * small staging buffers) passes to the mdbg_dist created with it and is freed by mdbg_dist_destroy: one mdbg_comm_rccl call per mdbg_dist. */
 int mdbg_comm_rccl(void* nccl_comm, uint32_t rank, uint32_t world, mdbg_comm* out);
 
 typedef struct mdbg_dist mdbg_dist;

@@ -87,3 +87,66 @@ def test_rccl_transport_with_a_one_rank_communicator(chunks):
     L.mdbg_dist_destroy(dd)
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+def test_pipelined_packed_batch_with_exceptions_through_the_c_layer():
+    """mdbg_dist_set_pipeline on a 2-bit packed batch that carries an exception list (N inside reads): every chunk gets its slice of the
+    list, rebased to the chunk's first base; the table equals the single-context one"""
+    import torch
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import api, emit as E, synth
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+    from rust_mdbg_amd.dist_c import UniqueId
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    L = api.load_library()
+    vt = Comm()
+    L.mdbg_comm_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Comm)]
+    assert L.mdbg_comm_rccl(comm, 0, 1, C.byref(vt)) == 0
+    k, l, d, a = 9, 12, 0.004, 2
+    reads = synth.synth_reads(11, 300000, 400, mean_len=7000, sd_len=2000, min_len=300, max_len=14000, err_ppm=2000)
+    reads = [r[:len(r) // 3] + b"N" + r[len(r) // 3 + 1:] if i % 5 == 0 and len(r) > 40 else r for i, r in enumerate(reads)]
+    from oracle import oracle as O
+    bases, offs = O.concat_reads(reads)
+    pk = E.pack_reads(bases, offs)
+    assert len(pk["exc_pos"]) == 80
+    with R.Mdbg(k, l, d, a) as m:
+        m.ingest_packed(pk, 0)
+        ref = m.finalize()
+    P = api.Params(k=k, l=l, density=d, min_abundance=a, reads_already_hpc=0, device=-1, flags=0, table_capacity_hint=0)
+    err = C.c_int()
+    L.mdbg_dist_create.restype = C.c_void_p
+    L.mdbg_dist_create.argtypes = [C.POINTER(api.Params), C.POINTER(Comm), C.POINTER(C.c_int)]
+    L.mdbg_dist_set_pipeline.argtypes = [C.c_void_p, C.c_uint32]
+    L.mdbg_dist_ingest_batch_packed_device.argtypes = [C.c_void_p, C.POINTER(api.PackedBatch), C.c_uint64, C.c_uint64]
+    L.mdbg_dist_finalize.argtypes = [C.c_void_p, C.POINTER(api.Nodes), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.mdbg_dist_destroy.argtypes = [C.c_void_p]
+    L.mdbg_dist_ctx.restype = C.c_void_p
+    L.mdbg_dist_ctx.argtypes = [C.c_void_p]
+    for chunks in (3, 7):
+        if chunks != 3:
+            assert L.mdbg_comm_rccl(comm, 0, 1, C.byref(vt)) == 0          # one transport object per mdbg_dist (mdbg_dist_destroy frees it)
+        dd = L.mdbg_dist_create(C.byref(P), C.byref(vt), C.byref(err))
+        assert dd and err.value == 0 and L.mdbg_dist_set_pipeline(dd, chunks) == 0
+        tw = torch.from_numpy(pk["words"].view(np.int64)).cuda()
+        to = torch.from_numpy(pk["offsets"].view(np.int64)).cuda()
+        tp = torch.from_numpy(pk["exc_pos"].view(np.int64)).cuda()
+        tv = torch.from_numpy(pk["exc_val"]).cuda()
+        torch.cuda.synchronize()
+        pb = api.PackedBatch(tw.data_ptr(), to.data_ptr(), len(reads), tp.data_ptr(), tv.data_ptr(), len(pk["exc_pos"]))
+        assert L.mdbg_dist_ingest_batch_packed_device(dd, C.byref(pb), len(bases), 0) == 0
+        nd, row, ng = api.Nodes(), C.c_void_p(), C.c_uint64()
+        assert L.mdbg_dist_finalize(dd, C.byref(nd), C.byref(row), C.byref(ng)) == 0
+        n = int(nd.n)
+        assert n == ng.value == ref["n_nodes"] > 500 and int(nd.n_distinct) == ref["n_nodes_before"]
+        with R.Mdbg(k, l, d, a) as m:           # any context can copy device memory to the host
+            keys = m.to_host(C.cast(nd.keys, C.c_void_p).value, n * k * 8, np.uint64).reshape(n, k)
+            rows = m.to_host(row.value, n * 8, np.uint64)
+            abund = m.to_host(C.cast(nd.abundance, C.c_void_p).value, n * 2, np.uint16)
+        assert np.array_equal(keys[np.argsort(rows)], ref["keys"]) and np.array_equal(abund[np.argsort(rows)], ref["abundance"])
+        L.mdbg_dist_destroy(dd)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
