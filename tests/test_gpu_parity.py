@@ -450,6 +450,24 @@ def test_large_and_sparse_read_ordinals():
     assert int(got["src_read"].max()) > (1 << 37) and exp["n_nodes"] > 500
 
 
+@pytest.mark.parametrize("k", [2047, 4096])
+def test_very_long_k(k):
+    """k up to 4096: the insert kernels stage 2048 + k - 1 hashes per workgroup (48 KB of LDS at k = 4096)"""
+    from rust_mdbg_amd import synth
+    rs = synth.synth_reads(3, 60000, 2, mean_len=30000, sd_len=2000, min_len=26000, max_len=34000, err_ppm=0)
+    reads = [rs[0], rs[1], rs[0], O.revcomp(rs[1])]
+    bases, offs = O.concat_reads(reads)
+    g = O.Graph(k, 8, 0.5, 2)
+    g.ingest(bases, offs)
+    exp = g.finalize(with_edges=False)
+    R = _mdbg()
+    with R.Mdbg(k, 8, 0.5, 2) as m:
+        m.ingest(bases, offs, 0)
+        got = m.finalize()
+    assert exp["n_nodes"] > 1000
+    assert_nodes_equal(got, exp)
+
+
 def test_overlapping_read_ordinals_are_an_error():
     """two batches whose ordinal ranges overlap (a caller that always passes 0) must not yield a silently wrong table"""
     R = _mdbg()
