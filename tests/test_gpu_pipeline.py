@@ -79,8 +79,9 @@ def test_plain_c_program_over_the_two_abis(example_reads, tmp_path):
     assert bad.returncode == 1 and "invalid parameter" in bad.stderr
 
 
-def test_reader_thread_is_released_when_the_consumer_fails(tmp_path):
-    """an error in the GPU stage (here: a byte outside ACGTN) must not leave the reader thread blocked on its queue"""
+@pytest.mark.parametrize("threads", [1, 4])
+def test_reader_thread_is_released_when_the_consumer_fails(tmp_path, threads):
+    """an error in the GPU stage (here: a byte outside ACGTN) must not leave the reader (and, with threads > 1, the packer) thread blocked"""
     import threading
     import time
     import rust_mdbg_amd as R
@@ -91,7 +92,7 @@ def test_reader_thread_is_released_when_the_consumer_fails(tmp_path):
             f.write(">r%d\n%s\n" % (i, ("ACGTTGCA" * 500) if i != 3 else ("ACGTTGCA" * 200 + "X" + "ACGTTGCA" * 200)))
     before = threading.active_count()
     with pytest.raises(R.MdbgError) as ei:
-        pipeline.run_file(p, str(tmp_path / "out"), 5, 10, 0.02, 2, batch_bases=200_000)      # many batches: the reader runs ahead
+        pipeline.run_file(p, str(tmp_path / "out"), 5, 10, 0.02, 2, batch_bases=200_000, threads=threads)      # many batches: the reader runs ahead
     assert ei.value.code == -2
     deadline = time.time() + 5
     while threading.active_count() > before and time.time() < deadline:
@@ -164,3 +165,19 @@ def test_file_pipeline_with_lmer_counts(example_reads, tmp_path):
     assert (out["n_minimizers"], out["n_nodes_before"], out["n_nodes"], out["n_edges"]) == (r["n_minimizers"], r["n_nodes_before"], r["n_nodes"], r["n_edges"])
     plain = O.sketch(b, o, l, d)
     assert 0 < out["n_minimizers"] < len(plain["hashes"])
+
+
+def test_file_pipeline_with_host_threads_equals_single_thread(example_reads, tmp_path):
+    """threads > 1: mapped file parsed in pieces, batches packed to 2 bits, three overlapped host stages — same graph files"""
+    import gzip
+    from rust_mdbg_amd import pipeline
+    plain = str(tmp_path / "reads.fa")
+    with gzip.open(os.path.join(GOLDEN, "reads-0.00.fa.gz")) as f, open(plain, "wb") as g:
+        g.write(f.read())
+    a = pipeline.run_file(plain, str(tmp_path / "t1"), 7, 10, 0.0008, 2, batch_bases=3_000_000, threads=1)
+    b = pipeline.run_file(plain, str(tmp_path / "t8"), 7, 10, 0.0008, 2, batch_bases=3_000_000, threads=8)
+    for f in ("n_reads", "n_bases", "n_minimizers", "n_windows", "n_nodes_before", "n_nodes", "n_edges"):
+        assert a[f] == b[f], f
+    assert a["n_nodes"] == 104
+    assert open(str(tmp_path / "t1") + ".gfa").read() == open(str(tmp_path / "t8") + ".gfa").read()
+    assert open(str(tmp_path / "t1") + ".0.sequences", "rb").read() == open(str(tmp_path / "t8") + ".0.sequences", "rb").read()
