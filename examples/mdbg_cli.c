@@ -1,14 +1,55 @@
 /* mdbg_cli.c — the two C ABIs used from plain C, the way rust-mdbg's main() would use them through FFI:
- *   reads.fa[.gz]  ->  mdbg_reader_*  ->  mdbg_ingest_batch  ->  mdbg_finalize  ->  mdbg_graph_edges  ->  <prefix>.gfa (+ <prefix>.0.sequences)
- * Same flags as the reference binary for this path (src/main.rs:330-420): -k -l --density --minabund --presimp --prefix.
- * Build:  gcc -O2 -Iinclude examples/mdbg_cli.c -Lrust_mdbg_amd -lmdbg_hip -lmdbg_emit -Wl,-rpath,$PWD/rust_mdbg_amd -o mdbg_cli
+ *   reads.fa[.gz]  ->  mdbg_reader_*  ->  mdbg_ingest_batch[_packed]  ->  mdbg_finalize  ->  mdbg_graph_edges  ->  <prefix>.gfa (+ <prefix>.0.sequences)
+ * Same flags as the reference binary for this path (src/main.rs:330-420): -k -l --density --minabund --presimp --prefix --threads
+ * --reference --lmer-counts/--lmer_counts_min/--lmer_counts_max --no-basespace.
+ * --threads N > 1: an uncompressed input is mapped and parsed by N threads (mdbg_reader_open_mt), batches are packed to 2 bits per
+ * base (mdbg_pack_reads) and a reader thread parses batch i+1 while the main thread packs and ingests batch i.
+ * Build:  gcc -O2 -Iinclude examples/mdbg_cli.c -Lrust_mdbg_amd -lmdbg_hip -lmdbg_emit -lpthread -Wl,-rpath,$PWD/rust_mdbg_amd -o mdbg_cli
  */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mdbg_emit.h"
 #include "mdbg_hip.h"
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* reader thread: one batch ahead of the consumer.  The parallel reader alternates two buffers (a batch stays valid until the call
+ * after the next one), so exactly one batch may be outstanding while the next is parsed. */
+typedef struct feed_t {
+    mdbg_reader* rd; uint64_t max_bases;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int have, rc;                          /* have: a batch is waiting to be picked up */
+    const uint8_t* bases; const uint64_t* offs; uint64_t n;
+} feed_t;
+static void* feed_main(void* arg) {
+    feed_t* f = (feed_t*)arg;
+    for (;;) {
+        const uint8_t* b; const uint64_t* o; uint64_t n;
+        const int rc = mdbg_reader_next(f->rd, f->max_bases, &b, &o, &n);
+        pthread_mutex_lock(&f->mu);
+        f->bases = b; f->offs = o; f->n = n; f->rc = rc; f->have = 1;
+        pthread_cond_broadcast(&f->cv);
+        while (f->have) pthread_cond_wait(&f->cv, &f->mu);          /* picking batch j up means the consumer is done with batch j-1: its buffer may be reused */
+        pthread_mutex_unlock(&f->mu);
+        if (rc || !n) return NULL;
+    }
+}
+/* next batch from the reader thread (the previous one must have been fully consumed) */
+static int feed_take(feed_t* f, const uint8_t** bases, const uint64_t** offs, uint64_t* n) {
+    pthread_mutex_lock(&f->mu);
+    while (!f->have) pthread_cond_wait(&f->cv, &f->mu);
+    *bases = f->bases; *offs = f->offs; *n = f->n;
+    const int rc = f->rc;
+    f->have = 0;
+    pthread_cond_broadcast(&f->cv);
+    pthread_mutex_unlock(&f->mu);
+    return rc;
+}
 
 static void die(mdbg_ctx* ctx, const char* what, int rc) {
     fprintf(stderr, "%s: %s (%s)\n", what, mdbg_strerror(rc), ctx && mdbg_last_error(ctx) ? mdbg_last_error(ctx) : "");
@@ -19,7 +60,8 @@ int main(int argc, char** argv) {
     mdbg_params p; memset(&p, 0, sizeof p);
     p.k = 10; p.l = 12; p.density = 0.1; p.min_abundance = 2; p.device = -1;       /* the reference's defaults (main.rs:430-450) */
     float presimp = 0.01f;
-    const char* input = NULL; const char* prefix = "graph"; int write_sequences = 1;
+    const char* input = NULL; const char* prefix = "graph"; int write_sequences = 1, threads = 1, reference = 0, timing = 0;
+    const char* lmer_counts = NULL; uint32_t lc_min = 2, lc_max = 100000;          /* main.rs:447-448 */
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-k") && i + 1 < argc) p.k = (uint32_t)atoi(argv[++i]);
         else if (!strcmp(argv[i], "-l") && i + 1 < argc) p.l = (uint32_t)atoi(argv[++i]);
@@ -28,27 +70,81 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--presimp") && i + 1 < argc) presimp = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--prefix") && i + 1 < argc) prefix = argv[++i];
         else if (!strcmp(argv[i], "--no-basespace")) write_sequences = 0;
+        else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--reference")) reference = 1;                                 /* main.rs:737: newlines inside FASTA records are removed */
+        else if (!strcmp(argv[i], "--lmer-counts") && i + 1 < argc) lmer_counts = argv[++i];
+        else if (!strcmp(argv[i], "--lmer_counts_min") && i + 1 < argc) lc_min = (uint32_t)strtoul(argv[++i], NULL, 10);
+        else if (!strcmp(argv[i], "--lmer_counts_max") && i + 1 < argc) lc_max = (uint32_t)strtoul(argv[++i], NULL, 10);
+        else if (!strcmp(argv[i], "--timing")) timing = 1;
         else if (argv[i][0] != '-') input = argv[i];
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
-    if (!input) { fprintf(stderr, "usage: mdbg_cli reads.fa[.gz] [-k K] [-l L] [--density D] [--minabund A] [--presimp P] [--prefix PFX] [--no-basespace]\n"); return 2; }
+    if (!input) { fprintf(stderr, "usage: mdbg_cli reads.fa[.gz] [-k K] [-l L] [--density D] [--minabund A] [--presimp P] [--prefix PFX] [--no-basespace] [--threads N] [--reference] [--lmer-counts FILE [--lmer_counts_min A] [--lmer_counts_max B]] [--timing]\n"); return 2; }
+    if (threads < 1) threads = 1;
 
     int err = 0;
     mdbg_ctx* ctx = mdbg_create(&p, &err);
     if (!ctx) die(NULL, "mdbg_create", err);
-    mdbg_reader* rd = mdbg_reader_open(input, 0, &err);
+    const double t0 = now_s();
+    if (lmer_counts) {                                               /* main.rs:544-575: the selected l-mers restrict the sketch */
+        uint64_t* codes = NULL; uint64_t n_codes = 0, ignored = 0;
+        int rc = mdbg_lmer_filter_from_counts(lmer_counts, p.l, p.density, lc_min, lc_max, &codes, &n_codes, &ignored);
+        if (rc) die(NULL, "mdbg_lmer_filter_from_counts", rc);
+        rc = mdbg_set_lmer_filter(ctx, codes, n_codes);
+        if (rc) die(ctx, "mdbg_set_lmer_filter", rc);
+        mdbg_lmer_filter_free(codes);
+    }
+    const uint64_t batch_bases = 256u << 20;
+    mdbg_reader* rd = mdbg_reader_open_mt(input, reference, threads, &err);
     if (!rd) die(NULL, "mdbg_reader_open", err);
-    uint64_t n_reads = 0, first = 0;
-    for (;;) {
+    uint64_t n_reads = 0, n_bases = 0, first = 0;
+    double t_wait = 0, t_pack = 0, t_gpu = 0;                       /* --timing: where the ingest loop spends its time */
+    if (threads > 1 && mdbg_reader_is_parallel(rd)) {
+        /* reader thread one batch ahead; this thread packs to 2 bits per base and ingests */
+        feed_t f; memset(&f, 0, sizeof f); f.rd = rd; f.max_bases = batch_bases;
+        pthread_mutex_init(&f.mu, NULL); pthread_cond_init(&f.cv, NULL);
+        pthread_t th; pthread_create(&th, NULL, feed_main, &f);
+        uint64_t* words = NULL, words_cap = 0, exc_cap = 1024;
+        uint64_t* exc_pos = (uint64_t*)malloc(exc_cap * 8); uint8_t* exc_val = (uint8_t*)malloc(exc_cap);
+        for (;;) {
+            const uint8_t* bases; const uint64_t* offs; uint64_t n;
+            double ta = now_s();
+            int rc = feed_take(&f, &bases, &offs, &n);
+            t_wait += now_s() - ta;
+            if (rc) die(NULL, "mdbg_reader_next", rc);
+            if (!n) break;
+            ta = now_s();
+            const uint64_t nb = offs[n], nw = mdbg_packed_words(nb);
+            if (nw > words_cap) { free(words); words_cap = nw + nw / 8 + 64; words = (uint64_t*)malloc(words_cap * 8); }
+            uint64_t n_exc = 0;
+            rc = mdbg_pack_reads(bases, nb, words, exc_pos, exc_val, exc_cap, &n_exc, threads);
+            if (rc == MDBG_E_CAPACITY) {                             /* more bytes outside ACGT than expected: make room, pack again */
+                exc_cap = n_exc + 1024; free(exc_pos); free(exc_val);
+                exc_pos = (uint64_t*)malloc(exc_cap * 8); exc_val = (uint8_t*)malloc(exc_cap);
+                rc = mdbg_pack_reads(bases, nb, words, exc_pos, exc_val, exc_cap, &n_exc, threads);
+            }
+            if (rc) die(NULL, "mdbg_pack_reads", rc);
+            t_pack += now_s() - ta; ta = now_s();
+            mdbg_packed_batch pb; memset(&pb, 0, sizeof pb);
+            pb.words = words; pb.offsets = offs; pb.n_reads = n; pb.exc_pos = exc_pos; pb.exc_val = exc_val; pb.n_exc = n_exc;
+            rc = mdbg_ingest_batch_packed(ctx, &pb, first);
+            if (rc) die(ctx, "mdbg_ingest_batch_packed", rc);
+            t_gpu += now_s() - ta;
+            first += n; n_reads += n; n_bases += nb;
+        }
+        pthread_join(th, NULL);
+        free(words); free(exc_pos); free(exc_val);
+    } else for (;;) {
         const uint8_t* bases; const uint64_t* offs; uint64_t n;
-        int rc = mdbg_reader_next(rd, 256u << 20, &bases, &offs, &n);
+        int rc = mdbg_reader_next(rd, batch_bases, &bases, &offs, &n);
         if (rc) die(NULL, "mdbg_reader_next", rc);
         if (!n) break;
         rc = mdbg_ingest_batch(ctx, bases, offs, n, first);          /* process_read_aux over the batch */
         if (rc) die(ctx, "mdbg_ingest_batch", rc);
-        first += n; n_reads += n;
+        first += n; n_reads += n; n_bases += offs[n];
     }
     mdbg_reader_close(rd);
+    const double t_ingest = now_s();
 
     mdbg_nodes nodes; mdbg_edge_list edges;
     int rc = mdbg_finalize(ctx, &nodes);
@@ -66,11 +162,13 @@ int main(int argc, char** argv) {
     snprintf(path, sizeof path, "%s.gfa", prefix);
     rc = mdbg_emit_write_gfa(path, &nodes, &edges);
     if (rc) die(NULL, "mdbg_emit_write_gfa", rc);
+    if (timing) fprintf(stderr, "timing: %llu reads, %llu bases; ingest %.3f s, to .gfa %.3f s (%.2f Gbases/s; context creation not included); ingest loop: waiting for the reader %.3f, packing %.3f, mdbg_ingest_batch_packed %.3f s\n",
+                        (unsigned long long)n_reads, (unsigned long long)n_bases, t_ingest - t0, now_s() - t0, (double)n_bases / (now_s() - t0) / 1e9, t_wait, t_pack, t_gpu);
     if (write_sequences) {                                          /* second pass over the input: the node sequences */
         snprintf(path, sizeof path, "%s.0.sequences", prefix);
         mdbg_seqfile* sf = mdbg_seqfile_open(path, p.k, p.l, &err);
         if (!sf) die(NULL, "mdbg_seqfile_open", err);
-        rd = mdbg_reader_open(input, 0, &err);
+        rd = mdbg_reader_open_mt(input, reference, threads, &err);
         if (!rd) die(NULL, "mdbg_reader_open", err);
         first = 0;
         for (;;) {

@@ -29,6 +29,22 @@ for label, kw in (("1 reader thread, ASCII batches", dict(threads=1)), ("1 threa
         dt = time.perf_counter() - t
         if best is None or dt < best[0]: best = (dt, c)
     out[label] = dict(seconds=round(best[0], 4), gbases_per_s=round(best[1]["n_bases"] / best[0] / 1e9, 2), nodes=best[1]["n_nodes"], edges=best[1]["n_edges"], seconds_until=best[1]["seconds_until"])
+# the same through the plain-C host (examples/mdbg_cli.c): no Python between the reader, the packer and the ingest call
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+exe = "/tmp/mdbg_cli"
+subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "mdbg_cli.c"), "-L" + os.path.join(root, "rust_mdbg_amd"),
+                       "-lmdbg_hip", "-lmdbg_emit", "-lpthread", "-Wl,-rpath," + os.path.join(root, "rust_mdbg_amd"), "-o", exe])
+cli = {}
+for th in (1, 16, 32):
+    best = None
+    for rep in range(2):
+        r = subprocess.run([exe, path, "-k", str(K), "-l", str(Lm), "--density", str(Dn), "--minabund", "2", "--prefix", "/tmp/outc", "--no-basespace", "--threads", str(th), "--timing"],
+                           capture_output=True, text=True, check=True)
+        line = [x for x in r.stderr.split("\n") if x.startswith("timing:")][0]
+        ing = float(line.split("ingest ")[1].split(" s")[0]); tot = float(line.split("to .gfa ")[1].split(" s")[0])
+        if best is None or tot < best[1]: best = (ing, tot, line)
+    cli["%d threads" % th] = dict(ingest_s=best[0], to_gfa_s=best[1], gbases_per_s=round(nb / best[1] / 1e9, 2), line=best[2])
+out_cli = cli
 rd = None if big else json.loads(subprocess.check_output([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "measure_reader.py"), "100000", "gz"]).decode().strip().split("\n")[-1])
 print(json.dumps(dict(file_gb=os.path.getsize(path) / 1e9, host_cores=os.cpu_count(), workload=("BASELINE configs[2] shape: 466,666 reads, 7.0 Gbases, k=35 l=12 d=0.002" if big else "BASELINE configs[1] shape: 100,000 reads, 1.50 Gbases, k=21 l=12 d=0.003") + " minabund=2, uncompressed FASTA in the page cache; nodes + edges + .gfa",
-                      pipeline=out, reader_only=rd)))
+                      pipeline=out, c_host_mdbg_cli=out_cli, reader_only=rd)))

@@ -66,7 +66,7 @@ def test_headers_are_plain_c_and_the_example_links(tmp_path):
     lib = os.path.join(ROOT, "rust_mdbg_amd")
     exe = str(tmp_path / "mdbg_cli")
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "mdbg_cli.c"), "-L" + lib, "-lmdbg_hip", "-lmdbg_emit", "-Wl,-rpath," + lib, "-o", exe], check=True)
+                    os.path.join(ROOT, "examples", "mdbg_cli.c"), "-L" + lib, "-lmdbg_hip", "-lmdbg_emit", "-lpthread", "-Wl,-rpath," + lib, "-o", exe], check=True)
     assert os.path.exists(exe)
 
 

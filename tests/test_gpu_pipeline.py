@@ -67,7 +67,7 @@ def test_plain_c_program_over_the_two_abis(example_reads, tmp_path):
     exe = str(tmp_path / "mdbg_cli")
     lib = os.path.join(ROOT, "rust_mdbg_amd")
     subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "mdbg_cli.c"), "-L" + lib, "-lmdbg_hip", "-lmdbg_emit",
-                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+                    "-lpthread", "-Wl,-rpath," + lib, "-o", exe], check=True)
     src = os.path.join(GOLDEN, "reads-0.00.fa.gz")
     r = subprocess.run([exe, src, "-k", "7", "-l", "10", "--density", "0.0008", "--minabund", "2", "--prefix", str(tmp_path / "c")],
                        check=True, capture_output=True, text=True)
@@ -77,6 +77,32 @@ def test_plain_c_program_over_the_two_abis(example_reads, tmp_path):
     assert read_lz4_frame(str(tmp_path / "c.0.sequences")) == read_lz4_frame(str(tmp_path / "py.0.sequences"))
     bad = subprocess.run([exe, src, "-k", "1"], capture_output=True, text=True)            # errors are codes + text, not aborts
     assert bad.returncode == 1 and "invalid parameter" in bad.stderr
+    # --threads: the uncompressed file is mapped and parsed in pieces, a reader thread runs one batch ahead, batches go in packed
+    import gzip
+    plain = str(tmp_path / "reads.fa")
+    with gzip.open(src) as f, open(plain, "wb") as g:
+        g.write(f.read())
+    r = subprocess.run([exe, plain, "-k", "7", "-l", "10", "--density", "0.0008", "--minabund", "2", "--prefix", str(tmp_path / "ct"), "--threads", "4", "--timing"],
+                       check=True, capture_output=True, text=True)
+    assert "Number of nodes after abundance filter: 104" in r.stdout and "timing:" in r.stderr
+    assert open(str(tmp_path / "ct.gfa")).read() == open(str(tmp_path / "py.gfa")).read()
+    assert read_lz4_frame(str(tmp_path / "ct.0.sequences")) == read_lz4_frame(str(tmp_path / "py.0.sequences"))
+    # --lmer-counts: same counters as the Python pipeline with the same counts file
+    import collections
+    cnt = collections.Counter()
+    for rd in example_reads[:40]:
+        text = O.encode_rle(rd)[0]
+        for i in range(len(text) - 9):
+            cnt[bytes(text[i:i + 10])] += 1
+    cf = str(tmp_path / "counts.txt")
+    with open(cf, "w") as f:
+        for w, c in cnt.items():
+            if b"N" not in w:
+                f.write("%s\t%d\n" % (w.decode(), c))
+    pc = pipeline.run_file(plain, str(tmp_path / "pyl"), 7, 10, 0.004, 2, lmer_counts=cf, lmer_counts_min=1, lmer_counts_max=60)
+    subprocess.run([exe, plain, "-k", "7", "-l", "10", "--density", "0.004", "--minabund", "2", "--prefix", str(tmp_path / "cl"), "--threads", "3",
+                    "--lmer-counts", cf, "--lmer_counts_min", "1", "--lmer_counts_max", "60"], check=True, capture_output=True, text=True)
+    assert pc["n_nodes"] > 0 and open(str(tmp_path / "cl.gfa")).read() == open(str(tmp_path / "pyl.gfa")).read()
 
 
 @pytest.mark.parametrize("threads", [1, 4])
