@@ -836,6 +836,21 @@ void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, 
     hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((n + OWN_SPAN - 1) / OWN_SPAN)), dim3(256),
                        (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err);
 }
+// Several small regions zeroed (and one scalar set) by ONE launch: the steps between the big kernels would otherwise be chains of
+// 5-microsecond fill kernels (ten of them in front of the sketch, five in front of finalize).
+struct ZeroList { u64* p[6]; u64 n[6]; u64* set_p; u64 set_v; };
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroList z) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, stride = (u64)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) for (u64 i = i0; i < z.n[r]; i += stride) z.p[r][i] = 0;
+    if (i0 == 0 && z.set_p) *z.set_p = z.set_v;
+}
+void launch_zero_regions(const ZeroList& z, hipStream_t s) {
+    u64 mx = 1;
+    for (int r = 0; r < 6; ++r) mx = z.n[r] > mx ? z.n[r] : mx;
+    const unsigned blocks = (unsigned)std::min<u64>(1024, (mx + 255) / 256);
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(blocks), dim3(256), 0, s, z);
+}
 void launch_reserve_check(const u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s) {
     hipLaunchKernelGGL(reserve_check_kernel, dim3(1), dim3(1), 0, s, n_distinct, batch_windows, cap, too_small);
 }
