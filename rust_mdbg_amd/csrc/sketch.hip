@@ -613,11 +613,22 @@ __global__ __launch_bounds__(256) void gather_kernel(u32 tile0, u32 n, const Rec
 
 // per-read offsets into the ordered minimizer arrays: off[slot] = first i with mread[i] >= slot, for the batch's
 // slots [slot0, slot0 + n_reads]; mread holds absolute slot indices and is sorted.
-__global__ void read_offsets_kernel(const u32* __restrict__ mread, u64 m0, u64 m1, u32 slot0, u32 n_reads, u64* __restrict__ off) {
+// m1_dev != null: launched BEFORE the host knows the batch's end, over an upper bound m1 (the store's capacity); the true end is *m1_dev.
+// *overflow != 0 then means a tile slab overflowed: the batch will be sketched again, what the gather wrote has holes — nothing to do here.
+__global__ void read_offsets_kernel(const u32* __restrict__ mread, u64 m0, u64 m1, const u64* __restrict__ m1_dev, const u32* __restrict__ overflow,
+                                    u32 slot0, u32 n_reads, u64* __restrict__ off) {
     const u64 i = m0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m1_dev) {
+        if (*overflow) return;
+        const u64 e = *m1_dev;
+        if (e > m1) return;                                            // the store was too small: the batch will be sketched again as well
+        m1 = e;
+    }
     if (i > m1) return;
-    const int64_t prev = (i == m0) ? (int64_t)slot0 - 1 : (int64_t)mread[i - 1];
-    const int64_t cur = (i == m1) ? (int64_t)slot0 + n_reads : (int64_t)mread[i];
+    int64_t prev = (i == m0) ? (int64_t)slot0 - 1 : (int64_t)mread[i - 1];
+    int64_t cur = (i == m1) ? (int64_t)slot0 + n_reads : (int64_t)mread[i];
+    if (prev < (int64_t)slot0 - 1) prev = (int64_t)slot0 - 1;         // (slots of this batch only, whatever the arrays hold)
+    if (cur > (int64_t)slot0 + n_reads) cur = (int64_t)slot0 + n_reads;
     for (int64_t r = prev + 1; r <= cur; ++r) off[r] = i;
 }
 
@@ -886,7 +897,11 @@ void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_b
 
 void launch_read_offsets(const u32* mread, u64 m0, u64 m1, u32 slot0, u32 n_reads, u64* off, hipStream_t s) {
     const u64 n = m1 - m0 + 1;
-    hipLaunchKernelGGL(read_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mread, m0, m1, slot0, n_reads, off);
+    hipLaunchKernelGGL(read_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mread, m0, m1, (const u64*)nullptr, (const u32*)nullptr, slot0, n_reads, off);
+}
+void launch_read_offsets_early(const u32* mread, u64 m0, u64 m1_upper, const u64* m1_dev, const u32* overflow, u32 slot0, u32 n_reads, u64* off, hipStream_t s) {
+    const u64 n = m1_upper - m0 + 1;
+    hipLaunchKernelGGL(read_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mread, m0, m1_upper, m1_dev, overflow, slot0, n_reads, off);
 }
 
 // hash_bound = floor(density * 2^64), saturating (src/read.rs:183)
