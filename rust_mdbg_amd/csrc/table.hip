@@ -735,13 +735,15 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
         F.o_rev[n] = rev ? 1 : 0;
     }
     __syncthreads();
+    // the keys: one wavefront per node, lane j copies element j (contiguous on both sides, no index arithmetic per element)
     const u32 nodes = (u32)(n_solid - q0 < 256 ? n_solid - q0 : 256);
-    const u32 total = nodes * k;
-    for (u32 e = threadIdx.x; e < total; e += 256) {
-        const u32 g = e / k, j = e - g * k;
+    const u32 lane = threadIdx.x & 63;
+    for (u32 g = threadIdx.x >> 6; g < nodes; g += 4) {
         const u64 src = sh_src[g];
         const u64 i = src & ~(1ull << 63);
-        F.o_keys[sh_row[g] * k + j] = F.mh[i + ((src >> 63) ? k - 1 - j : j)];
+        const bool rev = (src >> 63) != 0;
+        u64* const dst = F.o_keys + sh_row[g] * k;
+        for (u32 j = lane; j < k; j += 64) dst[j] = F.mh[i + (rev ? k - 1 - j : j)];
     }
 }
 
