@@ -117,8 +117,32 @@ class NumpyEngine:
             out.append((h, p, (h, p)))           # the token of this engine is simply the pair of receive buffers
         return out
 
-    def commit_import(self, token, rel_off, first_ordinal, owned=None):
+    def commit_import(self, token, rel_off, first_ordinal, owned=None, window_list=None):
         self.ingest_sketch(token[0], token[1], rel_off, first_ordinal)
+        if window_list is not None:            # the sender listed this rank's windows: pairs (index of the first minimizer, read), relative to the batch
+            self.batches[-1]["list"] = window_list.numpy().astype(np.int64).reshape(-1, 2)
+            self.batches[-1]["owned"] = owned
+
+    def _owner(self, w):
+        k, M = self.k, (1 << 64) - 1
+        x = (w[0] + w[k - 1] + w[(k - 1) >> 1] + w[k >> 1]) & M
+        return (self._fmix(x) * self.world) >> 64
+
+    def owner_lists(self, world):
+        """the mdbg_owner_lists of this engine: windows of the batch sketched last per owning rank -> (counts, int32 tensor of (window, read)
+        pairs bucketed by owner)"""
+        assert world == self.world
+        b = self.batches[-1]
+        sk, k = b["sk"], self.k
+        buckets = [[] for _ in range(world)]
+        for r in range(b["n"]):
+            lo, hi = int(sk["off"][r]), int(sk["off"][r + 1])
+            if hi - lo > k:
+                for i in range(hi - lo - k + 1):
+                    w = [int(x) for x in sk["hashes"][lo + i:lo + i + k]]
+                    buckets[self._owner(w)].append((lo + i, r))
+        flat = np.array([v for bk in buckets for pr in bk for v in pr], dtype=np.int32)
+        return [len(bk) for bk in buckets], torch.from_numpy(flat)
 
     @staticmethod
     def _fmix(x):
@@ -130,13 +154,24 @@ class NumpyEngine:
         k, M = self.k, (1 << 64) - 1
         for b in self.pending:
             sk = b["sk"]
-            for r in range(b["n"]):
-                lo, hi = int(sk["off"][r]), int(sk["off"][r + 1])
-                if hi - lo > k:
-                    for i in range(hi - lo - k + 1):
+            if "list" in b:                     # exactly the listed windows (each one checked, like insert_listed_span_kernel), and their number
+                cand, n_ok = [(int(r), int(wi) - int(sk["off"][int(r)])) for wi, r in b["list"]], 0
+                for r, i in cand:
+                    lo, hi = int(sk["off"][r]), int(sk["off"][r + 1])
+                    assert 0 <= i and hi - lo > k and lo + i + k <= hi
+                    n_ok += 1
+                assert b["owned"] is None or n_ok == b["owned"]
+            else:
+                cand = [(r, i) for r in range(b["n"]) if int(sk["off"][r + 1]) - int(sk["off"][r]) > k
+                        for i in range(int(sk["off"][r + 1]) - int(sk["off"][r]) - k + 1)]
+            for r, i in cand:
+                lo = int(sk["off"][r])
+                if True:
+                    if True:
                         w = [int(x) for x in sk["hashes"][lo + i:lo + i + k]]
                         x = (w[0] + w[k - 1] + w[(k - 1) >> 1] + w[k >> 1]) & M
                         if (self._fmix(x) * self.world) >> 64 != self.rank:
+                            assert "list" not in b, "a listed window is not owned by this rank"
                             continue
                         rev = not (w < w[::-1])
                         key = tuple(w[::-1] if rev else w)

@@ -51,6 +51,9 @@ def run_rank(rank, world, comm, reads, out, batches_per_rank=2, mode="route"):
     else:
         for bb, oo, s in chunks:
             drv.ingest_host(bb, oo, s)
+    if mode != "route" and world > 1:          # the window lists travelled with every foreign sketch (the protocol of the GPU engine)
+        foreign = [b for b in eng.batches if not (lo <= b["first"] < hi)]
+        assert foreign and all("list" in b for b in foreign)
     out[rank] = drv.finalize()
 
 
