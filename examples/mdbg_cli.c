@@ -2,8 +2,8 @@
  *   reads.fa[.gz]  ->  mdbg_reader_*  ->  mdbg_ingest_batch[_packed]  ->  mdbg_finalize  ->  mdbg_graph_edges  ->  <prefix>.gfa (+ <prefix>.0.sequences)
  * Same flags as the reference binary for this path (src/main.rs:330-420): -k -l --density --minabund --presimp --prefix --threads
  * --reference --lmer-counts/--lmer_counts_min/--lmer_counts_max --no-basespace.
- * --threads N > 1: an uncompressed input is mapped and parsed by N threads (mdbg_reader_open_mt), batches are packed to 2 bits per
- * base (mdbg_pack_reads) and a reader thread parses batch i+1 while the main thread packs and ingests batch i.
+ * --threads N > 1: an uncompressed input is mapped and parsed by N threads (mdbg_reader_open_mt) that also pack their pieces to 2 bits
+ * per base (mdbg_reader_next_packed); a reader thread produces batch i+1 while the main thread ingests batch i.
  * Build:  gcc -O2 -Iinclude examples/mdbg_cli.c -Lrust_mdbg_amd -lmdbg_hip -lmdbg_emit -lpthread -Wl,-rpath,$PWD/rust_mdbg_amd -o mdbg_cli
  */
 #define _POSIX_C_SOURCE 200809L
@@ -18,21 +18,22 @@
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
-/* reader thread: one batch ahead of the consumer.  The parallel reader alternates two buffers (a batch stays valid until the call
- * after the next one), so exactly one batch may be outstanding while the next is parsed. */
+/* reader thread: one batch ahead of the consumer.  The reader alternates two buffer sets (a batch stays valid until the call after
+ * the next one), so exactly one batch may be outstanding while the next is parsed and packed. */
 typedef struct feed_t {
     mdbg_reader* rd; uint64_t max_bases;
     pthread_mutex_t mu; pthread_cond_t cv;
     int have, rc;                          /* have: a batch is waiting to be picked up */
-    const uint8_t* bases; const uint64_t* offs; uint64_t n;
+    mdbg_packed_batch pb;
 } feed_t;
 static void* feed_main(void* arg) {
     feed_t* f = (feed_t*)arg;
     for (;;) {
-        const uint8_t* b; const uint64_t* o; uint64_t n;
-        const int rc = mdbg_reader_next(f->rd, f->max_bases, &b, &o, &n);
+        mdbg_packed_batch pb;
+        const int rc = mdbg_reader_next_packed(f->rd, f->max_bases, &pb);
+        const uint64_t n = rc ? 0 : pb.n_reads;
         pthread_mutex_lock(&f->mu);
-        f->bases = b; f->offs = o; f->n = n; f->rc = rc; f->have = 1;
+        f->pb = pb; f->rc = rc; f->have = 1;
         pthread_cond_broadcast(&f->cv);
         while (f->have) pthread_cond_wait(&f->cv, &f->mu);          /* picking batch j up means the consumer is done with batch j-1: its buffer may be reused */
         pthread_mutex_unlock(&f->mu);
@@ -40,10 +41,10 @@ static void* feed_main(void* arg) {
     }
 }
 /* next batch from the reader thread (the previous one must have been fully consumed) */
-static int feed_take(feed_t* f, const uint8_t** bases, const uint64_t** offs, uint64_t* n) {
+static int feed_take(feed_t* f, mdbg_packed_batch* pb) {
     pthread_mutex_lock(&f->mu);
     while (!f->have) pthread_cond_wait(&f->cv, &f->mu);
-    *bases = f->bases; *offs = f->offs; *n = f->n;
+    *pb = f->pb;
     const int rc = f->rc;
     f->have = 0;
     pthread_cond_broadcast(&f->cv);
@@ -98,42 +99,26 @@ int main(int argc, char** argv) {
     mdbg_reader* rd = mdbg_reader_open_mt(input, reference, threads, &err);
     if (!rd) die(NULL, "mdbg_reader_open", err);
     uint64_t n_reads = 0, n_bases = 0, first = 0;
-    double t_wait = 0, t_pack = 0, t_gpu = 0;                       /* --timing: where the ingest loop spends its time */
-    if (threads > 1 && mdbg_reader_is_parallel(rd)) {
+    double t_wait = 0, t_gpu = 0;                                   /* --timing: where the ingest loop spends its time */
+    if (threads > 1) {                                              /* any input: the streaming reader (.gz, .lz4) packs on the reader thread */
         /* reader thread one batch ahead; this thread packs to 2 bits per base and ingests */
         feed_t f; memset(&f, 0, sizeof f); f.rd = rd; f.max_bases = batch_bases;
         pthread_mutex_init(&f.mu, NULL); pthread_cond_init(&f.cv, NULL);
         pthread_t th; pthread_create(&th, NULL, feed_main, &f);
-        uint64_t* words = NULL, words_cap = 0, exc_cap = 1024;
-        uint64_t* exc_pos = (uint64_t*)malloc(exc_cap * 8); uint8_t* exc_val = (uint8_t*)malloc(exc_cap);
         for (;;) {
-            const uint8_t* bases; const uint64_t* offs; uint64_t n;
+            mdbg_packed_batch pb;
             double ta = now_s();
-            int rc = feed_take(&f, &bases, &offs, &n);
+            int rc = feed_take(&f, &pb);
             t_wait += now_s() - ta;
-            if (rc) die(NULL, "mdbg_reader_next", rc);
-            if (!n) break;
+            if (rc) die(NULL, "mdbg_reader_next_packed", rc);
+            if (!pb.n_reads) break;
             ta = now_s();
-            const uint64_t nb = offs[n], nw = mdbg_packed_words(nb);
-            if (nw > words_cap) { free(words); words_cap = nw + nw / 8 + 64; words = (uint64_t*)malloc(words_cap * 8); }
-            uint64_t n_exc = 0;
-            rc = mdbg_pack_reads(bases, nb, words, exc_pos, exc_val, exc_cap, &n_exc, threads);
-            if (rc == MDBG_E_CAPACITY) {                             /* more bytes outside ACGT than expected: make room, pack again */
-                exc_cap = n_exc + 1024; free(exc_pos); free(exc_val);
-                exc_pos = (uint64_t*)malloc(exc_cap * 8); exc_val = (uint8_t*)malloc(exc_cap);
-                rc = mdbg_pack_reads(bases, nb, words, exc_pos, exc_val, exc_cap, &n_exc, threads);
-            }
-            if (rc) die(NULL, "mdbg_pack_reads", rc);
-            t_pack += now_s() - ta; ta = now_s();
-            mdbg_packed_batch pb; memset(&pb, 0, sizeof pb);
-            pb.words = words; pb.offsets = offs; pb.n_reads = n; pb.exc_pos = exc_pos; pb.exc_val = exc_val; pb.n_exc = n_exc;
             rc = mdbg_ingest_batch_packed(ctx, &pb, first);
             if (rc) die(ctx, "mdbg_ingest_batch_packed", rc);
             t_gpu += now_s() - ta;
-            first += n; n_reads += n; n_bases += nb;
+            first += pb.n_reads; n_reads += pb.n_reads; n_bases += pb.offsets[pb.n_reads];
         }
         pthread_join(th, NULL);
-        free(words); free(exc_pos); free(exc_val);
     } else for (;;) {
         const uint8_t* bases; const uint64_t* offs; uint64_t n;
         int rc = mdbg_reader_next(rd, batch_bases, &bases, &offs, &n);
@@ -162,8 +147,8 @@ int main(int argc, char** argv) {
     snprintf(path, sizeof path, "%s.gfa", prefix);
     rc = mdbg_emit_write_gfa(path, &nodes, &edges);
     if (rc) die(NULL, "mdbg_emit_write_gfa", rc);
-    if (timing) fprintf(stderr, "timing: %llu reads, %llu bases; ingest %.3f s, to .gfa %.3f s (%.2f Gbases/s; context creation not included); ingest loop: waiting for the reader %.3f, packing %.3f, mdbg_ingest_batch_packed %.3f s\n",
-                        (unsigned long long)n_reads, (unsigned long long)n_bases, t_ingest - t0, now_s() - t0, (double)n_bases / (now_s() - t0) / 1e9, t_wait, t_pack, t_gpu);
+    if (timing) fprintf(stderr, "timing: %llu reads, %llu bases; ingest %.3f s, to .gfa %.3f s (%.2f Gbases/s; context creation not included); ingest loop: waiting for the reader %.3f, mdbg_ingest_batch_packed %.3f s\n",
+                        (unsigned long long)n_reads, (unsigned long long)n_bases, t_ingest - t0, now_s() - t0, (double)n_bases / (now_s() - t0) / 1e9, t_wait, t_gpu);
     if (write_sequences) {                                          /* second pass over the input: the node sequences */
         snprintf(path, sizeof path, "%s.0.sequences", prefix);
         mdbg_seqfile* sf = mdbg_seqfile_open(path, p.k, p.l, &err);

@@ -63,6 +63,12 @@ mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threa
 int mdbg_reader_is_parallel(const mdbg_reader* r);      /* 1: the file is mapped and parsed by several threads (two alternating batch buffers) */
 void mdbg_reader_close(mdbg_reader* r);
 
+/* The next batch straight in the 2-bit packed layout (mdbg_packed_batch of mdbg_hip.h, HOST memory owned by the reader): what
+ * mdbg_reader_next + mdbg_pack_reads would give, without the ASCII copy of the batch in between — with a parallel reader every parser
+ * thread packs its own piece.  out->n_reads == 0 at end of file; the number of bases is out->offsets[out->n_reads].  The arrays stay valid
+ * until the call AFTER the next one (two alternating sets), for every kind of reader.  Do not mix with mdbg_reader_next on one reader. */
+int mdbg_reader_next_packed(mdbg_reader* r, uint64_t max_bases, mdbg_packed_batch* out);
+
 /* ---- host packer for mdbg_ingest_batch_packed (layout: mdbg_packed_batch in mdbg_hip.h) -----------------------------
  * Replaces the per-read String copy of src/main.rs:733-739: the reader's ASCII batch is squeezed to 2 bits per base
  * (two 32-bit planes per 32 bases) before it crosses PCIe.  words: (n_bases + 31) / 32 entries.  Bytes outside "ACGT" go

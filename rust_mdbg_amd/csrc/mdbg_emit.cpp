@@ -332,6 +332,9 @@ struct mdbg_reader {
     u8* big2 = nullptr; size_t big2_cap = 0; std::vector<u64> offs2;      // ... the previous batch: the parallel path alternates two buffers, so a
                                                               // batch stays valid while the next one is being read (a packer thread can work on it)
     std::vector<std::vector<u8>> piece_bases; std::vector<std::vector<u64>> piece_lens;      // per-thread parse buffers, kept across batches (no fresh page faults)
+    // mdbg_reader_next_packed: the batch as 2-bit words + exception list (two alternating sets, like big / big2)
+    u64* pw = nullptr; size_t pw_cap = 0; u64* pw2 = nullptr; size_t pw2_cap = 0;
+    std::vector<u64> pexc_pos, pexc_pos2; std::vector<u8> pexc_val, pexc_val2;
     std::vector<u8> bases; std::vector<u64> offs;            // current batch
     std::vector<u8> pending; bool have_pending = false;      // a parsed record that did not fit the previous batch
     bool fill() {                                             // more input; false at EOF
@@ -449,7 +452,9 @@ size_t next_record_start(const u8* m, size_t n, size_t p, bool fasta) {
 }
 }  // namespace
 
-static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases) {
+// ascii_out: the sequences are copied side by side into r->big; otherwise they stay in the per-thread pieces (mdbg_reader_next_packed
+// packs them from there) and only the offsets are laid out
+static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_out = true) {
     r->offs.assign(1, 0);
     const u8* m = r->map; const size_t n = r->map_size;
     if (r->map_cur >= n) return MDBG_OK;
@@ -482,10 +487,10 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases) {
     size_t total = 0, reads = 0;
     std::vector<size_t> base0(T), read0(T);
     for (int i = 0; i < T; ++i) { base0[i] = total; read0[i] = reads; total += pc[i].bases.size(); reads += pc[i].lens.size(); }
-    if (total + 64 > r->big_cap) { free(r->big); r->big_cap = total + total / 8 + 4096; r->big = (u8*)malloc(r->big_cap); if (!r->big) { r->big_cap = 0; return MDBG_E_NOMEM; } }
+    if (ascii_out && total + 64 > r->big_cap) { free(r->big); r->big_cap = total + total / 8 + 4096; r->big = (u8*)malloc(r->big_cap); if (!r->big) { r->big_cap = 0; return MDBG_E_NOMEM; } }
     r->offs.resize(reads + 1);
     auto place = [&](int i) {
-        if (!pc[i].bases.empty()) memcpy(r->big + base0[i], pc[i].bases.data(), pc[i].bases.size());
+        if (ascii_out && !pc[i].bases.empty()) memcpy(r->big + base0[i], pc[i].bases.data(), pc[i].bases.size());
         u64 o = base0[i];
         for (size_t j = 0; j < pc[i].lens.size(); ++j) { r->offs[read0[i] + j] = o; o += pc[i].lens[j]; }
     };
@@ -543,7 +548,7 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
     return r->io_error ? MDBG_E_PARAM : MDBG_OK;             // a malformed compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->map) munmap((void*)r->map, r->map_size); free(r->big); free(r->big2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
+void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->map) munmap((void*)r->map, r->map_size); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
 
 }  // extern "C"
 
@@ -593,7 +598,83 @@ void pack_range(const uint8_t* bases, uint64_t n_bases, uint64_t w0, uint64_t w1
 }
 }  // namespace
 
+// Reader batches straight to the packed layout: every parser thread packs the sequences of its own piece (they are contiguous in its
+// buffer) into the words that lie entirely inside the piece's range of the batch; the few words that straddle two pieces are assembled
+// from per-thread partial contributions afterwards.  No ASCII copy of the batch is written.
+namespace {
+struct Partial { u64 word; u32 lo, hi; };
+void pack_piece(const u8* src, u64 B, u64 E, u64* words, ExcList& ex, std::vector<Partial>& parts, bool avx2) {
+    if (E <= B) return;
+    auto partial = [&](u64 a, u64 b) {                       // bases [a, b) inside one word
+        u32 lo, hi, bad;
+        pack32_scalar(src + (a - B), (unsigned)(b - a), lo, hi, bad);
+        const unsigned sh = (unsigned)(a & 31);
+        parts.push_back(Partial{a >> 5, lo << sh, hi << sh});
+        while (bad) { const unsigned i = (unsigned)__builtin_ctz(bad); bad &= bad - 1; ex.pos.push_back(a + i); ex.val.push_back(src[a - B + i]); }
+    };
+    const u64 w_lo = (B + 31) >> 5, w_hi = E >> 5;           // full words [w_lo, w_hi)
+    if (w_lo > w_hi) { partial(B, E); return; }              // the piece lies inside one word
+    if (B & 31) partial(B, w_lo << 5);
+    for (u64 w = w_lo; w < w_hi; ++w) {
+        const u8* p = src + ((w << 5) - B);
+        u32 lo, hi, bad;
+        if (avx2) pack32_avx2(p, lo, hi, bad); else pack32_sse2(p, lo, hi, bad);
+        words[w] = (u64)lo | ((u64)hi << 32);
+        while (bad) { const unsigned i = (unsigned)__builtin_ctz(bad); bad &= bad - 1; ex.pos.push_back((w << 5) + i); ex.val.push_back(p[i]); }
+    }
+    if (E & 31) partial(w_hi << 5, E);
+}
+int reader_pack_pieces(mdbg_reader* r, u64 total) {
+    const size_t T = r->piece_bases.size();
+    const u64 nw = (total + 31) / 32;
+    if (nw + 8 > r->pw_cap) { free(r->pw); r->pw_cap = nw + nw / 8 + 64; r->pw = (u64*)malloc(r->pw_cap * 8); if (!r->pw) { r->pw_cap = 0; return MDBG_E_NOMEM; } }
+    const bool avx2 = __builtin_cpu_supports("avx2");
+    std::vector<u64> base0(T + 1, 0);
+    for (size_t i = 0; i < T; ++i) base0[i + 1] = base0[i] + r->piece_bases[i].size();
+    std::vector<ExcList> ex(T); std::vector<std::vector<Partial>> parts(T);
+    auto work = [&](size_t i) { pack_piece(r->piece_bases[i].data(), base0[i], base0[i + 1], r->pw, ex[i], parts[i], avx2); };
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < T; ++i) th.emplace_back(work, i);
+        if (T) work(0);
+        for (auto& x : th) x.join();
+    }
+    for (size_t i = 0; i < T; ++i) for (const Partial& q : parts[i]) r->pw[q.word] = 0;       // words shared by pieces: clear, then OR the contributions
+    for (size_t i = 0; i < T; ++i) for (const Partial& q : parts[i]) r->pw[q.word] |= (u64)q.lo | ((u64)q.hi << 32);
+    r->pexc_pos.clear(); r->pexc_val.clear();
+    for (size_t i = 0; i < T; ++i) { r->pexc_pos.insert(r->pexc_pos.end(), ex[i].pos.begin(), ex[i].pos.end()); r->pexc_val.insert(r->pexc_val.end(), ex[i].val.begin(), ex[i].val.end()); }
+    return MDBG_OK;
+}
+}  // namespace
+
 extern "C" {
+int mdbg_reader_next_packed(mdbg_reader* r, uint64_t max_bases, mdbg_packed_batch* out) {
+    if (!r || !out) return MDBG_E_PARAM;
+    memset(out, 0, sizeof *out);
+    std::swap(r->pw, r->pw2); std::swap(r->pw_cap, r->pw2_cap); r->pexc_pos.swap(r->pexc_pos2); r->pexc_val.swap(r->pexc_val2);
+    if (r->map) {
+        int e;
+        r->offs.swap(r->offs2);
+        do e = reader_next_parallel(r, max_bases, false); while (!e && r->offs.size() == 1 && r->map_cur < r->map_size);
+        if (e) return e;
+        if (r->offs.size() == 1) { r->pexc_pos.clear(); r->pexc_val.clear(); out->offsets = r->offs.data(); return MDBG_OK; }      // end of file (the pieces still hold the last batch)
+        const u64 total = r->offs.back();
+        e = reader_pack_pieces(r, total); if (e) return e;
+    } else {                                                   // streaming reader (.gz, .lz4, one thread): parse, then pack the ASCII batch
+        const uint8_t* b; const uint64_t* o; uint64_t n;
+        r->offs.swap(r->offs2);                                // the offsets handed out last stay intact during this call
+        int e = mdbg_reader_next(r, max_bases, &b, &o, &n); if (e) return e;
+        const u64 total = r->offs.back(), nw = (total + 31) / 32;
+        if (nw + 8 > r->pw_cap) { free(r->pw); r->pw_cap = nw + nw / 8 + 64; r->pw = (u64*)malloc(r->pw_cap * 8); if (!r->pw) { r->pw_cap = 0; return MDBG_E_NOMEM; } }
+        ExcList ex;
+        pack_range(b, total, 0, nw, r->pw, ex, __builtin_cpu_supports("avx2"));
+        r->pexc_pos.swap(ex.pos); r->pexc_val.swap(ex.val);
+    }
+    out->words = r->pw; out->offsets = r->offs.data(); out->n_reads = r->offs.size() - 1;
+    out->exc_pos = r->pexc_pos.data(); out->exc_val = r->pexc_val.data(); out->n_exc = r->pexc_pos.size();
+    return MDBG_OK;
+}
+
 uint64_t mdbg_packed_words(uint64_t n_bases) { return (n_bases + 31) / 32; }
 
 int mdbg_pack_reads(const uint8_t* bases, uint64_t n_bases, uint64_t* words, uint64_t* exc_pos, uint8_t* exc_val, uint64_t exc_cap,

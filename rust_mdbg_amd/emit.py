@@ -119,7 +119,8 @@ class Emitter:
 
 
 # ---- host ingest (include/mdbg_emit.h: mdbg_reader_*) -----------------------------------------------------
-READER_EXPORTS = ["mdbg_reader_open", "mdbg_reader_open_mt", "mdbg_reader_next", "mdbg_reader_is_fasta", "mdbg_reader_is_parallel", "mdbg_reader_close"]
+READER_EXPORTS = ["mdbg_reader_open", "mdbg_reader_open_mt", "mdbg_reader_next", "mdbg_reader_next_packed", "mdbg_reader_is_fasta", "mdbg_reader_is_parallel",
+                  "mdbg_reader_close"]
 
 
 class Reader:
@@ -159,6 +160,28 @@ class Reader:
             nb = int(offs[-1])
             bases = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), shape=(max(nb, 1),))[:nb] if b.value else np.zeros(0, np.uint8)
             yield (bases.copy(), offs.copy()) if copy else (bases, offs)
+
+    def batches_packed(self, max_bases=256 << 20, copy=True):
+        """yields dicts in the layout of pack_reads / Mdbg.ingest_packed (words, offsets, exc_pos, exc_val, n_bases): the reader packs while it
+        parses (mdbg_reader_next_packed).  copy=False: views into the reader's buffers, valid until the batch after the next one is asked for"""
+        from .api import PackedBatch
+        self.L.mdbg_reader_next_packed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(PackedBatch)]
+        while True:
+            pb = PackedBatch()
+            rc = self.L.mdbg_reader_next_packed(self.h, max_bases, C.byref(pb))
+            if rc:
+                raise RuntimeError("mdbg_reader_next_packed failed: %d" % rc)
+            n = int(pb.n_reads)
+            if n == 0:
+                return
+            offs = np.ctypeslib.as_array(C.cast(pb.offsets, C.POINTER(C.c_uint64)), shape=(n + 1,))
+            nb = int(offs[-1])
+            nw, ne = (nb + 31) // 32, int(pb.n_exc)
+            words = np.ctypeslib.as_array(C.cast(pb.words, C.POINTER(C.c_uint64)), shape=(max(nw, 1),))[:nw]
+            ep = np.ctypeslib.as_array(C.cast(pb.exc_pos, C.POINTER(C.c_uint64)), shape=(max(ne, 1),))[:ne] if ne else np.zeros(0, np.uint64)
+            ev = np.ctypeslib.as_array(C.cast(pb.exc_val, C.POINTER(C.c_uint8)), shape=(max(ne, 1),))[:ne] if ne else np.zeros(0, np.uint8)
+            d = dict(words=words, offsets=offs, exc_pos=ep, exc_val=ev, n_bases=nb)
+            yield {f: (v.copy() if copy and hasattr(v, "copy") else v) for f, v in d.items()}
 
     def close(self):
         if self.h:

@@ -5,9 +5,10 @@ GPU like seq_io's reader thread, src/main.rs:830-839), process_read_aux on batch
 (src/main.rs:1006-1117), and the .sequences file (one LZ4-frame file instead of one per worker thread)."""
 import queue
 import threading
+import time
 
 from .api import Mdbg
-from .emit import Emitter, Reader, lmer_filter_from_counts, pack_reads
+from .emit import Emitter, Reader, lmer_filter_from_counts
 
 
 def apply_lmer_counts(m, lmer_counts, l, density, lmer_counts_min, lmer_counts_max):
@@ -38,68 +39,30 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                 pass
         return False
 
+    free = threading.Semaphore(2)          # packed batches are views into the reader's two alternating buffer sets: at most two may be outstanding
+
     def produce():
         try:
-            import numpy as np
-            ring = [np.empty(batch_bases // 32 + 64, dtype=np.uint64) for _ in range(4)] if packed else None      # queue depth 2 + one being filled + one being ingested
             with Reader(path, strip_newlines, threads=threads) as r:
-                if packed and r.parallel:
-                    # three stages: the reader parses batch i+1 (it alternates two buffers) while this thread packs batch i and the
-                    # consumer ingests batch i-1
-                    q1 = queue.Queue(maxsize=1)
-                    free = threading.Semaphore(2)       # the reader may start call j once batch j-2 has been packed
-
-                    def read():
-                        try:
-                            it = r.batches(batch_bases, copy=False)
-                            while True:
-                                while not free.acquire(timeout=0.2):
-                                    if stop.is_set():
-                                        return
-                                item = next(it, None)
-                                while not stop.is_set():
-                                    try:
-                                        q1.put(item, timeout=0.2)
-                                        break
-                                    except queue.Full:
-                                        pass
-                                if item is None or stop.is_set():
-                                    return
-                        except BaseException as e:          # noqa: BLE001
-                            q1.put(e)
-
-                    rt = threading.Thread(target=read, daemon=True)
-                    rt.start()
-                    try:
-                        bi = 0
-                        while True:
-                            try:
-                                item = q1.get(timeout=0.2)
-                            except queue.Empty:
-                                if stop.is_set():
-                                    return
-                                continue
-                            if item is None:
-                                break
-                            if isinstance(item, BaseException):
-                                raise item
-                            bases, offs = item
-                            pk = pack_reads(bases, offs.copy(), threads=threads, words_buf=ring[bi % 4])
-                            nb = len(bases)
-                            free.release()
-                            bi += 1
-                            if not put((pk, None, nb)):
+                if packed:
+                    # the reader packs while it parses (mdbg_reader_next_packed); batch i+1 is produced while batch i is ingested
+                    it = r.batches_packed(batch_bases, copy=False)
+                    while True:
+                        while not free.acquire(timeout=0.2):
+                            if stop.is_set():
                                 return
-                    finally:
-                        stop_reader = stop.is_set()
-                        if stop_reader:
-                            free.release()
-                        rt.join(timeout=5)
-                else:
-                    for bi, (bases, offs) in enumerate(r.batches(batch_bases, copy=not packed)):       # packed: the batch is consumed here, before the next one is read
-                        item = (pack_reads(bases, offs.copy(), threads=threads, words_buf=ring[bi % 4]), None, len(bases)) if packed else (bases, offs, len(bases))
-                        if not put(item):
+                        pk = next(it, None)
+                        if pk is None:
+                            break
+                        if not put((pk, None, pk["n_bases"])):
                             return
+                    put(None)
+                    while not stop.is_set():      # the reader's buffers must outlive the last batch's ingest: wait until the consumer is done
+                        time.sleep(0.005)
+                    return
+                for bases, offs in r.batches(batch_bases):
+                    if not put((bases, offs, len(bases))):
+                        return
             put(None)
         except BaseException as e:          # noqa: BLE001
             put(e)
@@ -107,7 +70,6 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
     th = threading.Thread(target=produce, daemon=True)
     th.start()
     n_reads = n_bases = 0
-    import time
     tm = {}
     t0 = time.perf_counter()
     try:
@@ -123,6 +85,7 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                 payload, offs, nb = item
                 if packed:
                     m.ingest_packed(payload, n_reads)
+                    free.release()                      # this batch's buffers may be reused
                 else:
                     m.ingest(payload, offs, n_reads)    # ctypes releases the GIL: the reader thread parses the next batch meanwhile
                 n_reads += (len(payload["offsets"]) if packed else len(offs)) - 1

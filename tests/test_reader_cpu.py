@@ -191,3 +191,52 @@ def test_parallel_reader_falls_back_for_compressed_input(example_reads, tmp_path
     e = tmp_path / "empty.fa"
     e.write_bytes(b"")
     assert collect(str(e), threads=4) == ([], True)
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fasta-multiline-strip", "fastq", "fastq-crlf", "gz"])
+def test_packed_reader_equals_reader_plus_packer(kind, tmp_path):
+    """mdbg_reader_next_packed (every parser thread packs its own piece; words that straddle pieces assembled afterwards) against
+    mdbg_reader_next + mdbg_pack_reads on the same file, same batch cuts: words, offsets and exception lists identical"""
+    import random
+    rnd = random.Random(7)
+    fastq = kind.startswith("fastq")
+    data = random_records(rnd, 500, fastq, crlf="crlf" in kind, multiline="multiline" in kind)      # the records hold N: exception lists are not empty
+    name = "r.fastq" if fastq else "r.fa"
+    if kind == "gz":
+        name += ".gz"
+        p = tmp_path / name
+        with gzip.open(p, "wb") as f:
+            f.write(data)
+    else:
+        p = tmp_path / name
+        p.write_bytes(data)
+    strip = kind.endswith("strip")
+    for threads in (1, 2, 5, 16):
+        for max_bases in (1 << 30, 100_000, 7_000, 33):
+            with E.Reader(str(p), strip, threads=threads) as ra, E.Reader(str(p), strip, threads=threads) as rb:
+                n = 0
+                for (bases, offs), pk in zip(ra.batches(max_bases), rb.batches_packed(max_bases)):
+                    exp = E.pack_reads(bases, offs, threads=3)
+                    assert pk["n_bases"] == len(bases) and np.array_equal(pk["offsets"], offs)
+                    assert np.array_equal(pk["words"], exp["words"]), (threads, max_bases, n)
+                    assert np.array_equal(pk["exc_pos"], exp["exc_pos"]) and np.array_equal(pk["exc_val"], exp["exc_val"])
+                    assert len(pk["exc_pos"]) > 0 or len(bases) < 2000
+                    n += len(offs) - 1
+                assert n == 500
+                assert list(ra.batches(max_bases)) == [] and list(rb.batches_packed(max_bases)) == []
+
+
+def test_packed_reader_buffers_alternate(tmp_path):
+    """copy=False views of batch i stay intact while batch i+1 is produced"""
+    import random
+    data = random_records(random.Random(3), 300, False)
+    p = tmp_path / "r.fa"
+    p.write_bytes(data)
+    for threads in (1, 4):
+        with E.Reader(str(p), threads=threads) as r:
+            it = r.batches_packed(40_000, copy=False)
+            prev = next(it)
+            snap = {f: (np.array(v, copy=True) if hasattr(v, "shape") else v) for f, v in prev.items()}
+            for cur in it:
+                assert all(np.array_equal(prev[f], snap[f]) for f in ("words", "offsets", "exc_pos", "exc_val"))
+                prev, snap = cur, {f: (np.array(v, copy=True) if hasattr(v, "shape") else v) for f, v in cur.items()}
