@@ -37,6 +37,11 @@ typedef struct mdbg_seqfile mdbg_seqfile;
 mdbg_seqfile* mdbg_seqfile_open(const char* path, uint32_t k, uint32_t l, int* err);
 int mdbg_seqfile_write_batch(mdbg_seqfile* f, const mdbg_nodes* nodes, const uint8_t* bases, const uint64_t* offsets,
                              uint64_t n_reads, uint64_t first_read_ordinal);
+/* The same for the nodes i with i % n_parts == part only: the reference writes one `.sequences` file per worker thread
+ * ("{prefix}.{thread}.sequences", src/main.rs:614-630) and its readers take all of them; n_parts files written by n_parts threads, each
+ * calling this with its own file and part on the same batch, give the same set of lines in parallel. */
+int mdbg_seqfile_write_batch_part(mdbg_seqfile* f, const mdbg_nodes* nodes, uint32_t part, uint32_t n_parts, const uint8_t* bases,
+                                  const uint64_t* offsets, uint64_t n_reads, uint64_t first_read_ordinal);
 int mdbg_seqfile_close(mdbg_seqfile* f);
 
 /* ---- host ingest: FASTA / FASTQ, optionally gzip-compressed, into the batch layout of

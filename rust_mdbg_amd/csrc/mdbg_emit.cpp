@@ -200,25 +200,36 @@ mdbg_seqfile* mdbg_seqfile_open(const char* path, uint32_t k, uint32_t l, int* e
     return s;
 }
 
-int mdbg_seqfile_write_batch(mdbg_seqfile* s, const mdbg_nodes* nd, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t first) {
-    if (!s || !nd || !offsets || (n_reads && !bases && offsets[n_reads])) return MDBG_E_PARAM;
+static inline void put_u64s(std::string& out, u64 v) {
+    char t[20]; int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) out.push_back(t[--n]);
+}
+// the lines of the nodes i with i % n_parts == part whose A-th sighting lies in this batch
+static int seqfile_write_part(mdbg_seqfile* s, const mdbg_nodes* nd, uint32_t part, uint32_t n_parts, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t first) {
+    if (!s || !nd || !offsets || (n_reads && !bases && offsets[n_reads]) || !n_parts || part >= n_parts) return MDBG_E_PARAM;
     const u32 k = nd->k;
-    char num[64];
-    for (u64 i = 0; i < nd->n; ++i) {
+    for (u64 i = part; i < nd->n; i += n_parts) {
         const u64 r = nd->src_read[i];
         if (r < first || r >= first + n_reads) continue;
         const u64 ro = offsets[r - first], a = nd->src_start[i], b = nd->src_end[i];
         if (ro + b > offsets[r - first + 1] || a > b) return MDBG_E_PARAM;
-        snprintf(num, sizeof num, "%u\t[", nd->index[i]); s->buf += num;                           // main.rs:702: {index}\t{node:?}\t{seq}\t*\t{origin}\t{shift:?}
-        for (u32 j = 0; j < k; ++j) { snprintf(num, sizeof num, j ? ", %llu" : "%llu", (unsigned long long)nd->keys[i * k + j]); s->buf += num; }
+        put_u64s(s->buf, nd->index[i]); s->buf += "\t[";                                              // main.rs:702: {index}\t{node:?}\t{seq}\t*\t{origin}\t{shift:?}
+        for (u32 j = 0; j < k; ++j) { if (j) s->buf += ", "; put_u64s(s->buf, nd->keys[i * k + j]); }
         s->buf += "]\t";
         if (nd->reversed[i]) for (u64 p = b; p > a; --p) s->buf += switch_base((char)bases[ro + p - 1]);   // utils::revcomp, main.rs:701
         else s->buf.append((const char*)bases + ro + a, b - a);
-        snprintf(num, sizeof num, "\t*\t*\t(%llu, %llu)\n", (unsigned long long)nd->shift_full[2 * i], (unsigned long long)nd->shift_full[2 * i + 1]);
-        s->buf += num;
+        s->buf += "\t*\t*\t("; put_u64s(s->buf, nd->shift_full[2 * i]); s->buf += ", "; put_u64s(s->buf, nd->shift_full[2 * i + 1]); s->buf += ")\n";
         if (s->buf.size() >= (4u << 20) && !s->flush_block()) return MDBG_E_IO;
     }
     return MDBG_OK;
+}
+int mdbg_seqfile_write_batch(mdbg_seqfile* s, const mdbg_nodes* nd, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t first) {
+    return seqfile_write_part(s, nd, 0, 1, bases, offsets, n_reads, first);
+}
+int mdbg_seqfile_write_batch_part(mdbg_seqfile* s, const mdbg_nodes* nd, uint32_t part, uint32_t n_parts, const uint8_t* bases, const uint64_t* offsets,
+                                  uint64_t n_reads, uint64_t first) {
+    return seqfile_write_part(s, nd, part, n_parts, bases, offsets, n_reads, first);
 }
 
 int mdbg_seqfile_close(mdbg_seqfile* s) {

@@ -14,7 +14,7 @@ _LIB = None
 from .api import EdgeList as Edges          # one type for the host emitter's and the GPU's edge list (include/mdbg_hip.h)
 
 
-EXPORTS = ["mdbg_lmer_filter_from_counts", "mdbg_lmer_filter_free", "mdbg_packed_words", "mdbg_pack_reads", "mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
+EXPORTS = ["mdbg_lmer_filter_from_counts", "mdbg_lmer_filter_free", "mdbg_packed_words", "mdbg_pack_reads", "mdbg_seqfile_write_batch_part", "mdbg_emit_create", "mdbg_emit_destroy", "mdbg_emit_edges", "mdbg_emit_write_gfa", "mdbg_seqfile_open",
            "mdbg_seqfile_write_batch", "mdbg_seqfile_close"]
 
 
@@ -34,6 +34,7 @@ def load_library():
         L.mdbg_seqfile_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
         L.mdbg_seqfile_write_batch.argtypes = [vp, C.POINTER(Nodes), vp, vp, C.c_uint64, C.c_uint64]
         L.mdbg_seqfile_close.argtypes = [vp]
+        L.mdbg_seqfile_write_batch_part.argtypes = [vp, C.POINTER(Nodes), C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_uint64]
         L.mdbg_packed_words.restype = C.c_uint64
         L.mdbg_packed_words.argtypes = [C.c_uint64]
         L.mdbg_pack_reads.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
@@ -105,6 +106,34 @@ class Emitter:
             rc = self.L.mdbg_seqfile_close(f)
         if rc:
             raise RuntimeError("mdbg_seqfile_close failed: %d" % rc)
+
+    def write_sequences_parallel(self, prefix, nodes, l, batches, threads):
+        """`threads` files "<prefix>.<t>.sequences" (the reference's one-file-per-worker layout, src/main.rs:614-630) written by as many
+        threads: every batch is handed to all of them, thread t writes the lines of the nodes i with i % threads == t.  -> the paths"""
+        from concurrent.futures import ThreadPoolExecutor
+        nt = nodes if isinstance(nodes, NodeTable) else NodeTable(nodes)
+        paths = ["%s.%d.sequences" % (prefix, t) for t in range(threads)]
+        files, err = [], C.c_int()
+        try:
+            for p in paths:
+                f = self.L.mdbg_seqfile_open(p.encode(), nt.c.k, l, C.byref(err))
+                if not f:
+                    raise RuntimeError("mdbg_seqfile_open failed: %d" % err.value)
+                files.append(f)
+            with ThreadPoolExecutor(max_workers=threads) as pool:
+                for bases, offsets, first in batches:
+                    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+                    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+                    job = lambda t: self.L.mdbg_seqfile_write_batch_part(files[t], C.byref(nt.c), t, threads, bases.ctypes.data, offsets.ctypes.data,
+                                                                         len(offsets) - 1, first)      # ctypes releases the GIL
+                    for rc in pool.map(job, range(threads)):
+                        if rc:
+                            raise RuntimeError("mdbg_seqfile_write_batch_part failed: %d" % rc)
+        finally:
+            rcs = [self.L.mdbg_seqfile_close(f) for f in files]
+        if any(rcs):
+            raise RuntimeError("mdbg_seqfile_close failed: %s" % rcs)
+        return paths
 
     def close(self):
         if self.h:

@@ -108,11 +108,16 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
     if write_sequences:                              # second pass over the input for the node sequences
         def again():
             first = 0
-            with Reader(path, strip_newlines) as r:
-                for bases, offs in r.batches(batch_bases):
+            with Reader(path, strip_newlines, threads=threads) as r:
+                for bases, offs in r.batches(batch_bases, copy=False):      # consumed before the next batch is asked for
                     yield bases, offs, first
                     first += len(offs) - 1
-        em.write_sequences(prefix + ".0.sequences", nodes, l, again())
+        t1 = time.perf_counter()
+        if threads > 1:                              # one file per writer thread, like the reference's worker threads (main.rs:614-630)
+            em.write_sequences_parallel(prefix, nodes, l, again(), min(threads, 16))
+        else:
+            em.write_sequences(prefix + ".0.sequences", nodes, l, again())
+        tm["sequences"] = time.perf_counter() - t1
     return dict(n_reads=n_reads, n_bases=n_bases, n_minimizers=stats["n_minimizers"], n_windows=stats["n_windows"],
                 n_nodes_before=nodes["n_nodes_before"], n_nodes=nodes["n_nodes"], n_edges=len(edges["n1"]),
                 presimp_removed=edges["presimp_removed"], seconds_until={k_: round(v, 4) for k_, v in tm.items()})

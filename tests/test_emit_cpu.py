@@ -131,3 +131,25 @@ def test_write_failures_are_io_errors(example_reads, tmp_path):
         em.write_sequences("/dev/full", r, c["l"], [(b, o, 0)])
     with pytest.raises(RuntimeError, match="-7"):
         em.write_sequences(str(tmp_path / "no_such_dir" / "x.sequences"), r, c["l"], [(b, o, 0)])
+
+
+def test_parallel_sequences_writer_same_lines(example_reads, tmp_path):
+    """write_sequences_parallel: T files written by T threads hold together exactly the lines of the single file"""
+    gold = json.load(open(os.path.join(GOLDEN, "example_cfg1.json")))
+    c = gold["config"]
+    r, b, o = oracle_run(example_reads, c["k"], c["l"], c["density"], c["minabund"])
+    em = E.Emitter()
+    one = str(tmp_path / "one.0.sequences")
+    half = len(o) // 2
+    cut = int(o[half])
+    batches = [(b[:cut], o[:half + 1], 0), (b[cut:], o[half:] - o[half], half)]
+    em.write_sequences(one, r, c["l"], batches)
+    paths = em.write_sequences_parallel(str(tmp_path / "par"), r, c["l"], batches, 5)
+    assert [os.path.basename(p) for p in paths] == ["par.%d.sequences" % t for t in range(5)]
+    want = [x for x in read_lz4_frame(one).decode().split("\n") if x and not x.startswith("#")]
+    got = []
+    for p in paths:
+        txt = read_lz4_frame(p).decode().split("\n")
+        assert txt[0].startswith("# k = ")
+        got += [x for x in txt if x and not x.startswith("#")]
+    assert sorted(got) == sorted(want) and len(want) == r["n_nodes"]
