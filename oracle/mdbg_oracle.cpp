@@ -579,32 +579,60 @@ orc_graph_t* orc_graph_from_nodes(uint64_t k, uint64_t n, const uint64_t* keys, 
 // the end (the reference shares one DashMap between its --threads workers, main.rs:595,834).
 // Returns the number of nodes with abundance >= minabund; *n_windows gets the occurrence count.
 struct VecHash { size_t operator()(const Kmer& v) const { u64 h = 0x9E3779B97F4A7C15ULL; for (u64 x : v) { h ^= x; h *= 0xff51afd7ed558ccdULL; h ^= h >> 32; } return (size_t)h; } };
+// Multi-threaded counting variant (bench.py's cpu_baseline): the reference counts into one concurrent map shared by its worker threads
+// (DashMap, src/main.rs:595,834); the port does it in two phases without a shared map — every thread sketches its share of the reads and
+// deals the canonical k-min-mers into one bucket per thread by key hash (flat arrays, k values per key), then every thread counts the
+// bucket it owns — so no thread waits for another and nothing is merged serially.
+struct KeyRef { const u64* p; u32 k; };
+struct KeyRefHash { size_t operator()(const KeyRef& a) const { u64 h = 0x9E3779B97F4A7C15ULL; for (u32 i = 0; i < a.k; ++i) { h ^= a.p[i]; h *= 0xff51afd7ed558ccdULL; h ^= h >> 32; } return (size_t)h; } };
+struct KeyRefEq { bool operator()(const KeyRef& a, const KeyRef& b) const { return std::memcmp(a.p, b.p, (size_t)a.k * 8) == 0; } };
 int64_t orc_count_threaded(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t k, uint64_t l, double density,
                            uint32_t minabund, int already_hpc, int threads, uint64_t* n_windows) {
     if (threads < 1) threads = 1;
-    std::vector<std::unordered_map<Kmer, u32, VecHash>> maps(threads);
-    std::vector<u64> wins(threads, 0); std::vector<int> errs(threads, 0);
-    auto work = [&](int t) {
-        u64 lo = n_reads * t / threads, hi = n_reads * (t + 1) / threads;
+    const size_t P = (size_t)threads;
+    std::vector<std::vector<std::vector<u64>>> deal(P, std::vector<std::vector<u64>>(P));      // deal[producer][owner]: keys, k values each
+    std::vector<u64> wins(P, 0); std::vector<int> errs(P, 0);
+    auto produce = [&](size_t t) {
+        const u64 lo = n_reads * t / P, hi = n_reads * (t + 1) / P;
+        std::vector<u64> key(k);
         for (u64 r = lo; r < hi; ++r) {
             Sketch sk; int e = extract_density(bases + offsets[r], offsets[r + 1] - offsets[r], l, density, already_hpc != 0, sk);
             if (e) { errs[t] = e; return; }
             const auto& T = sk.transformed;
             if (T.size() > k) for (size_t i = 0; i + k <= T.size(); ++i) {
-                Kmer node(T.begin() + i, T.begin() + i + k);
-                maps[t][kv_normalize(node).first] += 1; ++wins[t];
+                // KmerVec::normalize (src/kmer_vec.rs:34-39): the smaller of the window and its reverse, ties -> reversed (same values)
+                bool rev = true;
+                for (size_t j = 0; j < k; ++j) { const u64 a = T[i + j], b = T[i + k - 1 - j]; if (a != b) { rev = !(a < b); break; } }
+                for (size_t j = 0; j < k; ++j) key[j] = rev ? T[i + k - 1 - j] : T[i + j];
+                const size_t owner = KeyRefHash()(KeyRef{key.data(), (u32)k}) % P;
+                auto& dst = deal[t][owner];
+                dst.insert(dst.end(), key.begin(), key.end());
+                ++wins[t];
             }
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < threads; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-    for (int t = 0; t < threads; ++t) if (errs[t]) return errs[t];
-    auto& base = maps[0];
-    for (int t = 1; t < threads; ++t) { for (auto& kv : maps[t]) base[kv.first] += kv.second; maps[t].clear(); }
+    std::vector<int64_t> solids(P, 0);
+    auto count = [&](size_t o) {
+        size_t n = 0;
+        for (size_t t = 0; t < P; ++t) n += deal[t][o].size() / k;
+        std::unordered_map<KeyRef, u32, KeyRefHash, KeyRefEq> m;
+        m.reserve(n);
+        for (size_t t = 0; t < P; ++t) { const auto& v = deal[t][o]; for (size_t q = 0; q + k <= v.size(); q += k) m[KeyRef{v.data() + q, (u32)k}] += 1; }
+        int64_t s = 0;
+        for (auto& kv : m) if ((u16)kv.second >= (u16)minabund || minabund <= 1) ++s;
+        solids[o] = s;
+    };
+    auto run = [&](auto fn) {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < P; ++t) th.emplace_back(fn, t);
+        fn((size_t)0);
+        for (auto& x : th) x.join();
+    };
+    run(produce);
+    for (size_t t = 0; t < P; ++t) if (errs[t]) return errs[t];
+    run(count);
     int64_t solid = 0; u64 w = 0;
-    for (auto& kv : base) if ((u16)kv.second >= (u16)minabund || minabund <= 1) ++solid;
+    for (auto x : solids) solid += x;
     for (auto x : wins) w += x;
     if (n_windows) *n_windows = w;
     return solid;
