@@ -121,8 +121,9 @@ def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     dt = time.perf_counter() - t
     return {"value": float(offs[r1]) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port",
             "sample": "first %d reads (%.3f Gbases) of the same synthetic workload, %d threads, %.1f s; reads in RAM -> filtered node count; "
-                      "the port counts into one std::unordered_map per thread and merges them serially at the end, which undersells a %d-core box"
-                      % (r1, float(offs[r1]) / 1e9, cores, dt, cores)}
+                      "the port sketches on all threads, deals the canonical k-min-mers into one bucket per thread by key hash and counts "
+                      "every bucket on its own thread (no shared map, no serial merge)"
+                      % (r1, float(offs[r1]) / 1e9, cores, dt)}
 
 
 def api_stats_of(cdist):
