@@ -52,6 +52,14 @@ static int feed_take(feed_t* f, mdbg_packed_batch* pb) {
     return rc;
 }
 
+/* one writer of the .sequences pass: the lines of the nodes i with i % n_parts == part of the current batch, into its own file */
+typedef struct seqjob_t { mdbg_seqfile* sf; const mdbg_nodes* nodes; uint32_t part, n_parts; const uint8_t* bases; const uint64_t* offs; uint64_t n, first; int rc; } seqjob_t;
+static void* seqjob_main(void* arg) {
+    seqjob_t* j = (seqjob_t*)arg;
+    j->rc = mdbg_seqfile_write_batch_part(j->sf, j->nodes, j->part, j->n_parts, j->bases, j->offs, j->n, j->first);
+    return NULL;
+}
+
 static void die(mdbg_ctx* ctx, const char* what, int rc) {
     fprintf(stderr, "%s: %s (%s)\n", what, mdbg_strerror(rc), ctx && mdbg_last_error(ctx) ? mdbg_last_error(ctx) : "");
     exit(1);
@@ -150,24 +158,37 @@ int main(int argc, char** argv) {
     if (timing) fprintf(stderr, "timing: %llu reads, %llu bases; ingest %.3f s, to .gfa %.3f s (%.2f Gbases/s; context creation not included); ingest loop: waiting for the reader %.3f, mdbg_ingest_batch_packed %.3f s\n",
                         (unsigned long long)n_reads, (unsigned long long)n_bases, t_ingest - t0, now_s() - t0, (double)n_bases / (now_s() - t0) / 1e9, t_wait, t_gpu);
     if (write_sequences) {                                          /* second pass over the input: the node sequences */
-        snprintf(path, sizeof path, "%s.0.sequences", prefix);
-        mdbg_seqfile* sf = mdbg_seqfile_open(path, p.k, p.l, &err);
-        if (!sf) die(NULL, "mdbg_seqfile_open", err);
+        /* one file per writer thread, "<prefix>.<t>.sequences", as the reference's worker threads write them (main.rs:614-630) */
+        enum { MAX_WRITERS = 16 };
+        const int nw = threads > MAX_WRITERS ? MAX_WRITERS : threads;
+        mdbg_seqfile* sf[MAX_WRITERS]; seqjob_t job[MAX_WRITERS]; pthread_t th[MAX_WRITERS];
+        for (int t = 0; t < nw; ++t) {
+            snprintf(path, sizeof path, "%s.%d.sequences", prefix, t);
+            sf[t] = mdbg_seqfile_open(path, p.k, p.l, &err);
+            if (!sf[t]) die(NULL, "mdbg_seqfile_open", err);
+        }
         rd = mdbg_reader_open_mt(input, reference, threads, &err);
         if (!rd) die(NULL, "mdbg_reader_open", err);
         first = 0;
+        const double ts = now_s();
         for (;;) {
             const uint8_t* bases; const uint64_t* offs; uint64_t n;
             rc = mdbg_reader_next(rd, 256u << 20, &bases, &offs, &n);
             if (rc) die(NULL, "mdbg_reader_next", rc);
             if (!n) break;
-            rc = mdbg_seqfile_write_batch(sf, &nodes, bases, offs, n, first);
-            if (rc) die(NULL, "mdbg_seqfile_write_batch", rc);
+            for (int t = 0; t < nw; ++t) {
+                seqjob_t jb; jb.sf = sf[t]; jb.nodes = &nodes; jb.part = (uint32_t)t; jb.n_parts = (uint32_t)nw; jb.bases = bases; jb.offs = offs; jb.n = n; jb.first = first; jb.rc = 0;
+                job[t] = jb;
+                if (t) pthread_create(&th[t], NULL, seqjob_main, &job[t]);
+            }
+            seqjob_main(&job[0]);
+            for (int t = 1; t < nw; ++t) pthread_join(th[t], NULL);
+            for (int t = 0; t < nw; ++t) if (job[t].rc) die(NULL, "mdbg_seqfile_write_batch_part", job[t].rc);
             first += n;
         }
         mdbg_reader_close(rd);
-        rc = mdbg_seqfile_close(sf);
-        if (rc) die(NULL, "mdbg_seqfile_close", rc);
+        for (int t = 0; t < nw; ++t) { rc = mdbg_seqfile_close(sf[t]); if (rc) die(NULL, "mdbg_seqfile_close", rc); }
+        if (timing) fprintf(stderr, "timing: .sequences pass %.3f s (%d file%s)\n", now_s() - ts, nw, nw > 1 ? "s" : "");
     }
     mdbg_destroy(ctx);
     return 0;
