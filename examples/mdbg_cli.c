@@ -1,7 +1,7 @@
 /* mdbg_cli.c — the two C ABIs used from plain C, the way rust-mdbg's main() would use them through FFI:
  *   reads.fa[.gz]  ->  mdbg_reader_*  ->  mdbg_ingest_batch[_packed]  ->  mdbg_finalize  ->  mdbg_graph_edges  ->  <prefix>.gfa (+ <prefix>.0.sequences)
  * Same flags as the reference binary for this path (src/main.rs:330-420): -k -l --density --minabund --presimp --prefix --threads
- * --reference --lmer-counts/--lmer_counts_min/--lmer_counts_max --no-basespace.
+ * --reference --skiphpc --syncmers/-s --lmer-counts/--lmer_counts_min/--lmer_counts_max --no-basespace.
  * --threads N > 1: an uncompressed input is mapped and parsed by N threads (mdbg_reader_open_mt) that also pack their pieces to 2 bits
  * per base (mdbg_reader_next_packed); a reader thread produces batch i+1 while the main thread ingests batch i.
  * Build:  gcc -O2 -Iinclude examples/mdbg_cli.c -Lrust_mdbg_amd -lmdbg_hip -lmdbg_emit -lpthread -Wl,-rpath,$PWD/rust_mdbg_amd -o mdbg_cli
@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
     float presimp = 0.01f;
     const char* input = NULL; const char* prefix = "graph"; int write_sequences = 1, threads = 1, reference = 0, timing = 0;
     const char* lmer_counts = NULL; uint32_t lc_min = 2, lc_max = 100000;          /* main.rs:447-448 */
+    int syncmer_s_given = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-k") && i + 1 < argc) p.k = (uint32_t)atoi(argv[++i]);
         else if (!strcmp(argv[i], "-l") && i + 1 < argc) p.l = (uint32_t)atoi(argv[++i]);
@@ -85,10 +86,13 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--lmer_counts_min") && i + 1 < argc) lc_min = (uint32_t)strtoul(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "--lmer_counts_max") && i + 1 < argc) lc_max = (uint32_t)strtoul(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "--timing")) timing = 1;
+        else if (!strcmp(argv[i], "--skiphpc")) p.reads_already_hpc = 1;                         /* main.rs:490 */
+        else if (!strcmp(argv[i], "--syncmers")) { p.scheme = MDBG_SCHEME_SYNCMERS; if (!syncmer_s_given) p.syncmer_s = 4; }       /* main.rs:438,491-495: default s = 4 */
+        else if ((!strcmp(argv[i], "-s") || !strcmp(argv[i], "--s")) && i + 1 < argc) { p.syncmer_s = (uint32_t)atoi(argv[++i]); syncmer_s_given = 1; }
         else if (argv[i][0] != '-') input = argv[i];
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
-    if (!input) { fprintf(stderr, "usage: mdbg_cli reads.fa[.gz] [-k K] [-l L] [--density D] [--minabund A] [--presimp P] [--prefix PFX] [--no-basespace] [--threads N] [--reference] [--lmer-counts FILE [--lmer_counts_min A] [--lmer_counts_max B]] [--timing]\n"); return 2; }
+    if (!input) { fprintf(stderr, "usage: mdbg_cli reads.fa[.gz] [-k K] [-l L] [--density D] [--minabund A] [--presimp P] [--prefix PFX] [--no-basespace] [--threads N] [--reference] [--skiphpc] [--syncmers [-s S]] [--lmer-counts FILE [--lmer_counts_min A] [--lmer_counts_max B]] [--timing]\n"); return 2; }
     if (threads < 1) threads = 1;
 
     int err = 0;

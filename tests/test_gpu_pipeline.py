@@ -107,6 +107,15 @@ def test_plain_c_program_over_the_two_abis(example_reads, tmp_path):
     subprocess.run([exe, plain, "-k", "7", "-l", "10", "--density", "0.004", "--minabund", "2", "--prefix", str(tmp_path / "cl"), "--threads", "3",
                     "--lmer-counts", cf, "--lmer_counts_min", "1", "--lmer_counts_max", "60"], check=True, capture_output=True, text=True)
     assert pc["n_nodes"] > 0 and open(str(tmp_path / "cl.gfa")).read() == open(str(tmp_path / "pyl.gfa")).read()
+    # --syncmers -s / --skiphpc: the reference's flags for the other selection scheme (src/main.rs:490-495)
+    r = subprocess.run([exe, plain, "-k", "5", "-l", "12", "--density", "0.05", "--minabund", "2", "--prefix", str(tmp_path / "cs"), "--syncmers", "-s", "4",
+                        "--skiphpc", "--no-basespace"], check=True, capture_output=True, text=True)
+    b, o = O.concat_reads(example_reads)
+    g = O.Graph(5, 12, 0.05, 2, already_hpc=True, syncmer_s=4)
+    g.ingest(b, o)
+    exp = g.finalize(with_edges=True)
+    assert exp["n_nodes"] > 100
+    assert ("Number of nodes after abundance filter: %d" % exp["n_nodes"]) in r.stdout and ("Number of mdBG edges: %d" % exp["n_edges"]) in r.stdout
 
 
 @pytest.mark.parametrize("threads", [1, 4])
