@@ -468,7 +468,10 @@ orc_lmer_map_t* orc_lmer_map_new(const uint8_t* bytes, const uint64_t* offs, con
     r->err = lmer_map_build(lines, l, density, cmin, cmax, r->m);
     std::vector<std::pair<std::string, u64>> v(r->m.begin(), r->m.end());
     std::sort(v.begin(), v.end());
-    for (const auto& kv : v) { r->dump.insert(r->dump.end(), kv.first.begin(), kv.first.begin() + l); r->dump_hash.push_back(kv.second); }
+    for (const auto& kv : v) {            // keys of another length stay in the map (as in the reference) but can never equal a read's l-mer: not listed
+        if (kv.first.size() != l) continue;
+        r->dump.insert(r->dump.end(), kv.first.begin(), kv.first.end()); r->dump_hash.push_back(kv.second);
+    }
     return r;
 }
 int orc_lmer_map_err(orc_lmer_map_t* m) { return m->err; }
