@@ -293,6 +293,9 @@ def main():
             sq = sq_counters(args)
             if sq:
                 roof.update(valu_util=sq.get("valu_util"), valu_lane_ops_per_base=sq.get("valu_lane_ops_per_base"), sq_source=sq.get("source"))
+            if packed:
+                roof["note"] = ("b_in = 0.25 B/base (2-bit packed input, the north-star layout): the kernel is bound by integer VALU issue, not by HBM "
+                                "(valu_util, valu_lane_ops_per_base; traffic = 1.09x the algorithmic bytes); the same kernel on the b_in = 1.0 accounting is in roofline_ascii")
         roof_ascii = None
         if packed and not routed:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
             for _ in range(2):
