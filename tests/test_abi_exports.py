@@ -44,6 +44,32 @@ def test_struct_layouts_match_header():
     assert api.Nodes.keys.offset == 16 and api.Nodes.n_distinct.offset == 16 + 10 * 8
 
 
+def test_ctypes_mirrors_match_the_c_compiler(tmp_path):
+    """sizes and field offsets of every struct the Python mirrors declare, as gcc lays out the headers' own definitions"""
+    import ctypes as C
+    import subprocess
+    from rust_mdbg_amd import api, dist_c, emit
+    src = tmp_path / "layout.c"
+    fields = {
+        "mdbg_params": (api.Params, ["k", "l", "density", "min_abundance", "reads_already_hpc", "device", "flags", "table_capacity_hint", "scheme", "syncmer_s"]),
+        "mdbg_packed_batch": (api.PackedBatch, ["words", "offsets", "n_reads", "exc_pos", "exc_val", "n_exc"]),
+        "mdbg_nodes": (api.Nodes, ["n", "k", "keys", "index", "abundance", "seqlen", "shift", "shift_full", "src_read", "src_start", "src_end", "reversed", "n_distinct", "n_wrapped"]),
+        "mdbg_stats": (api.Stats, ["n_reads", "n_minimizers", "ms_sketch", "ms_sketch_tile"]),
+        "mdbg_comm": (dist_c.Comm, ["self", "rank", "world", "allgather_u64", "exchange", "allreduce_sum_u64", "exchange_begin", "exchange_wait"]),
+        "mdbg_edges": (emit.Edges, ["n", "n1", "o1", "n2", "o2", "overlap", "presimp_removed"]),
+    }
+    body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (t, t) + "".join('printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (t, f, t, f) for f in fs)
+                   for t, (_, fs) in fields.items())
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "mdbg_dist.h"\n#include "mdbg_emit.h"\nint main(void) {\n' + body + 'return 0; }\n')
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    got = dict(line.split() for line in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().split("\n"))
+    for t, (cls, fs) in fields.items():
+        assert int(got[t]) == C.sizeof(cls), t
+        for f in fs:
+            assert int(got["%s.%s" % (t, f)]) == getattr(cls, f).offset, (t, f)
+
+
 def test_create_without_gpu_fails_cleanly():
     """no silent CPU fallback: without a device mdbg_create reports MDBG_E_DEVICE"""
     import torch
