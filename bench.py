@@ -44,20 +44,48 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
                     help="multi-GPU mode: exchange of sketches + key-partitioned table (default inside a node: 3x faster per rank, profiles/r02_notes.md), or all-to-all of k-min-mer records by key range (the north star's wording)")
-    ap.add_argument("--dist-impl", choices=["py", "c"], default="py",
-                    help="multi-GPU driver: rust_mdbg_amd/dist.py over torch.distributed (chunked, exchange overlapped with the next chunk's sketch), or the "
-                         "library's own C layer (include/mdbg_dist.h: direct RCCL send/recv groups, one round per step)")
+    ap.add_argument("--dist-impl", choices=["py", "c"], default="c",
+                    help="multi-GPU driver: the library's own C layer (include/mdbg_dist.h: direct RCCL send/recv groups, the product boundary; default), or "
+                         "rust_mdbg_amd/dist.py over torch.distributed (the Python harness of the same protocol; the only driver of --dist-mode route)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="multi-GPU: chunks per step; the exchange of chunk c overlaps the sketch of chunk c+1 (0 = 4 in replicate mode, 1 in route mode)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a.gpus)                    # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run --nproc-per-node N with the same N" % (a.gpus, world))
+    if a.dist_mode == "route":
+        a.dist_impl = "py"                     # the record routing exists in the Python harness only
     cfg3 = world > 1 or a.force_dist            # BASELINE.json configs[3] shard per GPU, else configs[2]
     if a.genome_mb is None: a.genome_mb = 375.0 if cfg3 and world > 1 else 140.0
     if a.coverage is None: a.coverage = 52.0 if cfg3 and world > 1 else 50.0
     if a.l is None: a.l = 14 if cfg3 and world > 1 else 12
     if a.density is None: a.density = 0.003 if cfg3 and world > 1 else 0.002
     return a
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run on this node and become
+    that launcher.  Fewer than N visible GPUs is an error, not an N=1 run."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py: --gpus %d needs %d GPUs, %d visible on this node (one rank per GPU; RCCL does not run two ranks on one device)"
+                         % (n, n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def pmc_traffic(bases_per_launch, args, fmt=None):
@@ -149,6 +177,8 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     routed = world > 1 or args.force_dist
@@ -245,11 +275,13 @@ def main():
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        nb = torch.tensor([n_bases], device="cuda", dtype=torch.int64)
+        nb = torch.tensor([n_bases, 1], device="cuda", dtype=torch.int64)      # [bases, 1]: the second sum = ranks RCCL actually reached
         dist.all_reduce(nb)
-        total_bases = int(nb.item())
+        total_bases, n_ranks = int(nb[0].item()), int(nb[1].item())
     else:
-        total_bases = n_bases
+        total_bases, n_ranks = n_bases, 1
+    if n_ranks != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) took part in the all-reduce" % (args.gpus, n_ranks))
     consistent = None
     if routed:               # outside the timed region: the ranks' partitions must add up to the global node count
         loc = torch.tensor([(cdist if cdist is not None else runner).last_local], device="cuda", dtype=torch.int64)
@@ -317,7 +349,7 @@ def main():
         cpu = None
         if args.cpu_seconds > 0:
             cpu = cpu_baseline(m, d_bases, d_off, reads_per_gpu, n_bases, args)
-        out = {"metric": "Gbases/s ingested to k-min-mer graph", "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+        out = {"metric": "Gbases/s ingested to k-min-mer graph", "value": value, "unit": "Gbases/s", "n_gpus": n_ranks, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": ("synthetic human 3 Gb @52x over 8 GPUs (BASELINE.json configs[3]): %.0f Mb of genome and %.1f Gbases of ~15 kb HiFi-shaped reads per GPU, 0.1%% errors"

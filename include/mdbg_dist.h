@@ -60,7 +60,8 @@ typedef struct mdbg_dist mdbg_dist;
 /* p as for mdbg_create (p->device = this rank's GPU).  The comm table is copied. */
 mdbg_dist* mdbg_dist_create(const mdbg_params* p, const mdbg_comm* comm, int* err);
 void mdbg_dist_destroy(mdbg_dist* d);
-/* the rank's local context: for mdbg_get_stats, mdbg_sync, mdbg_last_error, mdbg_synth_reads_device ... (do not ingest through it) */
+/* the rank's local context: for mdbg_get_stats, mdbg_sync, mdbg_last_error, mdbg_synth_reads_device ... (do not ingest through it;
+ * mdbg_query_batch on it returns MDBG_E_STATE: the table holds only the keys this rank owns) */
 mdbg_ctx* mdbg_dist_ctx(mdbg_dist* d);
 
 /* Pipelining inside one ingest call: the batch is cut into `chunks` runs of whole reads (every rank runs `chunks` rounds per call, so all

@@ -84,6 +84,53 @@ BS_HD bs_u32 bs_xor3(bs_u32 a, bs_u32 b, bs_u32 c) {
     return a ^ b ^ c;
 #endif
 }
+// a ^ b ^ c where b and/or c are known to be zero planes (the flags are compile-time constants after unrolling): the three-input
+// logic builtin is opaque to the optimiser, an XOR with a literal zero would otherwise stay an instruction
+BS_HD bs_u32 bs_xor3z(bs_u32 a, bs_u32 b, bool bz, bs_u32 c, bool cz) {
+    if (bz && cz) return a;
+    if (bz) return a ^ c;
+    if (cz) return a ^ b;
+    return bs_xor3(a, b, c);
+}
+// (a ^ ia) | (b ^ ib) | (c ^ ic) with ia/ib/ic = all-ones or zero chosen by the low three bits of inv3 (bit 0: a): one v_bitop3
+// (full rate; v_or3_b32 issues at half rate on gfx950, profiles/r01_g_valu_rates.txt) with the complements folded into the table
+BS_HD bs_u32 bs_or3i(bs_u32 a, bs_u32 b, bs_u32 c, bs_u32 inv3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    switch (inv3 & 7u) {
+        case 0: return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE);
+        case 1: return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEF);
+        case 2: return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFB);
+        case 3: return __builtin_amdgcn_bitop3_b32(a, b, c, 0xBF);
+        case 4: return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFD);
+        case 5: return __builtin_amdgcn_bitop3_b32(a, b, c, 0xDF);
+        case 6: return __builtin_amdgcn_bitop3_b32(a, b, c, 0xF7);
+        default: return __builtin_amdgcn_bitop3_b32(a, b, c, 0x7F);
+    }
+#else
+    return (a ^ ((inv3 & 1u) ? ~0u : 0u)) | (b ^ ((inv3 & 2u) ? ~0u : 0u)) | (c ^ ((inv3 & 4u) ? ~0u : 0u));
+#endif
+}
+// x << 1 as an addition: v_add_u32 issues at full rate, v_lshlrev_b32 at half rate (same table)
+BS_HD bs_u32 bs_shl1(bs_u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    bs_u32 r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x << 1;
+#endif
+}
+// per-half left shift of the two 16-bit halves of x by the amounts in the halves of s (each < 16 ... or 16 -> 0 handled by the caller)
+BS_HD bs_u32 bs_pk_shl16(bs_u32 x, bs_u32 s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    bs_u32 r;
+    asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(r) : "v"(s), "v"(x));
+    return r;
+#else
+    const bs_u32 lo = ((x & 0xFFFFu) << (s & 15u)) & 0xFFFFu, hi = (((x >> 16) << ((s >> 16) & 15u)) & 0xFFFFu) << 16;
+    return hi | lo;
+#endif
+}
 BS_HD bs_u64 bs_rol64(bs_u64 x, unsigned r) { r &= 63; return (x << r) | (x >> ((64 - r) & 63)); }
 
 // plane "in[p - u]" of a stream held as (prev2, prev, cur) words, u in 0..63
@@ -105,38 +152,69 @@ BS_HD bs_u32 bs_plane0(bs_u32 truth, bs_u32 p0, bs_u32 p1) {
 }
 
 // ---- homopolymer compaction: both planes of one raw word squeezed towards the MSB under keep mask m --------
-// (Hacker's Delight 7-4 "compress", mirrored: zeros are counted from the MSB side, so the parallel prefix uses
-// right shifts and only the moves use left shifts.)
+// Two levels.  (1) Every BYTE is squeezed towards its own MSB by three rounds of Hacker's Delight 7-4 "compress", mirrored (zeros
+// are counted from the MSB side, so the parallel prefix uses right shifts, which issue at full rate on gfx950, and only the moves use
+// left shifts) and run on the four bytes at once: the prefix XOR stops at byte boundaries (masked shifts), so a bit moves by the number
+// of dropped bits in front of it IN ITS BYTE — three rounds instead of five, each with a three-step instead of a five-step prefix.
+// (2) The four left-justified bytes are closed up: bytes 1 and 3 move up against bytes 0 and 2 by one packed 16-bit shift (per-half
+// amounts 8 - popcount of the byte in front), then the low half moves up against the high half by 16 - popcount of the high half.
+// 198 instead of 267 issue cycles per word and plane pair (full-rate ops 2.4, half-rate 4.2 cycles; round 2's five-round network).
+// A 32-bit constant held in a VECTOR register: the three-input logic op issues at half rate when one operand is a scalar register
+// (profiles/r01_g_valu_rates.txt), which is where the compiler puts a constant it cannot encode inline.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BS_VCONST(name, val) bs_u32 name; asm("v_mov_b32 %0, %1" : "=v"(name) : "i"(val))
+#else
+#define BS_VCONST(name, val) const bs_u32 name = (val)
+#endif
 BS_HD void bs_compress2(bs_u32 m, bs_u32& x0, bs_u32& x1) {
+    BS_VCONST(k7f, 0x7F7F7F7F); BS_VCONST(k3f, 0x3F3F3F3F); BS_VCONST(k0f, 0x0F0F0F0F);
+    BS_VCONST(khi8, 0xFF00FF00); BS_VCONST(klo8, 0x00FF00FF); BS_VCONST(khi16, 0xFFFF0000); BS_VCONST(klo16, 0x0000FFFF);
     x0 &= m; x1 &= m;
-    bs_u32 mk = ~m >> 1;
+    const bs_u32 m_in = m;
+    bs_u32 mk = (~m >> 1) & k7f;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 5; ++i) {
-        bs_u32 mp = mk ^ (mk >> 1);
-        mp ^= mp >> 2; mp ^= mp >> 4; mp ^= mp >> 8; mp ^= mp >> 16;
+    for (int i = 0; i < 3; ++i) {
+        bs_u32 mp = mk ^ ((mk >> 1) & k7f);
+        mp ^= (mp >> 2) & k3f;
+        mp ^= (mp >> 4) & k0f;
         const bs_u32 mv = mp & m;
         const int s = 1 << i;
-        m = (m ^ mv) | (mv << s);
-        const bs_u32 t0 = x0 & mv; x0 = (x0 ^ t0) | (t0 << s);
-        const bs_u32 t1 = x1 & mv; x1 = (x1 ^ t1) | (t1 << s);
+        const bs_u32 t0 = x0 & mv, t1 = x1 & mv;
+        if (i == 0) { m = (m ^ mv) | bs_shl1(mv); x0 = (x0 ^ t0) | bs_shl1(t0); x1 = (x1 ^ t1) | bs_shl1(t1); }
+        else { m = (m ^ mv) | (mv << s); x0 = (x0 ^ t0) | (t0 << s); x1 = (x1 ^ t1) | (t1 << s); }
         mk &= ~mp;
     }
+    // per-half amounts: high half 8 - popc(byte 0), low half 8 - popc(byte 2); then 16 - popc(bytes 0..1)
+    const bs_u32 c0 = bs_popc(m_in & 0xFF000000u), c2 = bs_popc(m_in & 0x0000FF00u), c01 = bs_popc(m_in >> 16);
+    const bs_u32 sh8 = ((8u - c0) << 16) | (8u - c2);
+    const bs_u32 sh16 = 16u - c01;
+    x0 = (x0 & khi8) | bs_pk_shl16(x0 & klo8, sh8);
+    x1 = (x1 & khi8) | bs_pk_shl16(x1 & klo8, sh8);
+    x0 = (x0 & khi16) | ((x0 & klo16) << sh16);
+    x1 = (x1 & khi16) | ((x1 & klo16) << sh16);
 }
 
-// position (0 = MSB) of the (n+1)-th set bit of m counted from the MSB; n < popcount(m)
+// position (0 = MSB) of the (n+1)-th set bit of m counted from the MSB; n < popcount(m).
+// Binary search on "how many bits are set among the top pos + w positions" — one shift, one popcount, one compare per level, m and n
+// are never modified (round 2 renormalised m and n at every level: 9-10 instructions per level instead of 5-6).
 BS_HD bs_u32 bs_select_msb(bs_u32 m, bs_u32 n) {
     bs_u32 pos = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int w = 16; w >= 1; w >>= 1) {
-        const bs_u32 top = m >> (32 - w);            // the w most significant bits still under consideration
-        const bs_u32 c = bs_popc(top);
-        if (n >= c) { n -= c; pos += (bs_u32)w; m <<= w; }
+        const bs_u32 c = bs_popc(m >> ((bs_u32)(32 - w) - pos));      // set bits among the top pos + w positions (pos + w <= 31 ... 32 - w - pos >= 1 except the first level)
+        pos |= n >= c ? (bs_u32)w : 0u;
     }
     return pos;
+}
+
+// hash bit j is the same for all four bases: its plane is a constant (folded into `inv`)
+template <bool FWD> BS_HD constexpr bool bs_tzero(int j) {
+    const bs_u32 t = FWD ? bs_truth_f(j) : bs_truth_r(j);
+    return t == 0 || t == 15;
 }
 
 // ---- bit-sliced filter: per-strand W planes of one dense word -------------------------------------------------
@@ -167,23 +245,28 @@ BS_HD void bs_strand_planes(bs_u32 c0, bs_u32 c1, bs_u32 p0, bs_u32 p1, bs_u32 q
         }
     }
     // sliding XOR over L consecutive planes: W_b = XOR_{j=b-L+1..b} T_j (same index set for both strands, other delays);
-    // W_63 in full (three-input XORs), then W_{b-1} = W_b ^ T_b ^ T_{b-L}
+    // W_63 in full (three-input XORs over the planes that are not constant), then W_{b-1} = W_b ^ T_b ^ T_{b-L}
     inv = 0;
     {
         constexpr int hi0 = NT - 1, lo0 = NT - L;
-        bs_u32 w = T[lo0];
-        int t = lo0 + 1;
+        bs_u32 w = 0, pend = 0;
+        bool have_w = false, have_p = false;            // compile-time constants once the loop is unrolled
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (; t + 1 <= hi0; t += 2) w = bs_xor3(w, T[t], T[t + 1]);
-        if (t <= hi0) w ^= T[t];
+        for (int t = lo0; t <= hi0; ++t) {
+            if (bs_tzero<FWD>(JLO + t)) continue;
+            if (!have_w) { w = T[t]; have_w = true; }
+            else if (!have_p) { pend = T[t]; have_p = true; }
+            else { w = bs_xor3(w, pend, T[t]); have_p = false; }
+        }
+        if (have_p) w ^= pend;
         W[0] = w;
     }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int i = 1; i < BS_B; ++i) W[i] = bs_xor3(W[i - 1], T[NT - i], T[NT - i - L]);
+    for (int i = 1; i < BS_B; ++i) W[i] = bs_xor3z(W[i - 1], T[NT - i], bs_tzero<FWD>(JLO + NT - i), T[NT - i - L], bs_tzero<FWD>(JLO + NT - i - L));
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -203,24 +286,26 @@ BS_HD void bs_strand_planes(bs_u32 c0, bs_u32 c1, bs_u32 p0, bs_u32 p1, bs_u32 q
 // "all BS_B hash bits are zero", a plain OR-reduction.
 template <bool FWD, bool ZERO>
 BS_HD bs_u32 bs_strand_compare(const bs_u32 W[BS_B], const bs_u32 Wp[BS_B], bs_u32 inv, const bs_u32 bmask[BS_B]) {
-    bs_u32 x[BS_B];
+    bs_u32 x[BS_B], xr[BS_B];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int i = 0; i < BS_B; ++i) {
         // forward: out_b is W_b delayed by (63 - b) = i already; bring every bit to the common delay BS_B - 1
         const int d = FWD ? (BS_B - 1) - i : i;
-        x[i] = d == 0 ? W[i] : bs_alignbit(Wp[i], W[i], (bs_u32)d);
-        if ((inv >> i) & 1) x[i] = ~x[i];
+        xr[i] = d == 0 ? W[i] : bs_alignbit(Wp[i], W[i], (bs_u32)d);        // complements (inv) are folded into the logic below
     }
     if (ZERO) {
-        bs_u32 any = x[0];
+        static_assert(BS_B == 8, "the OR tree below is written for eight planes");
+        bs_u32 any = bs_or3i(xr[0], xr[1], xr[2], inv);
+        any = bs_or3i(any, xr[3], xr[4], (inv >> 2) & 6u);
+        any = bs_or3i(any, xr[5], xr[6], (inv >> 4) & 6u);
+        return ~(any | (((inv >> 7) & 1u) ? ~xr[7] : xr[7]));
+    }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int i = 1; i < BS_B; ++i) any |= x[i];
-        return ~any;
-    }
+    for (int i = 0; i < BS_B; ++i) x[i] = ((inv >> i) & 1) ? ~xr[i] : xr[i];
     bs_u32 le = 0xFFFFFFFFu;
     // from the least significant evaluated bit up: le = bound_bit ? (le | ~x) : (le & ~x)
 #if defined(__HIPCC__)

@@ -154,7 +154,7 @@ constexpr int HW = HALO_BASES / 32;           // leading halo words
 constexpr int TT = TILE_THREADS;
 constexpr int WPT = RW / TT;                  // raw words per thread
 constexpr int DPAD = 4;                       // zero words in front of the dense stream (look-back of the first words)
-constexpr int QCAP = 768;                     // candidates per evaluation round
+constexpr int QCAP = 704;                     // candidates that fit the unordered list (evaluated in rounds of TILE_THREADS)
 constexpr int RS_CAP = 32;                    // read starts of a tile kept in LDS (more: binary search in global memory)
 
 struct __attribute__((aligned(16))) TileLds {
@@ -165,13 +165,14 @@ struct __attribute__((aligned(16))) TileLds {
     u16 dfirst[RW + 8];                       // raw word that holds dense position 32 * D
     union {
         u32 stage[2 * RW];                    // FMT_ASCII: half planes of the 16-base chunks (phase 1 only)
-        struct { u32 cand[RW + 8]; u16 cpre[RW + 8]; u16 list[QCAP]; } c;
+        struct { u32 cand[RW + 8]; u16 cpre[RW + 8]; u16 list[QCAP]; u16 surv[TILE_THREADS]; } c;    // cpre doubles as the survivors' hashes (u64 x TT) before count_words
     } a;
     u64 t3[2 << (2 * BS_GS)];                 // exact evaluation: 3-base groups {F, R}
     int64_t rs_rel[RS_CAP];                   // start of read rl + i, relative to the first staged position
-    u32 misc[32];                             // [0..4] scan scratch, [8] slow, [11] Hh, [16] next round, [17] list fill
+    u32 misc[32];                             // [0..4] scan scratch, [8] slow, [11] Hh, [16] next round, [17] list fill, [18..20] survivors per round
 };
 static_assert(sizeof(TileLds) * 6 <= 160 * 1024, "6 workgroups per CU");
+static_assert((RW + 8) * 2 >= TILE_THREADS * 8 && ((RW + 8) * 4) % 8 == 0, "cpre holds one u64 per thread");
 
 // 16 ASCII bases -> {plane0 half | plane1 half}, MSB first (base 0 in bits 31 / 15); bad != 0: a byte outside ACGT
 __device__ inline u32 ascii16_to_hp(uint4 v, u32& bad) {
@@ -204,6 +205,17 @@ __device__ inline u32 range_mask(int64_t a, int64_t b) {
 
 __device__ inline u32 dpp_wave_shr1(u32 x) {        // lane i <- lane i-1 (lane 0: 0)
     return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
+
+// LDS fetch-add issued by every active lane as ONE ds_add_rtn_u32.  atomicAdd() on a wave-uniform LDS address is rewritten by the
+// compiler's atomic optimizer into a scalar loop over the active lanes (s_ff1 / v_readlane / v_writelane, ~9 scalar instructions per
+// lane): in the filter loop that was 126 scalar instructions per step, half of the kernel's SALU count, for a same-address conflict the
+// LDS resolves in a few cycles.
+__device__ inline u32 lds_fetch_add(u32* p, u32 v) {
+    u32 r;
+    const u32 addr = (u32)(uintptr_t)(__attribute__((address_space(3))) u32*)p;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(v) : "memory");
+    return r;
 }
 
 // what a tile hands to the gather: records in position order + their number
@@ -291,9 +303,10 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         if (tid && pi0 - 1 >= 0 && pi0 - 1 < n_pairs) { const uint2 q = a.planes[pi0 - 1]; pv0 = q.x >> 31; pv1 = q.y >> 31; }
     }
     const u32 rl = rec->rl, rh_ = rec->rh;
-    for (int i = tid; i < 2 * (DPAD + RW + 4); i += TT) S.dense[i] = 0;
+    static_assert((2 * (DPAD + RW + 4)) % 4 == 0, "the dense stream is a whole number of 16-byte words");
+    for (int i = tid; i < 2 * (DPAD + RW + 4) / 4; i += TT) ((uint4*)S.dense)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < (2 << (2 * BS_GS))) S.t3[tid] = a.t4[tid];
-    if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[11] = 0; S.misc[17] = 0; }
+    if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[11] = 0; S.misc[17] = 0; S.misc[18] = 0; S.misc[19] = 0; S.misc[20] = 0; }
     __syncthreads();
     if (rh_ - rl < (u32)TREC_N) {                       // the usual case: the read starts come with the tile's record
         if ((u32)tid <= rh_ - rl) {
@@ -364,9 +377,12 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
             S.dense[w] = 0;                                  // the read-start bitmap has been consumed: back to an empty dense stream
             kw[i] = k; n_kept[i] = bs_popc(k); mine += n_kept[i];
         }
+        if (hpc) {                                           // (wave-uniform: no exec juggling per word)
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            if (hpc || kw[i] != 0xFFFFFFFFu) bs_compress2(kw[i], x0[i], x1[i]);
+            for (int i = 0; i < WPT; ++i) bs_compress2(kw[i], x0[i], x1[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) if (kw[i] != 0xFFFFFFFFu) bs_compress2(kw[i], x0[i], x1[i]);
         }
     }
     u32 H;
@@ -374,10 +390,15 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     static_assert(HW % WPT == 0, "the halo is a whole number of threads");
     if (tid == HW / WPT) S.misc[11] = off;                   // kept bases of the halo words
     if (tid == TT - 1) S.rpre[RW] = (u16)H;
+    static_assert(WPT == 4, "one 16-byte store of keep masks and one 8-byte store of prefixes per thread");
+    *(uint4*)(S.kw + WPT * tid) = make_uint4(kw[0], kw[1], kw[2], kw[3]);
+    {
+        const u32 o1 = off + n_kept[0], o2 = o1 + n_kept[1], o3 = o2 + n_kept[2];
+        *(uint2*)(S.rpre + WPT * tid) = make_uint2(off | o1 << 16, o2 | o3 << 16);
+    }
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const int w = WPT * tid + i;
-        S.kw[w] = kw[i]; S.rpre[w] = (u16)off;
         const u32 n = n_kept[i];
         if (n) {
             const u32 wi = off >> 5, s = off & 31;
@@ -412,35 +433,55 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         for (int i = 0; i < BS_B; ++i) bmask[i] = ((a.btop >> (BS_B - 1 - i)) & 1u) ? 0xFFFFFFFFu : 0u;
         const u32 n_steps = (n_out + 62) / 63;
         const bool zero_test = a.btop == 0;                          // density < 2^-BS_B: "all evaluated hash bits are zero"
-        for (u32 st = wv; st < n_steps; st += TT / 64) {
+        const u32 wv_s = (u32)__builtin_amdgcn_readfirstlane(wv);    // the step index lives in scalar registers
+        const int nb_addr = 4 * ((lane + 63) & 63);                  // ds_bpermute address of the lane in front
+        // first / last candidate-plane position that is owned: words wholly inside [x_lo, x_hi) need no mask
+        const int x_lo = __builtin_amdgcn_readfirstlane((int)e_lo + BS_B - 1), x_hi = __builtin_amdgcn_readfirstlane((int)H + BS_B - 1);
+        for (u32 st = wv_s; st < n_steps; st += TT / 64) {
             const int D = (int)(63 * st) + lane - 1;                  // lane 0 recomputes the word before the step's first
             const u32* dw = S.dense + 2 * (DPAD + (D < RW + 3 ? D : RW + 3));     // words past the stream are zero; their results are dropped
             const uint2 c = *(const uint2*)dw, p = *(const uint2*)(dw - 2);
             uint2 q = make_uint2(0u, 0u);
             if (L + BS_B - 2 >= 32) q = *(const uint2*)(dw - 4);
+            // the planes of the word in front live in the lane in front.  They come through the LDS crossbar (ds_bpermute: no memory
+            // access, and not a VALU slot — the kernel is bound by VALU issue; round 2 used 14 v_mov_dpp wave_shr:1 per word here)
             u32 W[BS_B], Wp[BS_B], inv;
             bs_strand_planes<L, true>(c.x, c.y, p.x, p.y, q.x, q.y, W, inv);
 #pragma unroll
-            for (int i = 0; i < BS_B; ++i) Wp[i] = dpp_wave_shr1(W[i]);
+            for (int i = 0; i < BS_B - 1; ++i) Wp[i] = (u32)__builtin_amdgcn_ds_bpermute(nb_addr, (int)W[i]);
+            Wp[BS_B - 1] = 0;                                         // forward: plane BS_B-1 is already at the common delay
             u32 cand = zero_test ? bs_strand_compare<true, true>(W, Wp, inv, bmask) : bs_strand_compare<true, false>(W, Wp, inv, bmask);
             bs_strand_planes<L, false>(c.x, c.y, p.x, p.y, q.x, q.y, W, inv);
+            Wp[0] = 0;                                                // reverse: plane 0 is
 #pragma unroll
-            for (int i = 0; i < BS_B; ++i) Wp[i] = dpp_wave_shr1(W[i]);
+            for (int i = 1; i < BS_B; ++i) Wp[i] = (u32)__builtin_amdgcn_ds_bpermute(nb_addr, (int)W[i]);
             cand |= zero_test ? bs_strand_compare<false, true>(W, Wp, inv, bmask) : bs_strand_compare<false, false>(W, Wp, inv, bmask);
-            if (lane && (u32)D < n_out) {
-                cand &= range_mask((int64_t)e_lo + BS_B - 1 - 32 * (int64_t)D, (int64_t)H + BS_B - 1 - 32 * (int64_t)D);
-                S.a.c.cand[D] = cand;
-                if (cand) {                                           // common case: all candidates of the tile fit one unordered list
-                    u32 slot = atomicAdd(&S.misc[17], bs_popc(cand));
-                    while (cand) {
-                        const u32 b = (u32)__clz(cand); cand &= ~(0x80000000u >> b);
-                        if (slot < QCAP) S.a.c.list[slot] = (u16)(32 * D + b - (BS_B - 1));
-                        ++slot;
-                    }
+            // only the step that holds the first owned position and the one that holds the last need the range mask (wave-uniform test)
+            const int Dw0 = (int)(63 * st) - 1;
+            if (32 * Dw0 < x_lo || 32 * (Dw0 + 64) > x_hi) cand &= range_mask((int64_t)x_lo - 32 * (int64_t)D, (int64_t)x_hi - 32 * (int64_t)D);
+            if (lane && (u32)D < n_out) S.a.c.cand[D] = cand;
+        }
+        for (u32 D = n_out + tid; D < RW + 8; D += TT) S.a.c.cand[D] = 0;
+    }
+    __syncthreads();
+    // the (unordered) candidate list: every thread expands the bitmap words 4 tid .. 4 tid + 3.  (Round 2 and the first version of this
+    // round appended to the list inside the filter loop: one LDS fetch-add and a bit loop per step, 12 times per wave instead of once.)
+    {
+        const uint4 cw = *(const uint4*)(S.a.c.cand + WPT * tid);
+        const u32 w5[5] = {cw.x, cw.y, cw.z, cw.w, tid == TT - 1 ? S.a.c.cand[RW] : 0u};       // the last thread also takes word RW
+        const u32 c = bs_popc(cw.x) + bs_popc(cw.y) + bs_popc(cw.z) + bs_popc(cw.w) + bs_popc(w5[4]);
+        if (c) {
+            u32 slot = lds_fetch_add(&S.misc[17], c);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                u32 w = w5[i];
+                while (w) {
+                    const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b);
+                    if (slot < QCAP) S.a.c.list[slot] = (u16)(32 * (WPT * tid + i) + b - (BS_B - 1));
+                    ++slot;
                 }
             }
         }
-        for (u32 D = n_out + tid; D < RW + 8; D += TT) S.a.c.cand[D] = 0;
     }
     __syncthreads();
     MDBG_STAMP(3);
@@ -449,11 +490,14 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     // ---- phase 4: exact evaluation, ranks, records -------------------------------------------------------------------
     const int nw = tid == TT - 1 ? WPT + 1 : WPT;                     // words 4*tid .. ; the last thread also takes word RW
     auto count_words = [&]() -> u32 {                                 // cpre[] <- exclusive counts of the bitmap per word; returns the total
-        u32 cnt = 0, cw[WPT + 1];
-        for (int i = 0; i < nw; ++i) { cw[i] = bs_popc(S.a.c.cand[WPT * tid + i]); cnt += cw[i]; }
+        const uint4 cw = *(const uint4*)(S.a.c.cand + WPT * tid);
+        const u32 c0 = bs_popc(cw.x), c1 = bs_popc(cw.y), c2 = bs_popc(cw.z), c3 = bs_popc(cw.w);
+        const u32 last = tid == TT - 1 ? bs_popc(S.a.c.cand[RW]) : 0u;       // the last thread also takes word RW
         u32 total;
-        u32 o = block_excl_scan_256(cnt, S.misc, total);
-        for (int i = 0; i < nw; ++i) { S.a.c.cpre[WPT * tid + i] = (u16)o; o += cw[i]; }
+        const u32 o = block_excl_scan_256(c0 + c1 + c2 + c3 + last, S.misc, total);
+        const u32 o1 = o + c0, o2 = o1 + c1, o3 = o2 + c2;
+        *(uint2*)(S.a.c.cpre + WPT * tid) = make_uint2(o | o1 << 16, o2 | o3 << 16);
+        if (tid == TT - 1) S.a.c.cpre[RW] = (u16)(o3 + c3);
         __syncthreads();
         return total;
     };
@@ -482,46 +526,82 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         return 32 * w + bs_select_msb(S.kw[w], r - S.rpre[w]);
     };
     const u32 n_rs = rh_ - rl + 1;                                     // reads that touch the staged range
-    auto eval = [&](u32 e, CandOut& o) -> bool {                       // exact: src/read.rs:196-208 for the l-mer ending at dense position e
+    // exact 64-bit hash of the l-mer ending at dense position e (src/read.rs:196)
+    auto exact = [&](u32 e) -> u64 {
         const u32 wi = e >> 5, s = e & 31;
         const u32* dw = S.dense + 2 * (DPAD + wi);
         const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);
-        const u64 h = bs_exact_hash<BS_GS>(v0, v1, L, S.t3);
-        if (h > a.bound) return false;
-        const int64_t rel_end = dense_to_raw(e);
-        u32 r; int64_t q0;                                             // the read holding the END position; q0: its start, tile-relative
+        return bs_exact_hash<BS_GS>(v0, v1, L, S.t3);
+    };
+    // raw coordinates of a selected l-mer (src/read.rs:196-208): its FIRST base decides the read; an l-mer that runs over the next
+    // read's start (a forced run start, so its dense rank is the number of kept bases in front of it) belongs to no read
+    auto place = [&](u32 e, u64 h, CandOut& o) -> bool {
+        const u32 sd = e - (u32)(L - 1);
+        const int64_t rel_start = dense_to_raw(sd);
+        u32 r; int64_t q0, q1;                                         // the read holding the first base; q0: its start, q1: the next read's, tile-relative
         if (n_rs <= RS_CAP) {
             u32 i = 0;
-            while (i + 1 < n_rs && S.rs_rel[i + 1] <= rel_end) ++i;
-            r = rl + i; q0 = S.rs_rel[i];
-        } else { r = find_read(a.offsets, rl, rh_, (u64)(raw0 + rel_end)); q0 = (int64_t)a.offsets[r] - raw0; }
-        const u32 sd = e - (u32)(L - 1);
-        if (q0 > 0) {                                                  // the read starts inside the staged range: the l-mer must not cross it
-            const u32 w = (u32)q0 >> 5, b = (u32)q0 & 31;
-            const u32 ds = S.rpre[w] + (b ? bs_popc(S.kw[w] >> (32 - b)) : 0u);
-            if (sd < ds) return false;
+            while (i + 1 < n_rs && S.rs_rel[i + 1] <= rel_start) ++i;
+            r = rl + i; q0 = S.rs_rel[i]; q1 = i + 1 < n_rs ? S.rs_rel[i + 1] : (int64_t)RW * 32;
+        } else {
+            r = find_read(a.offsets, rl, rh_, (u64)(raw0 + rel_start)); q0 = (int64_t)a.offsets[r] - raw0;
+            q1 = r < rh_ ? (int64_t)a.offsets[r + 1] - raw0 : (int64_t)RW * 32;
         }
-        o.hash = h; o.pos = (u32)((int64_t)dense_to_raw(sd) - q0); o.read = r + a.read_base;
-        return true;
+        bool crosses = false;
+        if (q1 < (int64_t)RW * 32) {
+            const u32 w = (u32)q1 >> 5, b = (u32)q1 & 31;
+            const u32 ds = S.rpre[w] + (b ? bs_popc(S.kw[w] >> (32 - b)) : 0u);
+            crosses = ds <= e;
+        }
+        // (the outputs are written on every path: hipcc 7.2 zeroed a caller's variable that was assigned only after a successful return
+        // for the lanes that came through the block above)
+        o.hash = h; o.pos = (u32)(rel_start - q0); o.read = r + a.read_base;
+        return !crosses;
+    };
+    auto eval = [&](u32 e, CandOut& o) -> bool {
+        const u64 h = exact(e);
+        return h <= a.bound && place(e, h, o);
     };
     auto clear_bit = [&](u32 e) { const u32 x = e + BS_B - 1; atomicAnd(&S.a.c.cand[x >> 5], ~(0x80000000u >> (x & 31))); };
     auto rank_of = [&](u32 e) -> u32 { const u32 x = e + BS_B - 1, D = x >> 5, b = x & 31; return S.a.c.cpre[D] + (b ? bs_popc(S.a.c.cand[D] >> (32 - b)) : 0u); };
 
     const u32 n_cand = S.misc[17];
     if (n_cand <= QCAP) {
-        // every candidate sits in the list (any order): evaluate, drop the failures from the bitmap, rank the survivors there
-        CandOut keep[QCAP / TT]; u32 keep_ok = 0;
+        // every candidate sits in the list (any order).  Rounds of TT candidates, two stages each: (1) one lane per candidate evaluates
+        // the exact hash — about half fail (bit 55) —, the survivors are packed (wave-aggregated slot) into surv / their hashes; (2) one
+        // lane per SURVIVOR maps it to raw coordinates and its read, so the longer half of the work runs on full waves.  Failures
+        // leave the bitmap; the popcount scan of the bitmap then ranks the survivors in position order.
+        constexpr int NR = (QCAP + TT - 1) / TT;
+        CandOut keep[NR] = {}; u32 keep_e[NR] = {}; u32 keep_ok = 0;
+        u64* const s_h = (u64*)S.a.c.cpre;
 #pragma unroll
-        for (int i = 0; i < QCAP / TT; ++i) {
-            const u32 j = tid + TT * i;
-            if (j < n_cand) { const u32 e = S.a.c.list[j]; if (eval(e, keep[i])) keep_ok |= 1u << i; else clear_bit(e); }
+        for (int i = 0; i < NR; ++i) {
+            if ((u32)(TT * i) < n_cand) {
+                if (i) __syncthreads();                               // the previous round's survivors have been read
+                const u32 j = tid + TT * i;
+                bool pass = false; u32 e = 0; u64 h = 0;
+                if (j < n_cand) { e = S.a.c.list[j]; h = exact(e); pass = h <= a.bound; if (!pass) clear_bit(e); }
+                const u64 bal = __ballot(pass);
+                if (bal) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&S.misc[18 + i], (u32)__popcll(bal));
+                    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                    if (pass) { const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)); S.a.c.surv[slot] = (u16)e; s_h[slot] = h; }
+                }
+                __syncthreads();
+                if ((u32)tid < S.misc[18 + i]) {
+                    e = S.a.c.surv[tid];
+                    keep_e[i] = e;
+                    if (place(e, s_h[tid], keep[i])) keep_ok |= 1u << i; else clear_bit(e);
+                }
+            }
         }
         __syncthreads();
         MDBG_STAMP(4);
         const u32 nv = n_cand ? count_words() : 0;
         MDBG_STAMP(5);
 #pragma unroll
-        for (int i = 0; i < QCAP / TT; ++i) if ((keep_ok >> i) & 1u) put_rec(a, slab, rank_of(S.a.c.list[tid + TT * i]), keep[i].hash, keep[i].pos, keep[i].read);
+        for (int i = 0; i < NR; ++i) if ((keep_ok >> i) & 1u) put_rec(a, slab, rank_of(keep_e[i]), keep[i].hash, keep[i].pos, keep[i].read);
         if (tid == 0) { put_count(a, gt, nv); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; } }
     } else {
         // dense settings: rounds of whole bitmap words; pass A validates, pass B (after the recount) writes

@@ -548,7 +548,12 @@ __global__ __launch_bounds__(256) void wrap_list_kernel(Slot* __restrict__ tab, 
     const u64 word = tab[s].word;
     if (word == EMPTY) return;
     const u32 count = tab[s].count + 1u;
-    if (count < A || (!all_solid && count - A < 65536u) || !(A == 1 || (u16)count >= (u16)A)) return;
+    if (count < A || (!all_solid && count - A < 65536u) || !(A == 1 || (u16)count >= (u16)A)) {
+        // not listed (any more): a rank left by an earlier finalize (finalize -> ingest -> finalize without reset, the node's u16 abundance
+        // has wrapped below minabund meanwhile) would send the scan kernels to another node's segment or past the lists
+        if (tab[s].pad) tab[s].pad = 0;
+        return;
+    }
     const u32 r = (u32)atomicAdd(&counters[0], 1ull);
     atomicAdd(&counters[1], (unsigned long long)count);
     w_count[r] = count; w_jstar[r] = (u64)A + 65536ull * ((count - A) / 65536u);

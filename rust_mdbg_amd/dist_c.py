@@ -30,9 +30,12 @@ def rccl_comm(rank, world, dist=None):
     if rank == 0 and L.ncclGetUniqueId(C.byref(uid)) != 0:
         raise RuntimeError("ncclGetUniqueId failed")
     if world > 1:
-        box = [bytes(uid.internal) if rank == 0 else None]
+        # all 128 bytes: the id is binary (bytes(uid.internal) on a c_char array stops at the first NUL byte)
+        box = [C.string_at(C.byref(uid), C.sizeof(uid)) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        C.memmove(C.byref(uid), box[0], 128)
+        if len(box[0]) != C.sizeof(uid):
+            raise RuntimeError("ncclUniqueId: %d bytes received, %d expected" % (len(box[0]), C.sizeof(uid)))
+        C.memmove(C.byref(uid), box[0], C.sizeof(uid))
     comm = C.c_void_p()
     if L.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
         raise RuntimeError("ncclCommInitRank failed")

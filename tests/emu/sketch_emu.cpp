@@ -152,16 +152,18 @@ void tile(const u8* bases, int64_t nb, const u64* offsets, u32 n_reads, bool hpc
             const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);
             const u64 h = bs_exact_hash<BS_GS>(v0, v1, L, t4);
             if (h > bound) continue;
-            const int64_t abs_end = raw0 + dense_to_raw(e);
-            const u32 r = find_read(offsets, 0, n_reads - 1, (u64)abs_end);
-            const int64_t q0 = (int64_t)offsets[r];
+            // the kernel's rule (sketch.hip, place): the FIRST base decides the read; an l-mer that reaches the next read's start is dropped
             const u32 sd = e - (u32)(L - 1);
-            if (q0 > raw0) {
-                const u32 rel = (u32)(q0 - raw0), w2 = rel >> 5, b2 = rel & 31;
+            const int64_t abs_start = raw0 + dense_to_raw(sd);
+            const u32 r = find_read(offsets, 0, n_reads - 1, (u64)abs_start);
+            const int64_t q0 = (int64_t)offsets[r];
+            const int64_t q1 = (r + 1 < n_reads ? (int64_t)offsets[r + 1] : nb) - raw0;
+            if (r + 1 < n_reads && q1 < (int64_t)RW * 32) {
+                const u32 w2 = (u32)q1 >> 5, b2 = (u32)q1 & 31;
                 const u32 ds = rpre[w2] + (b2 ? bs_popc(kw[w2] >> (32 - b2)) : 0u);
-                if (sd < ds) continue;
+                if (ds <= e) continue;
             }
-            out.hash.push_back(h); out.pos.push_back((u32)(raw0 + dense_to_raw(sd) - q0)); out.read.push_back(r);
+            out.hash.push_back(h); out.pos.push_back((u32)(abs_start - q0)); out.read.push_back(r);
         }
     }
 }

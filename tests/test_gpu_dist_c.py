@@ -30,6 +30,23 @@ def test_c_program_drives_ranks_through_mdbg_dist(exe, world, reads, rounds, pac
     assert "EQUAL to the single-context table" in r.stdout
 
 
+@pytest.fixture(scope="module")
+def exe_procs(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("distp") / "mdbg_dist_procs")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "mdbg_dist_procs.c"),
+                    "-L" + LIB, "-lmdbg_hip", "-lpthread", "-Wl,-rpath," + LIB, "-o", out], check=True)
+    return out
+
+
+@pytest.mark.parametrize("world,reads,rounds,packed,chunks", [(2, 300, 2, 0, 1), (2, 300, 1, 1, 3), (3, 300, 3, 0, 2), (4, 200, 2, 1, 1)])
+def test_separate_processes_drive_ranks_through_mdbg_dist(exe_procs, world, reads, rounds, packed, chunks):
+    """the ranks are OS processes (forked before the GPU runtime is touched), each with its own library state and mdbg_dist, sharing the
+    one GPU; the communicator is a shared-memory function table (host-staged exchange).  Partitions put together == single-context table"""
+    r = subprocess.run([exe_procs, str(world), str(reads), str(rounds), str(packed), str(chunks)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "world %d PROCESSES" % world in r.stdout and "EQUAL to the single-context table" in r.stdout
+
+
 from rust_mdbg_amd.dist_c import Comm      # noqa: E402  (mirror of mdbg_comm)
 
 
