@@ -60,6 +60,75 @@ u32 xxh32(const u8* p, size_t len, u32 seed) {
     return h;
 }
 
+// the same hash over a stream (content checksum of an LZ4 frame: XXH32 of everything the frame decodes to)
+struct Xxh32Stream {
+    u32 v[4]; u8 mem[16]; u32 memsize = 0; u64 total = 0; u32 seed = 0;
+    void init(u32 sd) { const u32 P1 = 2654435761u, P2 = 2246822519u; seed = sd; v[0] = sd + P1 + P2; v[1] = sd + P2; v[2] = sd; v[3] = sd - P1; memsize = 0; total = 0; }
+    static u32 rd(const u8* q) { u32 x; memcpy(&x, q, 4); return x; }
+    static u32 round(u32 acc, u32 in) { return rotl32(acc + in * 2246822519u, 13) * 2654435761u; }
+    void update(const u8* p, size_t len) {
+        total += len;
+        if (memsize + len < 16) { memcpy(mem + memsize, p, len); memsize += (u32)len; return; }
+        const u8* end = p + len;
+        if (memsize) {
+            memcpy(mem + memsize, p, 16 - memsize);
+            for (int i = 0; i < 4; ++i) v[i] = round(v[i], rd(mem + 4 * i));
+            p += 16 - memsize; memsize = 0;
+        }
+        while (p + 16 <= end) { for (int i = 0; i < 4; ++i) v[i] = round(v[i], rd(p + 4 * i)); p += 16; }
+        if (p < end) { memcpy(mem, p, (size_t)(end - p)); memsize = (u32)(end - p); }
+    }
+    u32 digest() const {
+        const u32 P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+        u32 h = total >= 16 ? rotl32(v[0], 1) + rotl32(v[1], 7) + rotl32(v[2], 12) + rotl32(v[3], 18) : seed + P5;
+        h += (u32)total;
+        const u8* p = mem; const u8* end = mem + memsize;
+        while (p + 4 <= end) { h = rotl32(h + rd(p) * P3, 17) * P4; p += 4; }
+        while (p < end) { h = rotl32(h + (*p) * P5, 11) * P1; ++p; }
+        h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+        return h;
+    }
+};
+
+// ---- LZ4 block encoder (the reference writes its .sequences files through lzzzz's frame compressor, src/main.rs:32,65) ----------
+// Greedy parse over a table of the last position of every 4-byte hash (one probe, matches extended in both directions), with the
+// LZ4 block format's end rules (the last match starts at least 12 bytes before the end of the block, the last 5 bytes are literals).
+// `table` is scratch kept by the caller.
+void lz4_block_encode(const u8* src, size_t n, std::vector<u8>& dst, std::vector<u32>& table) {
+    dst.clear();
+    auto rd32 = [&](size_t i) { u32 x; memcpy(&x, src + i, 4); return x; };
+    auto put_len = [&](size_t v) { while (v >= 255) { dst.push_back(255); v -= 255; } dst.push_back((u8)v); };
+    auto sequence = [&](size_t lit0, size_t lit_n, size_t off, size_t ml) {         // ml = 0: the closing literals-only sequence
+        const size_t mc = ml ? ml - 4 : 0;
+        dst.push_back((u8)((lit_n >= 15 ? 15 : lit_n) << 4 | (mc >= 15 ? 15 : mc)));
+        if (lit_n >= 15) put_len(lit_n - 15);
+        dst.insert(dst.end(), src + lit0, src + lit0 + lit_n);
+        if (ml) { dst.push_back((u8)(off & 0xFF)); dst.push_back((u8)(off >> 8)); if (mc >= 15) put_len(mc - 15); }
+    };
+    size_t anchor = 0;
+    if (n > 12) {
+        table.assign(1u << 16, 0u);                                                  // position + 1 of the last occurrence of a hash
+        const size_t mflimit = n - 12, matchlimit = n - 5;
+        size_t i = 0, misses = 0;
+        while (i < mflimit) {
+            const u32 seq = rd32(i);
+            const u32 h = (seq * 2654435761u) >> 16;
+            const size_t cand = table[h];
+            table[h] = (u32)(i + 1);
+            if (cand && i - (cand - 1) <= 65535 && rd32(cand - 1) == seq) {
+                size_t m = cand - 1;
+                while (i > anchor && m > 0 && src[i - 1] == src[m - 1]) { --i; --m; }
+                size_t ml = 4;
+                while (i + ml < matchlimit && src[i + ml] == src[m + ml]) ++ml;
+                sequence(anchor, i - anchor, i - m, ml);
+                i += ml; anchor = i; misses = 0;
+                if (i >= 2 && i - 2 < mflimit) table[(rd32(i - 2) * 2654435761u) >> 16] = (u32)(i - 1);
+            } else i += 1 + (misses++ >> 6);                                        // skip faster through incompressible stretches
+        }
+    }
+    sequence(anchor, n - anchor, 0, 0);
+}
+
 char switch_base(char c) {                                    // src/utils.rs:10-24
     switch (c) { case 'a': return 't'; case 'c': return 'g'; case 't': return 'a'; case 'g': return 'c'; case 'u': return 'a';
                  case 'A': return 'T'; case 'C': return 'G'; case 'T': return 'A'; case 'G': return 'C'; case 'U': return 'A'; default: return 'N'; }
@@ -71,13 +140,20 @@ struct mdbg_emit { std::vector<u32> n1, n2, ov; std::vector<u8> o1, o2; };
 
 struct mdbg_seqfile {
     FILE* f = nullptr; u32 k = 0, l = 0; std::string buf;
-    // LZ4 frame, independent stored blocks of <= 4 MiB
+    // LZ4 frame, independent blocks of <= 4 MiB, compressed (lz4_block_encode) unless that does not make them smaller
+    std::vector<u8> zbuf; std::vector<u32> ztab;
     bool flush_block() {
         size_t off = 0;
         while (off < buf.size()) {
             const u32 n = (u32)std::min<size_t>(buf.size() - off, 4u << 20);
-            const u32 hdr = n | 0x80000000u;                  // highest bit: block is not compressed
-            if (fwrite(&hdr, 4, 1, f) != 1 || fwrite(buf.data() + off, 1, n, f) != n) return false;
+            lz4_block_encode((const u8*)buf.data() + off, n, zbuf, ztab);
+            if (zbuf.size() < n) {
+                const u32 hdr = (u32)zbuf.size();
+                if (fwrite(&hdr, 4, 1, f) != 1 || fwrite(zbuf.data(), 1, zbuf.size(), f) != zbuf.size()) return false;
+            } else {
+                const u32 hdr = n | 0x80000000u;              // highest bit: block is not compressed
+                if (fwrite(&hdr, 4, 1, f) != 1 || fwrite(buf.data() + off, 1, n, f) != n) return false;
+            }
             off += n;
         }
         buf.clear();
@@ -247,9 +323,10 @@ int mdbg_seqfile_close(mdbg_seqfile* s) {
 
 // ---- LZ4 frame input (src/main.rs:168-172: a ".lz4" file goes through lzzzz's BufReadDecompressor) --------------------
 // Streaming decoder of the LZ4 frame format (magic 0x184D2204; linked or independent blocks, stored or compressed blocks,
-// skippable and concatenated frames); block / content checksums are read past, not verified.
+// skippable and concatenated frames); the header, block and content checksums (XXH32) are verified where the frame carries them.
 struct Lz4In {
     FILE* f = nullptr; bool bad = false, done = false, in_frame = false, blk_sum = false, content_sum = false;
+    Xxh32Stream content;
     std::vector<u8> out;              // [history (<= 64 KiB) | bytes of the current block]; rd = next byte to hand out
     size_t rd = 0;
     std::vector<u8> blk;
@@ -274,7 +351,10 @@ struct Lz4In {
             size_t skip = 1;                                    // header checksum
             if ((fb[0] >> 3) & 1) skip += 8;                    // content size
             if (fb[0] & 1) skip += 4;                           // dictionary id
-            u8 tmp[16]; if (!get(tmp, skip)) { bad = true; return false; }
+            u8 desc[16] = {fb[0], fb[1]};                       // descriptor = FLG, BD, [content size], [dictionary id]; then its checksum byte
+            if (!get(desc + 2, skip)) { bad = true; return false; }
+            if (((xxh32(desc, 2 + skip - 1, 0) >> 8) & 0xFF) != desc[2 + skip - 1]) { bad = true; return false; }
+            content.init(0);
             in_frame = true; out.clear(); rd = 0;
             return true;
         }
@@ -305,7 +385,10 @@ struct Lz4In {
             u8 z[4]; if (!get(z, 4)) { bad = true; return false; }
             const u32 w = (u32)z[0] | (u32)z[1] << 8 | (u32)z[2] << 16 | (u32)z[3] << 24;
             if (w == 0) {                                       // end mark
-                if (content_sum) { u8 c4[4]; if (!get(c4, 4)) { bad = true; return false; } }
+                if (content_sum) {
+                    u8 c4[4]; if (!get(c4, 4)) { bad = true; return false; }
+                    if (((u32)c4[0] | (u32)c4[1] << 8 | (u32)c4[2] << 16 | (u32)c4[3] << 24) != content.digest()) { bad = true; return false; }
+                }
                 in_frame = false;
                 continue;
             }
@@ -313,10 +396,15 @@ struct Lz4In {
             if (n > (8u << 20)) { bad = true; return false; }
             blk.resize(n);
             if (!get(blk.data(), n)) { bad = true; return false; }
-            if (blk_sum) { u8 c4[4]; if (!get(c4, 4)) { bad = true; return false; } }
+            if (blk_sum) {
+                u8 c4[4]; if (!get(c4, 4)) { bad = true; return false; }
+                if (((u32)c4[0] | (u32)c4[1] << 8 | (u32)c4[2] << 16 | (u32)c4[3] << 24) != xxh32(blk.data(), n, 0)) { bad = true; return false; }
+            }
             if (rd > (64u << 10)) { const size_t drop = rd - (64u << 10); out.erase(out.begin(), out.begin() + (long)drop); rd -= drop; }   // keep 64 KiB of history
+            const size_t before = out.size();
             if (w & 0x80000000u) out.insert(out.end(), blk.begin(), blk.end());
             else if (!decode_block(blk.data(), n)) { bad = true; return false; }
+            if (content_sum) content.update(out.data() + before, out.size() - before);
             return true;
         }
     }
@@ -556,7 +644,7 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
         if (r->bases.size() >= max_bases) break;
     }
     *bases = r->bases.data(); *offsets = r->offs.data(); *n_reads = r->offs.size() - 1;
-    return r->io_error ? MDBG_E_PARAM : MDBG_OK;             // a malformed compressed stream
+    return r->io_error ? MDBG_E_IO : MDBG_OK;                // a malformed / truncated compressed stream
 }
 
 void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->map) munmap((void*)r->map, r->map_size); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }

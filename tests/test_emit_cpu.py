@@ -28,28 +28,66 @@ def oracle_edges(r):
     return sorted(zip(r["edge_n1"].tolist(), r["edge_o1"].tolist(), r["edge_n2"].tolist(), r["edge_o2"].tolist(), r["edge_overlap"].tolist()))
 
 
-def read_lz4_frame(path):
-    """minimal LZ4 frame reader (stored and compressed blocks are both legal; we only write stored ones)"""
+def lz4_block_decode(src):
+    """LZ4 block format, written from its specification (test-side decoder, independent of the library's)"""
+    out = bytearray()
+    i, n = 0, len(src)
+    while i < n:
+        tok = src[i]; i += 1
+        lit = tok >> 4
+        if lit == 15:
+            while True:
+                b = src[i]; i += 1; lit += b
+                if b != 255:
+                    break
+        out += src[i:i + lit]; i += lit
+        if i >= n:
+            break                                  # the last sequence has literals only
+        off = src[i] | src[i + 1] << 8; i += 2
+        ml = tok & 15
+        if ml == 15:
+            while True:
+                b = src[i]; i += 1; ml += b
+                if b != 255:
+                    break
+        ml += 4
+        assert 0 < off <= len(out)
+        for _ in range(ml):                        # byte by byte: a match may overlap its own output
+            out.append(out[-off])
+    return bytes(out)
+
+
+def read_lz4_frame(path, stats=None):
+    """minimal LZ4 frame reader: independent blocks, stored or compressed"""
     raw = open(path, "rb").read()
     assert raw[:4] == b"\x04\x22\x4d\x18"
     flg, bd, hc = raw[4], raw[5], raw[6]
-    assert flg >> 6 == 1 and not (flg & 0x0C) and not (flg & 1)           # version 01, no content size/checksum, no dict id
+    assert flg >> 6 == 1 and (flg & 0x20) and not (flg & 0x0C) and not (flg & 1)   # version 01, independent blocks, no content size/checksum, no dict id
     import xxhash
     assert hc == (xxhash.xxh32(raw[4:6], seed=0).intdigest() >> 8) & 0xFF   # header checksum per the LZ4 frame format
-    pos, out = 7, b""
+    pos, out = 7, []
+    n_comp = n_stored = 0
     while True:
         (sz,) = struct.unpack_from("<I", raw, pos)
         pos += 4
         if sz == 0:
             break
-        assert sz & 0x80000000, "compressed block: not expected from this writer"
         n = sz & 0x7FFFFFFF
-        out += raw[pos:pos + n]
+        assert n <= 4 << 20
+        if sz & 0x80000000:
+            out.append(raw[pos:pos + n]); n_stored += 1
+        else:
+            blk = lz4_block_decode(raw[pos:pos + n]); n_comp += 1
+            assert len(blk) <= 4 << 20
+            # the format's end rules: the last five bytes of a block are literals
+            out.append(blk)
         pos += n
         if flg & 0x10:
             pos += 4
     assert pos == len(raw)
-    return out
+    if stats is not None:
+        stats.update(compressed_blocks=n_comp, stored_blocks=n_stored, file_bytes=len(raw))
+    return b"".join(out)
 
 
 def test_example_cfg1_edges_and_files(example_reads, tmp_path):
@@ -153,3 +191,33 @@ def test_parallel_sequences_writer_same_lines(example_reads, tmp_path):
         assert txt[0].startswith("# k = ")
         got += [x for x in txt if x and not x.startswith("#")]
     assert sorted(got) == sorted(want) and len(want) == r["n_nodes"]
+
+
+def test_sequences_blocks_are_compressed(tmp_path):
+    """the .sequences frame holds COMPRESSED LZ4 blocks (the reference writes its files through lzzzz's frame compressor, src/main.rs:65):
+    a test-side decoder reproduces the lines, blocks larger than one 4-MiB block included, and the file is well under the text's size"""
+    from rust_mdbg_amd import synth
+    k, l, d, a = 12, 12, 0.01, 2
+    reads = synth.synth_reads(11, 300000, 1400, mean_len=9000, sd_len=1000, min_len=4000, max_len=15000, err_ppm=1000)
+    r, b, o = oracle_run(reads, k, l, d, a)
+    assert r["n_nodes"] > 4500
+    em = E.Emitter()
+    em.edges(r)
+    p = str(tmp_path / "big.0.sequences")
+    em.write_sequences(p, r, l, [(b, o, 0)])
+    st = {}
+    lines = read_lz4_frame(p, st).decode().split("\n")
+    body = [x for x in lines if x and not x.startswith("#")]
+    assert len(body) == r["n_nodes"]
+    text_bytes = sum(len(x) + 1 for x in lines)
+    assert text_bytes > (4 << 20), "the case must span more than one block"
+    assert st["compressed_blocks"] >= 2 and st["stored_blocks"] == 0
+    assert st["file_bytes"] < 0.62 * text_bytes, (st, text_bytes)
+    # every line parses the way src/to_basespace.rs:203-214 does: index, [minimizers], sequence, *, *, (s0, s1)
+    idx = set()
+    for x in body[:2000]:
+        f = x.split("\t")
+        assert len(f) == 6 and f[3] == "*" and f[4] == "*" and f[1].startswith("[") and f[5].startswith("(")
+        assert len(f[1][1:-1].split(", ")) == k and set(f[2]) <= set("ACGTN")
+        idx.add(int(f[0]))
+    assert len(idx) == 2000

@@ -94,20 +94,20 @@ def lz4_block(data, history=b""):
 
 def lz4_frame(data, block=1 << 16, linked=True, block_checksum=False, content_checksum=False, store_every=0):
     import struct
+    import xxhash
     flg = 0x40 | (0 if linked else 0x20) | (0x10 if block_checksum else 0) | (0x04 if content_checksum else 0)
-    out = bytearray(struct.pack("<I", 0x184D2204) + bytes([flg, 0x40, 0]))       # BD: 64 KiB blocks; header checksum byte is not verified
+    desc = bytes([flg, 0x40])                                                     # BD: 64 KiB blocks
+    out = bytearray(struct.pack("<I", 0x184D2204) + desc + bytes([(xxhash.xxh32(desc, seed=0).intdigest() >> 8) & 0xFF]))
     for bi, a in enumerate(range(0, len(data), block)):
         chunk = data[a:a + block]
         comp = lz4_block(chunk, data[max(0, a - 65535):a] if linked else b"")
-        if (store_every and bi % store_every == 0) or len(comp) >= len(chunk):
-            out += struct.pack("<I", len(chunk) | 0x80000000) + chunk
-        else:
-            out += struct.pack("<I", len(comp)) + comp
+        payload = chunk if (store_every and bi % store_every == 0) or len(comp) >= len(chunk) else comp
+        out += struct.pack("<I", len(payload) | (0x80000000 if payload is chunk else 0)) + payload
         if block_checksum:
-            out += b"\0\0\0\0"
+            out += struct.pack("<I", xxhash.xxh32(payload, seed=0).intdigest())
     out += struct.pack("<I", 0)
     if content_checksum:
-        out += b"\0\0\0\0"
+        out += struct.pack("<I", xxhash.xxh32(data, seed=0).intdigest())
     return bytes(out)
 
 
@@ -135,6 +135,22 @@ def test_lz4_input(tmp_path, example_reads):
     assert collect(str(fq)) == ([b"ACGT", b"GG"], False)
     bad = tmp_path / "bad.fa.lz4"
     bad.write_bytes(lz4_frame(text)[:-30000])
+    with pytest.raises(Exception):
+        collect(str(bad))
+    # checksums are verified: one flipped bit in a STORED block (nothing else would notice it), in the content, in the header
+    good = bytearray(lz4_frame(text, block_checksum=True, store_every=1))
+    good[7 + 4 + 1000] ^= 0x04
+    bad.write_bytes(bytes(good))
+    with pytest.raises(Exception, match="-7"):
+        collect(str(bad))
+    good = bytearray(lz4_frame(text, content_checksum=True, store_every=1))
+    good[7 + 4 + 1000] ^= 0x04
+    bad.write_bytes(bytes(good))
+    with pytest.raises(Exception):
+        collect(str(bad))
+    good = bytearray(lz4_frame(text))
+    good[5] ^= 0x10                                                                          # BD byte no longer matches the header checksum
+    bad.write_bytes(bytes(good))
     with pytest.raises(Exception):
         collect(str(bad))
 
