@@ -69,6 +69,19 @@ def parse():
     return a
 
 
+def expected_graph(args, world, reads_per_gpu, n_bases):
+    """the graph this workload must produce (tests/golden/bench_counts.json), or None for a workload that has no recorded counts"""
+    try:
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))
+    except OSError:
+        return None
+    for w in ref["workloads"]:
+        if (w["k"], w["l"], w["density"], w["minabund"], w["genome_mb"], w["coverage"], w["n_gpus"], w["reads_per_gpu"], w["bases_per_gpu"]) == \
+           (args.k, args.l, args.density, args.minabund, args.genome_mb, args.coverage, world, reads_per_gpu, n_bases):
+            return w["graph"]
+    return None
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run on this node and become
     that launcher.  Fewer than N visible GPUs is an error, not an N=1 run."""
@@ -349,6 +362,10 @@ def main():
         cpu = None
         if args.cpu_seconds > 0:
             cpu = cpu_baseline(m, d_bases, d_off, reads_per_gpu, n_bases, args)
+        graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
+        want = expected_graph(args, world, reads_per_gpu, n_bases)
+        if want is not None and not os.environ.get("MDBG_STOP_PHASE") and any(graph[f] != want[f] for f in want):
+            raise SystemExit("bench.py: the graph of this run %r differs from the recorded one %r (tests/golden/bench_counts.json): no line printed" % (graph, want))
         out = {"metric": "Gbases/s ingested to k-min-mer graph", "value": value, "unit": "Gbases/s", "n_gpus": n_ranks, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
@@ -361,6 +378,7 @@ def main():
                "roofline": roof, "roofline_ascii": roof_ascii, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
+                         "checked_against_recorded_counts": want is not None,
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent},
                "edges_after_timed_region": edges}

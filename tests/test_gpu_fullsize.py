@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+from conftest import ROOT
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -80,6 +81,23 @@ def test_config3_size_properties():
         two = m.finalize()
         for f in FIELDS:
             assert np.array_equal(one[f], two[f]), f
+        # 4b. the PACKED path (what bench.py times) gives the identical table at full size, and the counts are the ones bench.py checks
+        import torch
+        words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()      # the fill ran on torch's stream, the packer runs on the context's
+        assert m.pack_device(db, nb, words.data_ptr()) == 0
+        m.reset(0)
+        m.ingest_packed_device(words.data_ptr(), do, n_reads, nb, 0)
+        three = m.finalize()
+        st3 = m.stats()
+        for f in FIELDS:
+            assert np.array_equal(one[f], three[f]), f
+        del words
+        import json
+        want = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w["reads_per_gpu"] == n_reads and w["l"] == l][0]
+        assert nb == want["bases_per_gpu"]
+        assert {"minimizers": st3["n_minimizers"], "windows": st3["n_windows"], "distinct": st3["n_distinct"], "nodes": three["n_nodes"]} == want["graph"]
+        assert (st["n_minimizers"], st["n_windows"], st["n_distinct"]) == (st3["n_minimizers"], st3["n_windows"], st3["n_distinct"])
         # 5. multi-k on the resident sketches == a fresh context with that k
         m.reset(21)
         k21 = m.finalize()
