@@ -131,7 +131,7 @@ BS_HD bs_u32 bs_pk_shl16(bs_u32 x, bs_u32 s) {
     return hi | lo;
 #endif
 }
-BS_HD bs_u64 bs_rol64(bs_u64 x, unsigned r) { r &= 63; return (x << r) | (x >> ((64 - r) & 63)); }
+BS_HD constexpr bs_u64 bs_rol64(bs_u64 x, unsigned r) { return (x << (r & 63)) | (x >> ((64 - (r & 63)) & 63)); }
 
 // plane "in[p - u]" of a stream held as (prev2, prev, cur) words, u in 0..63
 BS_HD bs_u32 bs_delay(bs_u32 cur, bs_u32 prev, bs_u32 prev2, int u) {
@@ -322,20 +322,29 @@ BS_HD bs_u32 bs_strand_compare(const bs_u32 W[BS_B], const bs_u32 Wp[BS_B], bs_u
 // v0 / v1: the code planes of the 32 dense positions ending at the candidate, bit u = position e - u.
 // tab: (1 << 2*GS) x {F, R}: GS-base groups indexed by (GS bits of v0) | (GS bits of v1) << GS, bit v = distance v:
 //   F = XOR_v rol(h[c_v], v), R = XOR_v rol(rc[c_v], GS - 1 - v).
-template <int GS>
-BS_HD bs_u64 bs_exact_hash(bs_u32 v0, bs_u32 v1, int l, const bs_u64* tab) {
+// A last group of T = l mod GS bases is looked up like a full one with its missing (farther) positions read as code 0 ('A'); what
+// 'A' contributes at those positions is a compile-time constant that is XORed out again (round 2 evaluated the tail base by base
+// with select chains over the 64-bit seeds: 14 more registers for l = 14).
+template <int GS, int T> BS_HD constexpr bs_u64 bs_tail_f() { bs_u64 k = 0; for (int v = T; v < GS; ++v) k ^= bs_rol64(bs_seed_f(0), (unsigned)v); return k; }
+template <int GS, int T> BS_HD constexpr bs_u64 bs_tail_r() { bs_u64 k = 0; for (int v = T; v < GS; ++v) k ^= bs_rol64(bs_seed_r(0), (unsigned)(GS - 1 - v)); return k; }
+template <int GS, int L>
+BS_HD bs_u64 bs_exact_hash(bs_u32 v0, bs_u32 v1, const bs_u64* tab) {
     bs_u64 fh = 0, rh = 0;
-    const int G = l / GS;
+    constexpr int G = L / GS, T = L % GS;
     constexpr bs_u32 M = (1u << GS) - 1u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
     for (int g = 0; g < G; ++g) {
         const bs_u32 idx = ((v0 >> (GS * g)) & M) | (((v1 >> (GS * g)) & M) << GS);
         fh ^= bs_rol64(tab[2 * idx], (unsigned)(GS * g));
-        rh ^= bs_rol64(tab[2 * idx + 1], (unsigned)(l - GS - GS * g));
+        rh ^= bs_rol64(tab[2 * idx + 1], (unsigned)(L - GS - GS * g));
     }
-    for (int u = GS * G; u < l; ++u) {
-        const int c = (int)(((v1 >> u) & 1u) << 1 | ((v0 >> u) & 1u));
-        fh ^= bs_rol64(bs_seed_f(c), (unsigned)u);
-        rh ^= bs_rol64(bs_seed_r(c), (unsigned)(l - 1 - u));
+    if (T) {
+        constexpr bs_u32 MT = (1u << T) - 1u;
+        const bs_u32 idx = ((v0 >> (GS * G)) & MT) | (((v1 >> (GS * G)) & MT) << GS);
+        fh ^= bs_rol64(tab[2 * idx] ^ bs_tail_f<GS, T>(), (unsigned)(GS * G));
+        rh ^= bs_rol64(tab[2 * idx + 1] ^ bs_tail_r<GS, T>(), (unsigned)((64 + T - GS) & 63));       // l - 1 - (GS*G + v) = (T - GS) + (GS - 1 - v)
     }
     return fh < rh ? fh : rh;
 }

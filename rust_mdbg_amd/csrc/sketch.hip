@@ -154,7 +154,7 @@ constexpr int HW = HALO_BASES / 32;           // leading halo words
 constexpr int TT = TILE_THREADS;
 constexpr int WPT = RW / TT;                  // raw words per thread
 constexpr int DPAD = 4;                       // zero words in front of the dense stream (look-back of the first words)
-constexpr int QCAP = 704;                     // candidates that fit the unordered list (evaluated in rounds of TILE_THREADS)
+constexpr int QCAP = 448;                     // candidates that fit the unordered list (evaluated in rounds of TILE_THREADS); more: the word-wise rounds
 constexpr int RS_CAP = 32;                    // read starts of a tile kept in LDS (more: binary search in global memory)
 
 struct __attribute__((aligned(16))) TileLds {
@@ -162,17 +162,23 @@ struct __attribute__((aligned(16))) TileLds {
                                               // words hold the read-start bitmap (every reader zeroes what it read)
     u32 kw[RW];                               // keep mask of raw word w
     u16 rpre[RW + 8];                         // kept bases in front of raw word w; [RW] = all
-    u16 dfirst[RW + 8];                       // raw word that holds dense position 32 * D
-    union {
-        u32 stage[2 * RW];                    // FMT_ASCII: half planes of the 16-base chunks (phase 1 only)
-        struct { u32 cand[RW + 8]; u16 cpre[RW + 8]; u16 list[QCAP]; u16 surv[TILE_THREADS]; } c;    // cpre doubles as the survivors' hashes (u64 x TT) before count_words
-    } a;
+    struct { u32 cand[RW + 8]; u16 cpre[RW + 8]; u16 list[QCAP]; u16 surv[TILE_THREADS]; } c;    // cpre doubles as the survivors' hashes (u64 x TT) before count_words
     u64 t3[2 << (2 * BS_GS)];                 // exact evaluation: 3-base groups {F, R}
-    int64_t rs_rel[RS_CAP];                   // start of read rl + i, relative to the first staged position
+    int64_t rs0;                              // start of read rl relative to the first staged position (may lie far in front of it)
+    int32_t rs_rel[RS_CAP];                   // start of read rl + i, i >= 1, likewise (clamped to 2^31 - 1)
     u32 misc[32];                             // [0..4] scan scratch, [8] slow, [11] Hh, [16] next round, [17] list fill, [18..20] survivors per round
+#ifdef MDBG_LDS_PAD
+    u32 pad_experiment[MDBG_LDS_PAD / 4];     // occupancy experiments only (scratch/build_variant.sh)
+#endif
 };
-static_assert(sizeof(TileLds) * 6 <= 160 * 1024, "6 workgroups per CU");
-static_assert((RW + 8) * 2 >= TILE_THREADS * 8 && ((RW + 8) * 4) % 8 == 0, "cpre holds one u64 per thread");
+// FMT_ASCII stages the half planes of its 16-base chunks (2 * RW words, phase 1 only) in memory that is idle then: the part of the dense
+// stream behind the read-start bitmap plus the keep masks (the stream part is zeroed again before phase 2 writes it)
+constexpr int STAGE_AT = 2 * (DPAD + RW + 4) + RW - 2 * RW;      // index into dense[]: the stage ends where kw[] ends
+static_assert(STAGE_AT >= RW && STAGE_AT % 4 == 0 && offsetof(TileLds, kw) == sizeof(u32) * 2 * (DPAD + RW + 4), "stage = dense[STAGE_AT ..) + kw[]");
+#ifndef MDBG_LDS_PAD
+static_assert(sizeof(TileLds) * 7 <= 160 * 1024, "7 workgroups per CU");
+#endif
+static_assert((RW + 8) * 2 >= TILE_THREADS * 8 && ((RW + 8) * 4) % 8 == 0 && offsetof(TileLds, c) % 16 == 0, "cpre holds one u64 per thread");
 
 // 16 ASCII bases -> {plane0 half | plane1 half}, MSB first (base 0 in bits 31 / 15); bad != 0: a byte outside ACGT
 __device__ inline u32 ascii16_to_hp(uint4 v, u32& bad) {
@@ -263,7 +269,7 @@ struct CandOut { u64 hash; u32 pos, read; };
 // and dropped: the loop makes the compiler keep ~100 more values live across the phases, 3-4 instead of 6 waves per SIMD, 3.4-4.9 ms
 // instead of 2.2 ms; capped to 80 registers it spills and is no better.  profiles/r02_notes.md.)
 template <int L>
-__global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
+__global__ __launch_bounds__(TT, 7) void sketch_bs_kernel(SketchArgs a) {
     __shared__ TileLds S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t nb = (int64_t)a.n_bases;
@@ -311,19 +317,20 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     if (rh_ - rl < (u32)TREC_N) {                       // the usual case: the read starts come with the tile's record
         if ((u32)tid <= rh_ - rl) {
             const int64_t rel = tid == 0 ? rec->start0 : (int64_t)rec->rel[tid - 1];
-            S.rs_rel[tid] = rel;
+            if (tid == 0) S.rs0 = rel; else S.rs_rel[tid] = (int32_t)rel;
             if (rel >= 0 && rel < RW * 32) atomicOr(&S.dense[rel >> 5], 0x80000000u >> (rel & 31));
         }
     } else for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) {
         const int64_t rel = (int64_t)a.offsets[r] - raw0;
-        if (r - rl < RS_CAP) S.rs_rel[r - rl] = rel;
+        if (r == rl) S.rs0 = rel; else if (r - rl < RS_CAP) S.rs_rel[r - rl] = (int32_t)(rel > 0x7FFFFFFF ? 0x7FFFFFFF : rel);
         if (rel >= 0 && rel < RW * 32) atomicOr(&S.dense[rel >> 5], 0x80000000u >> (rel & 31));
     }
+    u32* const stage = S.dense + STAGE_AT;
     if (a.fmt == FMT_ASCII) {
         u32 bad_any = 0;
         if (interior) {
 #pragma unroll
-            for (int g = 0; g < CPT; ++g) S.a.stage[tid + TT * g] = ascii16_to_hp(av[g], bad_any);
+            for (int g = 0; g < CPT; ++g) stage[tid + TT * g] = ascii16_to_hp(av[g], bad_any);
         } else {
 #pragma unroll 1
             for (int g = 0; g < CPT; ++g) {
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
                 u32 w4[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};     // positions outside the batch read as 'A' (masked below)
                 if (pos >= 0 && pos + 16 <= nb) { const uint4 q = *(const uint4*)(a.bases + pos); w4[0] = q.x; w4[1] = q.y; w4[2] = q.z; w4[3] = q.w; }
                 else for (int i = 0; i < 16; ++i) if (pos + i >= 0 && pos + i < nb) w4[i >> 2] = (w4[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((u32)a.bases[pos + i] << (8 * (i & 3)));
-                S.a.stage[ci] = ascii16_to_hp(make_uint4(w4[0], w4[1], w4[2], w4[3]), bad_any);
+                stage[ci] = ascii16_to_hp(make_uint4(w4[0], w4[1], w4[2], w4[3]), bad_any);
             }
         }
         if (bad_any) {                               // some byte of my chunks is not one of ACGT: the tile takes the generic path
@@ -348,10 +355,13 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const uint2 h = *(const uint2*)(S.a.stage + 2 * (WPT * tid + i));
+            const uint2 h = *(const uint2*)(stage + 2 * (WPT * tid + i));
             x0[i] = (h.x & 0xFFFF0000u) | (h.y >> 16); x1[i] = (h.x << 16) | (h.y & 0xFFFFu);
         }
-        if (tid) { const u32 hp = S.a.stage[2 * WPT * tid - 1]; pv0 = hp >> 16; pv1 = hp; }
+        if (tid) { const u32 hp = stage[2 * WPT * tid - 1]; pv0 = hp >> 16; pv1 = hp; }
+        __syncthreads();                                     // the stage has been read: its stream part goes back to zero (the barriers of the scan below order this before the stream writes)
+        static_assert((2 * (DPAD + RW + 4) - STAGE_AT) == 4 * TT && STAGE_AT % 4 == 0, "one 16-byte store per thread");
+        ((uint4*)(S.dense + STAGE_AT))[tid] = make_uint4(0u, 0u, 0u, 0u);
     } else {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) { x0[i] = __brev(pr[i].x); x1[i] = __brev(pr[i].y); }
@@ -402,8 +412,6 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         const u32 n = n_kept[i];
         if (n) {
             const u32 wi = off >> 5, s = off & 31;
-            const u32 d_first = (off + 31) >> 5;
-            if (32 * d_first < off + n) S.dfirst[d_first] = (u16)w;
             unsigned long long* dst = (unsigned long long*)(S.dense + 2 * (DPAD + wi));
             atomicOr(dst, (unsigned long long)(x0[i] >> s) | ((unsigned long long)(x1[i] >> s) << 32));
             if (s + n > 32) atomicOr(dst + 1, (unsigned long long)bs_alignbit(x0[i], 0u, s) | ((unsigned long long)bs_alignbit(x1[i], 0u, s) << 32));
@@ -459,16 +467,16 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
             // only the step that holds the first owned position and the one that holds the last need the range mask (wave-uniform test)
             const int Dw0 = (int)(63 * st) - 1;
             if (32 * Dw0 < x_lo || 32 * (Dw0 + 64) > x_hi) cand &= range_mask((int64_t)x_lo - 32 * (int64_t)D, (int64_t)x_hi - 32 * (int64_t)D);
-            if (lane && (u32)D < n_out) S.a.c.cand[D] = cand;
+            if (lane && (u32)D < n_out) S.c.cand[D] = cand;
         }
-        for (u32 D = n_out + tid; D < RW + 8; D += TT) S.a.c.cand[D] = 0;
+        for (u32 D = n_out + tid; D < RW + 8; D += TT) S.c.cand[D] = 0;
     }
     __syncthreads();
     // the (unordered) candidate list: every thread expands the bitmap words 4 tid .. 4 tid + 3.  (Round 2 and the first version of this
     // round appended to the list inside the filter loop: one LDS fetch-add and a bit loop per step, 12 times per wave instead of once.)
     {
-        const uint4 cw = *(const uint4*)(S.a.c.cand + WPT * tid);
-        const u32 w5[5] = {cw.x, cw.y, cw.z, cw.w, tid == TT - 1 ? S.a.c.cand[RW] : 0u};       // the last thread also takes word RW
+        const uint4 cw = *(const uint4*)(S.c.cand + WPT * tid);
+        const u32 w5[5] = {cw.x, cw.y, cw.z, cw.w, tid == TT - 1 ? S.c.cand[RW] : 0u};       // the last thread also takes word RW
         const u32 c = bs_popc(cw.x) + bs_popc(cw.y) + bs_popc(cw.z) + bs_popc(cw.w) + bs_popc(w5[4]);
         if (c) {
             u32 slot = lds_fetch_add(&S.misc[17], c);
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
                 u32 w = w5[i];
                 while (w) {
                     const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b);
-                    if (slot < QCAP) S.a.c.list[slot] = (u16)(32 * (WPT * tid + i) + b - (BS_B - 1));
+                    if (slot < QCAP) S.c.list[slot] = (u16)(32 * (WPT * tid + i) + b - (BS_B - 1));
                     ++slot;
                 }
             }
@@ -490,14 +498,14 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
     // ---- phase 4: exact evaluation, ranks, records -------------------------------------------------------------------
     const int nw = tid == TT - 1 ? WPT + 1 : WPT;                     // words 4*tid .. ; the last thread also takes word RW
     auto count_words = [&]() -> u32 {                                 // cpre[] <- exclusive counts of the bitmap per word; returns the total
-        const uint4 cw = *(const uint4*)(S.a.c.cand + WPT * tid);
+        const uint4 cw = *(const uint4*)(S.c.cand + WPT * tid);
         const u32 c0 = bs_popc(cw.x), c1 = bs_popc(cw.y), c2 = bs_popc(cw.z), c3 = bs_popc(cw.w);
-        const u32 last = tid == TT - 1 ? bs_popc(S.a.c.cand[RW]) : 0u;       // the last thread also takes word RW
+        const u32 last = tid == TT - 1 ? bs_popc(S.c.cand[RW]) : 0u;       // the last thread also takes word RW
         u32 total;
         const u32 o = block_excl_scan_256(c0 + c1 + c2 + c3 + last, S.misc, total);
         const u32 o1 = o + c0, o2 = o1 + c1, o3 = o2 + c2;
-        *(uint2*)(S.a.c.cpre + WPT * tid) = make_uint2(o | o1 << 16, o2 | o3 << 16);
-        if (tid == TT - 1) S.a.c.cpre[RW] = (u16)(o3 + c3);
+        *(uint2*)(S.c.cpre + WPT * tid) = make_uint2(o | o1 << 16, o2 | o3 << 16);
+        if (tid == TT - 1) S.c.cpre[RW] = (u16)(o3 + c3);
         __syncthreads();
         return total;
     };
@@ -509,20 +517,26 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         u32 hi = c0;
         for (int i = 0; i < nw; ++i) {
             const int D = WPT * tid + i;
-            u32 w = S.a.c.cand[D];
-            u32 r = S.a.c.cpre[D];
+            u32 w = S.c.cand[D];
+            u32 r = S.c.cpre[D];
             const u32 n = bs_popc(w);
             if (n == 0 || r < c0 || r + n > c0 + QCAP) continue;
             hi = r + n;
-            while (w) { const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b); S.a.c.list[r - c0] = (u16)(32 * D + b - (BS_B - 1)); ++r; }
+            while (w) { const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b); S.c.list[r - c0] = (u16)(32 * D + b - (BS_B - 1)); ++r; }
         }
         if (hi > c0) atomicMax(&S.misc[16], hi);
         __syncthreads();
         return S.misc[16];
     };
-    auto dense_to_raw = [&](u32 r) -> u32 {                            // tile-relative raw position of dense position r
-        u32 w = S.dfirst[r >> 5];
-        while (S.rpre[w + 1] <= r) ++w;
+    // tile-relative raw position of dense position r.  The kept fraction is nearly uniform along a tile, so r * RW / H lands within a word
+    // or two of the raw word that holds r (round 2 kept a table of first raw words per dense word: 2 KB of LDS and five instructions
+    // per raw word in phase 2; that LDS is what admits a seventh workgroup per CU)
+    const float raw_per_dense = (float)RW / (float)(H ? H : 1u);
+    auto dense_to_raw = [&](u32 r) -> u32 {
+        u32 w = (u32)((float)r * raw_per_dense);
+        w = w < (u32)RW - 1u ? w : (u32)RW - 1u;
+        while (S.rpre[w] > r) --w;                                      // rpre[0] = 0 <= r
+        while (S.rpre[w + 1] <= r) ++w;                                 // rpre[RW] = H > r
         return 32 * w + bs_select_msb(S.kw[w], r - S.rpre[w]);
     };
     const u32 n_rs = rh_ - rl + 1;                                     // reads that touch the staged range
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         const u32 wi = e >> 5, s = e & 31;
         const u32* dw = S.dense + 2 * (DPAD + wi);
         const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);
-        return bs_exact_hash<BS_GS>(v0, v1, L, S.t3);
+        return bs_exact_hash<BS_GS, L>(v0, v1, S.t3);
     };
     // raw coordinates of a selected l-mer (src/read.rs:196-208): its FIRST base decides the read; an l-mer that runs over the next
     // read's start (a forced run start, so its dense rank is the number of kept bases in front of it) belongs to no read
@@ -541,8 +555,8 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         u32 r; int64_t q0, q1;                                         // the read holding the first base; q0: its start, q1: the next read's, tile-relative
         if (n_rs <= RS_CAP) {
             u32 i = 0;
-            while (i + 1 < n_rs && S.rs_rel[i + 1] <= rel_start) ++i;
-            r = rl + i; q0 = S.rs_rel[i]; q1 = i + 1 < n_rs ? S.rs_rel[i + 1] : (int64_t)RW * 32;
+            while (i + 1 < n_rs && (int64_t)S.rs_rel[i + 1] <= rel_start) ++i;
+            r = rl + i; q0 = i ? (int64_t)S.rs_rel[i] : S.rs0; q1 = i + 1 < n_rs ? (int64_t)S.rs_rel[i + 1] : (int64_t)RW * 32;
         } else {
             r = find_read(a.offsets, rl, rh_, (u64)(raw0 + rel_start)); q0 = (int64_t)a.offsets[r] - raw0;
             q1 = r < rh_ ? (int64_t)a.offsets[r + 1] - raw0 : (int64_t)RW * 32;
@@ -562,8 +576,8 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         const u64 h = exact(e);
         return h <= a.bound && place(e, h, o);
     };
-    auto clear_bit = [&](u32 e) { const u32 x = e + BS_B - 1; atomicAnd(&S.a.c.cand[x >> 5], ~(0x80000000u >> (x & 31))); };
-    auto rank_of = [&](u32 e) -> u32 { const u32 x = e + BS_B - 1, D = x >> 5, b = x & 31; return S.a.c.cpre[D] + (b ? bs_popc(S.a.c.cand[D] >> (32 - b)) : 0u); };
+    auto clear_bit = [&](u32 e) { const u32 x = e + BS_B - 1; atomicAnd(&S.c.cand[x >> 5], ~(0x80000000u >> (x & 31))); };
+    auto rank_of = [&](u32 e) -> u32 { const u32 x = e + BS_B - 1, D = x >> 5, b = x & 31; return S.c.cpre[D] + (b ? bs_popc(S.c.cand[D] >> (32 - b)) : 0u); };
 
     const u32 n_cand = S.misc[17];
     if (n_cand <= QCAP) {
@@ -573,24 +587,24 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         // leave the bitmap; the popcount scan of the bitmap then ranks the survivors in position order.
         constexpr int NR = (QCAP + TT - 1) / TT;
         CandOut keep[NR] = {}; u32 keep_e[NR] = {}; u32 keep_ok = 0;
-        u64* const s_h = (u64*)S.a.c.cpre;
+        u64* const s_h = (u64*)S.c.cpre;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if ((u32)(TT * i) < n_cand) {
                 if (i) __syncthreads();                               // the previous round's survivors have been read
                 const u32 j = tid + TT * i;
                 bool pass = false; u32 e = 0; u64 h = 0;
-                if (j < n_cand) { e = S.a.c.list[j]; h = exact(e); pass = h <= a.bound; if (!pass) clear_bit(e); }
+                if (j < n_cand) { e = S.c.list[j]; h = exact(e); pass = h <= a.bound; if (!pass) clear_bit(e); }
                 const u64 bal = __ballot(pass);
                 if (bal) {
                     u32 base = 0;
                     if (lane == 0) base = atomicAdd(&S.misc[18 + i], (u32)__popcll(bal));
                     base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                    if (pass) { const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)); S.a.c.surv[slot] = (u16)e; s_h[slot] = h; }
+                    if (pass) { const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)); S.c.surv[slot] = (u16)e; s_h[slot] = h; }
                 }
                 __syncthreads();
                 if ((u32)tid < S.misc[18 + i]) {
-                    e = S.a.c.surv[tid];
+                    e = S.c.surv[tid];
                     keep_e[i] = e;
                     if (place(e, s_h[tid], keep[i])) keep_ok |= 1u << i; else clear_bit(e);
                 }
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         const u32 n_all = count_words();
         for (u32 c0 = 0; c0 < n_all;) {
             const u32 c1 = build_list(c0);
-            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; const u32 e = S.a.c.list[j]; if (!eval(e, o)) clear_bit(e); }
+            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; const u32 e = S.c.list[j]; if (!eval(e, o)) clear_bit(e); }
             __syncthreads();
             c0 = c1;
         }
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(TT) void sketch_bs_kernel(SketchArgs a) {
         MDBG_STAMP(5);
         for (u32 c0 = 0; c0 < nv;) {
             const u32 c1 = build_list(c0);
-            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; if (eval(S.a.c.list[j], o)) put_rec(a, slab, c0 + j, o.hash, o.pos, o.read); }
+            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; if (eval(S.c.list[j], o)) put_rec(a, slab, c0 + j, o.hash, o.pos, o.read); }
             __syncthreads();
             c0 = c1;
         }

@@ -60,7 +60,7 @@ void tile(const u8* bases, int64_t nb, const u64* offsets, u32 n_reads, bool hpc
     const int64_t raw0 = (int64_t)gt * TILE_STRIDE - HALO_BASES;
     const int64_t first_base = (int64_t)offsets[0];
     std::vector<u32> dense(2 * (DPAD + RW + 4), 0), kw(RW), force(RW, 0), cand(RW + 8, 0);
-    std::vector<u16> rpre(RW + 8, 0), dfirst(RW + 8, 0), cpre(RW + 8, 0);
+    std::vector<u16> rpre(RW + 8, 0), cpre(RW + 8, 0);
     for (u32 r = 0; r < n_reads; ++r) { const int64_t rel = (int64_t)offsets[r] - raw0; if (rel >= 0 && rel < RW * 32) force[rel >> 5] |= 0x80000000u >> (rel & 31); }
     // phase 1: planes (MSB first), alphabet
     std::vector<u32> X0(RW, 0), X1(RW, 0);
@@ -91,8 +91,7 @@ void tile(const u8* bases, int64_t nb, const u64* offsets, u32 n_reads, bool hpc
         kw[w] = k; rpre[w] = (u16)off;
         const u32 n = bs_popc(k);
         if (n) {
-            const u32 wi = off >> 5, s = off & 31, d_first = (off + 31) >> 5;
-            if (32 * d_first < off + n) dfirst[d_first] = (u16)w;
+            const u32 wi = off >> 5, s = off & 31;
             dense[2 * (DPAD + wi)] |= x0 >> s; dense[2 * (DPAD + wi) + 1] |= x1 >> s;
             if (s + n > 32) { dense[2 * (DPAD + wi + 1)] |= bs_alignbit(x0, 0u, s); dense[2 * (DPAD + wi + 1) + 1] |= bs_alignbit(x1, 0u, s); }
         }
@@ -136,8 +135,11 @@ void tile(const u8* bases, int64_t nb, const u64* offsets, u32 n_reads, bool hpc
     const u32 e_lo = Hh > (u32)(L - 1) ? Hh : (u32)(L - 1);
     for (int D = 0; D <= RW; ++D)
         cand[D] = (u32)D < n_out ? cand[D] & range_mask((int64_t)e_lo + BS_B - 1 - 32 * (int64_t)D, (int64_t)H + BS_B - 1 - 32 * (int64_t)D) : 0u;
+    const float raw_per_dense = (float)RW / (float)(H ? H : 1u);        // the kernel's first guess of the raw word (sketch.hip, dense_to_raw)
     auto dense_to_raw = [&](u32 r) -> u32 {
-        u32 w = dfirst[r >> 5];
+        u32 w = (u32)((float)r * raw_per_dense);
+        w = w < (u32)RW - 1u ? w : (u32)RW - 1u;
+        while (rpre[w] > r) --w;
         while (rpre[w + 1] <= r) ++w;
         return 32 * w + bs_select_msb(kw[w], r - rpre[w]);
     };
@@ -150,7 +152,7 @@ void tile(const u8* bases, int64_t nb, const u64* offsets, u32 n_reads, bool hpc
             const u32 wi = e >> 5, s = e & 31;
             const u32* dw = dense.data() + 2 * (DPAD + wi);
             const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);
-            const u64 h = bs_exact_hash<BS_GS>(v0, v1, L, t4);
+            const u64 h = bs_exact_hash<BS_GS, L>(v0, v1, t4);
             if (h > bound) continue;
             // the kernel's rule (sketch.hip, place): the FIRST base decides the read; an l-mer that reaches the next read's start is dropped
             const u32 sd = e - (u32)(L - 1);
