@@ -154,7 +154,7 @@ constexpr int HW = HALO_BASES / 32;           // leading halo words
 constexpr int TT = TILE_THREADS;
 constexpr int WPT = RW / TT;                  // raw words per thread
 constexpr int DPAD = 4;                       // zero words in front of the dense stream (look-back of the first words)
-constexpr int QCAP = 448;                     // candidates that fit the unordered list (evaluated in rounds of TILE_THREADS); more: the word-wise rounds
+constexpr int QCAP = 704;                     // candidates that fit the unordered list (evaluated in rounds of TILE_THREADS); more: the word-wise rounds
 constexpr int RS_CAP = 32;                    // read starts of a tile kept in LDS (more: binary search in global memory)
 
 struct __attribute__((aligned(16))) TileLds {
@@ -175,8 +175,10 @@ struct __attribute__((aligned(16))) TileLds {
 // stream behind the read-start bitmap plus the keep masks (the stream part is zeroed again before phase 2 writes it)
 constexpr int STAGE_AT = 2 * (DPAD + RW + 4) + RW - 2 * RW;      // index into dense[]: the stage ends where kw[] ends
 static_assert(STAGE_AT >= RW && STAGE_AT % 4 == 0 && offsetof(TileLds, kw) == sizeof(u32) * 2 * (DPAD + RW + 4), "stage = dense[STAGE_AT ..) + kw[]");
+// Six workgroups per CU (23.8 KB each).  Seven fit when the candidate list is cut to 448 entries (23.3 KB): measured the same speed,
+// five are 25 % slower — the kernel is bound by issue throughput (VALU, LDS, scalar), not by latency, from six on.
 #ifndef MDBG_LDS_PAD
-static_assert(sizeof(TileLds) * 7 <= 160 * 1024, "7 workgroups per CU");
+static_assert(sizeof(TileLds) * 6 <= 160 * 1024 && sizeof(TileLds) * 7 > 160 * 1024, "6 workgroups per CU");
 #endif
 static_assert((RW + 8) * 2 >= TILE_THREADS * 8 && ((RW + 8) * 4) % 8 == 0 && offsetof(TileLds, c) % 16 == 0, "cpre holds one u64 per thread");
 
@@ -269,7 +271,7 @@ struct CandOut { u64 hash; u32 pos, read; };
 // and dropped: the loop makes the compiler keep ~100 more values live across the phases, 3-4 instead of 6 waves per SIMD, 3.4-4.9 ms
 // instead of 2.2 ms; capped to 80 registers it spills and is no better.  profiles/r02_notes.md.)
 template <int L>
-__global__ __launch_bounds__(TT, 7) void sketch_bs_kernel(SketchArgs a) {
+__global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
     __shared__ TileLds S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t nb = (int64_t)a.n_bases;
@@ -408,7 +410,6 @@ __global__ __launch_bounds__(TT, 7) void sketch_bs_kernel(SketchArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-        const int w = WPT * tid + i;
         const u32 n = n_kept[i];
         if (n) {
             const u32 wi = off >> 5, s = off & 31;
@@ -645,21 +646,23 @@ __global__ __launch_bounds__(TT, 7) void sketch_bs_kernel(SketchArgs a) {
 // ---- gather: per-tile records -> final position-ordered arrays ---------------------------------------------
 // exclusive scan of n_valid over the tiles (carry[0] in/out = running total), three small kernels:
 // sums of 1024-tile blocks, scan of the block sums by one workgroup, per-block scan + base.
-__global__ __launch_bounds__(1024) void tile_scan_sums_kernel(u32 n, const u32* __restrict__ n_valid, u64* __restrict__ block_sum) {
-    __shared__ u32 ws[16];
-    const u32 i = blockIdx.x * 1024 + threadIdx.x;
-    u32 v = i < n ? n_valid[i] : 0;
+__global__ __launch_bounds__(256) void tile_scan_sums_kernel(u32 n, const u32* __restrict__ n_valid, u64* __restrict__ block_sum) {
+    __shared__ u32 ws[4];
+    const u32 i0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    u32 v = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (i0 + q < n) v += n_valid[i0 + q];
     for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) { u64 t = 0; for (int q = 0; q < 16; ++q) t += ws[q]; block_sum[blockIdx.x] = t; }
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = (u64)ws[0] + ws[1] + ws[2] + ws[3];
 }
-__global__ __launch_bounds__(1024) void tile_scan_top_kernel(u32 n_blocks, u64* __restrict__ block_sum, u64* __restrict__ carry) {
-    __shared__ u64 ws[16]; __shared__ u64 run;
+__global__ __launch_bounds__(256) void tile_scan_top_kernel(u32 n_blocks, u64* __restrict__ block_sum, u64* __restrict__ carry) {
+    __shared__ u64 ws[4]; __shared__ u64 run;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) run = carry[0];
     __syncthreads();
-    for (u32 i0 = 0; i0 < n_blocks; i0 += 1024) {
+    for (u32 i0 = 0; i0 < n_blocks; i0 += 256) {
         const u32 i = i0 + tid;
         const u64 v = i < n_blocks ? block_sum[i] : 0;
         u64 inc = v;
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(1024) void tile_scan_top_kernel(u32 n_blocks, u64* 
         if (lane == 63) ws[wv] = inc;
         __syncthreads();
         u64 b = run, tot = 0;
-        for (int q = 0; q < 16; ++q) { if (q < wv) b += ws[q]; tot += ws[q]; }
+        for (int q = 0; q < 4; ++q) { if (q < wv) b += ws[q]; tot += ws[q]; }
         if (i < n_blocks) block_sum[i] = b + inc - v;
         __syncthreads();
         if (tid == 0) run += tot;
@@ -675,55 +678,66 @@ __global__ __launch_bounds__(1024) void tile_scan_top_kernel(u32 n_blocks, u64* 
     }
     if (tid == 0) carry[0] = run;
 }
-__global__ __launch_bounds__(1024) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base) {
-    __shared__ u32 ws[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 i = blockIdx.x * 1024 + tid;
-    const u32 v = i < n ? n_valid[i] : 0;
-    const u32 inc = wave_incl_scan(v);
-    if (lane == 63) ws[wv] = inc;
-    __syncthreads();
-    u64 b = block_base[blockIdx.x];
-    for (int q = 0; q < wv; ++q) b += ws[q];
-    if (i < n) tile_base[i] = b + inc - v;
+__global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base) {
+    __shared__ u32 tmp[8];
+    const u32 i0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    u32 v[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = i0 + q < n ? n_valid[i0 + q] : 0u; mine += v[q]; }
+    u32 total;
+    u64 b = block_base[blockIdx.x] + block_excl_scan_256(mine, tmp, total);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { if (i0 + q < n) tile_base[i0 + q] = b; b += v[q]; }
 }
-// one wave per tile of the launch (tiles [tile0, tile0 + n)); a tile whose records did not fit is skipped (the host retries)
-__global__ __launch_bounds__(256) void gather_kernel(u32 tile0, u32 n, const Rec* __restrict__ slab, u32 slab_cap, const u32* __restrict__ n_valid,
-                                                     const u64* __restrict__ tile_base, u64* __restrict__ out_hash,
-                                                     u32* __restrict__ out_pos, u32* __restrict__ out_read, u64 out_cap) {
+// one wave per tile of the launch (tiles [tile0, tile0 + n)); a tile whose records did not fit is skipped (the host retries).
+// The per-read offsets come out of the same pass (round 2 ran a second kernel over the gathered read indices): off[slot] = first
+// index i with mread[i] >= slot for the batch's slots [slot0, slot0 + n_reads].  A record whose read differs from the record in front of
+// it writes off[] for its read and for the empty reads in between; "the record in front" of a tile's first record is the last record of
+// the nearest non-empty tile in front (a walk over n_valid, amortised one step per tile), or — in front of the launch — the last
+// entry an earlier launch of the batch wrote; the wave of the batch's LAST tile also fills the entries behind the last record.
+struct GatherArgs {
+    u32 tile0, n; const Rec* slab; u32 slab_cap; const u32* n_valid; const u64* tile_base;
+    u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
+    u64 m0; u32 slot0, n_reads; u64* off; u32 last_launch;        // m0: first store index of the batch
+};
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
     const u32 b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= n) return;
+    if (b >= g.n) return;
     const u32 lane = threadIdx.x & 63;
-    const u32 nv = n_valid[tile0 + b];
-    if (!nv || nv > slab_cap) return;
-    const Rec* s = slab + (size_t)b * slab_cap;
-    const u64 base = tile_base[b];
-    for (u32 j = lane; j < nv; j += 64) {
-        const Rec r = s[j];
-        const u64 idx = base + j;
-        if (idx < out_cap) { out_hash[idx] = r.hash; out_pos[idx] = r.pos; out_read[idx] = r.read; }
+    const u32 nv = g.n_valid[g.tile0 + b];
+    const bool tail = g.last_launch && b == g.n - 1;
+    if ((!nv && !tail) || nv > g.slab_cap) return;
+    const Rec* s = g.slab + (size_t)b * g.slab_cap;
+    const u64 base = g.tile_base[b];
+    int64_t prev = (int64_t)g.slot0 - 1;                              // read of the record in front of this tile's first
+    {
+        int64_t q = (int64_t)b - 1;
+        while (q >= 0 && g.n_valid[g.tile0 + q] == 0) --q;
+        if (q >= 0) { const u32 c = g.n_valid[g.tile0 + q]; if (c <= g.slab_cap) prev = (int64_t)g.slab[(size_t)q * g.slab_cap + c - 1].read; }
+        else { const u64 b0 = g.tile_base[0]; if (b0 > g.m0 && b0 <= g.out_cap) prev = (int64_t)g.out_read[b0 - 1]; }
     }
-}
-
-// per-read offsets into the ordered minimizer arrays: off[slot] = first i with mread[i] >= slot, for the batch's
-// slots [slot0, slot0 + n_reads]; mread holds absolute slot indices and is sorted.
-// m1_dev != null: launched BEFORE the host knows the batch's end, over an upper bound m1 (the store's capacity); the true end is *m1_dev.
-// *overflow != 0 then means a tile slab overflowed: the batch will be sketched again, what the gather wrote has holes — nothing to do here.
-__global__ void read_offsets_kernel(const u32* __restrict__ mread, u64 m0, u64 m1, const u64* __restrict__ m1_dev, const u32* __restrict__ overflow,
-                                    u32 slot0, u32 n_reads, u64* __restrict__ off) {
-    const u64 i = m0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m1_dev) {
-        if (*overflow) return;
-        const u64 e = *m1_dev;
-        if (e > m1) return;                                            // the store was too small: the batch will be sketched again as well
-        m1 = e;
+    const int64_t lo = (int64_t)g.slot0 - 1, hi = (int64_t)g.slot0 + g.n_reads;
+    if (prev < lo) prev = lo;
+    for (u32 j0 = 0; j0 < nv; j0 += 64) {
+        const u32 j = j0 + lane;
+        Rec r{}; r.read = 0;
+        if (j < nv) r = s[j];
+        int64_t pr = (int64_t)__shfl_up(r.read, 1, 64);
+        if (lane == 0) pr = prev;
+        prev = (int64_t)__shfl(r.read, 63, 64);                       // (only used when a further round follows: all 64 lanes hold records then)
+        if (j < nv) {
+            const u64 idx = base + j;
+            if (idx < g.out_cap) { g.out_hash[idx] = r.hash; g.out_pos[idx] = r.pos; g.out_read[idx] = r.read; }
+            int64_t cur = (int64_t)r.read; if (cur > hi) cur = hi;
+            for (int64_t x = pr + 1; x <= cur; ++x) g.off[x] = idx;
+        }
     }
-    if (i > m1) return;
-    int64_t prev = (i == m0) ? (int64_t)slot0 - 1 : (int64_t)mread[i - 1];
-    int64_t cur = (i == m1) ? (int64_t)slot0 + n_reads : (int64_t)mread[i];
-    if (prev < (int64_t)slot0 - 1) prev = (int64_t)slot0 - 1;         // (slots of this batch only, whatever the arrays hold)
-    if (cur > (int64_t)slot0 + n_reads) cur = (int64_t)slot0 + n_reads;
-    for (int64_t r = prev + 1; r <= cur; ++r) off[r] = i;
+    if (tail) {
+        int64_t last = nv ? (int64_t)s[nv - 1].read : prev;
+        if (last < lo) last = lo;
+        const u64 m_end = base + nv;
+        for (int64_t x = last + 1 + lane; x <= hi; x += 64) g.off[x] = m_end;
+    }
 }
 
 // Error path only (a byte outside ACGTN was seen somewhere in the batch): the reference's exact rule — nthash panics iff a
@@ -989,25 +1003,15 @@ void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_b
     if (ev_end) (void)hipEventRecord(ev_end, s);
 }
 
-void launch_read_offsets(const u32* mread, u64 m0, u64 m1, u32 slot0, u32 n_reads, u64* off, hipStream_t s) {
-    const u64 n = m1 - m0 + 1;
-    hipLaunchKernelGGL(read_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mread, m0, m1, (const u64*)nullptr, (const u32*)nullptr, slot0, n_reads, off);
-}
-void launch_read_offsets_early(const u32* mread, u64 m0, u64 m1_upper, const u64* m1_dev, const u32* overflow, u32 slot0, u32 n_reads, u64* off, hipStream_t s) {
-    const u64 n = m1_upper - m0 + 1;
-    hipLaunchKernelGGL(read_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mread, m0, m1_upper, m1_dev, overflow, slot0, n_reads, off);
-}
-
-// hash_bound = floor(density * 2^64), saturating (src/read.rs:183)
 // scan + gather of the tiles [tile0, tile0 + n) of one launch; carry[0] in/out = running total of minimizers
-void launch_gather(u32 tile0, u32 n, const Rec* slab, u32 slab_cap, const u32* n_valid, u64* scan_tmp, u64* tile_base, u64* carry,
-                   u64* out_hash, u32* out_pos, u32* out_read, u64 out_cap, hipStream_t s) {
-    if (!n) return;
-    const u32 nb = (n + 1023) / 1024;
-    hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(1024), 0, s, n, n_valid + tile0, scan_tmp);
-    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(1024), 0, s, nb, scan_tmp, carry);
-    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(1024), 0, s, n, n_valid + tile0, scan_tmp, tile_base);
-    hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tile0, n, slab, slab_cap, n_valid, tile_base, out_hash, out_pos, out_read, out_cap);
+void launch_gather(const GatherArgs& g, u64* scan_tmp, u64* tile_base, u64* carry, hipStream_t s) {
+    if (!g.n) return;
+    const u32 n = g.n, nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp);
+    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
+    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp, tile_base);
+    GatherArgs a = g; a.tile_base = tile_base;
+    hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, a);
 }
 
 // ---- --lmer-counts (src/read.rs:200-205, src/minimizers.rs:53-113): keep a selected minimizer only if its l-mer is in a given set ---------
@@ -1077,6 +1081,7 @@ void launch_lmer_filter(const LmerFilterArgs& a, u32 fmt, const u8* bases, const
     }
 }
 
+// hash_bound = floor(density * 2^64), saturating (src/read.rs:183)
 u64 make_hash_bound(double density) {
     const double v = density * 18446744073709551616.0;
     return !(v > 0.0) ? 0 : (v >= 18446744073709551616.0 ? ~0ull : (u64)v);

@@ -120,7 +120,7 @@ def test_config4_full_shard_properties_and_multik_sweep():
                 m.reset(k)
             nd = m.finalize_device()
             st = m.stats()
-            assert st["n_minimizers"] == st0["n_minimizers"] and st["n_sketch_tile_launches"] == (1 if k == ks[0] else 0)      # no re-sketching
+            assert st["n_minimizers"] == st0["n_minimizers"] and (st["n_sketch_tile_launches"] >= 1 if k == ks[0] else st["n_sketch_tile_launches"] == 0)      # no re-sketching
             res = _node_tensors(torch, nd, k)
             assert int(nd.n) > 1_000_000 and int(nd.n_distinct) > int(nd.n)
             with R.Mdbg(k, 12, 0.003, a) as f:
