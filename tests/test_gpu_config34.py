@@ -129,3 +129,116 @@ def test_config4_full_shard_properties_and_multik_sweep():
             for name in res:
                 assert torch.equal(res[name], fresh[name]), (k, name)
             del res, fresh
+
+
+def test_config3_whole_genome_streamed_through_one_gpu():
+    """BASELINE configs[3] at FULL size on ONE GPU: the eight shards of the synthetic human data set (3 Gb genome, 10.4 M reads, ~156 Gbases)
+    generated shard by shard on the device, packed, and pushed through one context as eight batches with global ordinals; then one
+    finalize.  The N=1 anchor of the 1 -> 8 curve and the table at ~10^8 distinct keys.  Checked: the invariants of the shard test, that the
+    window count is the sum of the shards' (windows never span reads), and that the table grew without losing or duplicating a key (a second
+    pass into a table sized up front gives the same node, distinct and window counts and the same key / index / abundance checksums)."""
+    import json
+    import os
+    import time
+    import torch
+    import rust_mdbg_amd as R
+    k, l, d, a, W = 35, 14, 0.003, 2, 8
+    free0 = torch.cuda.mem_get_info()[0]
+    rec = {"config": {"k": k, "l": l, "density": d, "minabund": a, "genome_len": SHARD_GENOME * W, "reads": SHARD_READS * W, "batches": W}, "batches": []}
+    with R.Mdbg(k, l, d, a) as m:
+        words = None
+        total_bases = 0
+        t_ingest = 0.0
+        min_free = free0
+        caps = []
+        for r in range(W):
+            db, do, nb = m.synth_reads_device(seed=1, genome_len=SHARD_GENOME * W, n_reads=SHARD_READS, first_read=r * SHARD_READS)
+            if words is None:
+                words = torch.zeros(int(nb * 1.02) // 32 + 64, dtype=torch.int64, device="cuda")
+            assert (nb + 31) // 32 + 2 <= words.numel()
+            torch.cuda.synchronize()
+            assert m.pack_device(db, nb, words.data_ptr()) == 0
+            m.sync()
+            t = time.perf_counter()
+            m.ingest_packed_device(words.data_ptr(), do, SHARD_READS, nb, r * SHARD_READS)
+            m.sync()
+            dt = time.perf_counter() - t
+            st = m.stats()
+            t_ingest += dt
+            total_bases += nb
+            min_free = min(min_free, torch.cuda.mem_get_info()[0])
+            caps.append(st["table_capacity"])
+            rec["batches"].append({"bases": nb, "ingest_ms": dt * 1e3, "minimizers_total": st["n_minimizers"], "windows_total": st["n_windows"],
+                                   "distinct_total": st["n_distinct"], "table_capacity": st["table_capacity"]})
+        t = time.perf_counter()
+        nd = m.finalize_device()
+        m.sync()
+        t_fin = time.perf_counter() - t
+        st = m.stats()
+        min_free = min(min_free, torch.cuda.mem_get_info()[0])
+        n = int(nd.n)
+        assert 150e9 < total_bases < 160e9 and st["n_slow_tiles"] == 0 and st["n_reads"] == SHARD_READS * W
+        assert n > 8_000_000 and int(nd.n_distinct) > n
+        # invariants (as for one shard)
+        idx = _dev(torch, nd.index, n, torch.int32).to(torch.int64) & 0xFFFFFFFF
+        assert bool((idx[1:] > idx[:-1]).all()) and int(idx[-1]) < int(nd.n_distinct)
+        ab = _dev(torch, nd.abundance, n, torch.int16).to(torch.int64) & 0xFFFF
+        assert int(ab.min()) >= a
+        sl = _dev(torch, nd.seqlen, n, torch.int32).to(torch.int64) & 0xFFFFFFFF
+        assert bool(((_dev(torch, nd.src_end, n, torch.int64) - _dev(torch, nd.src_start, n, torch.int64) - l + 2) == sl).all())
+        sr = _dev(torch, nd.src_read, n, torch.int64)
+        assert int(sr.max()) < SHARD_READS * W and int(sr.min()) >= 0
+        seen_shards = torch.unique(sr // SHARD_READS)
+        assert seen_shards.numel() == W                                   # every batch is the A-th sighting of some node: ordinals are global
+        kk = _dev(torch, nd.keys, n * k, torch.int64).view(n, k)
+        assert int(kk.min()) >= 0 and int(kk.max()) <= O.hash_bound(d)
+        step = 4_000_000                                                  # canonical orientation, in slices (the flipped copy of all keys would be 4 GB more)
+        for s0 in range(0, n, step):
+            q = kk[s0:s0 + step]
+            rv = q.flip(1)
+            neq = q != rv
+            first = neq.to(torch.int8).argmax(1)
+            rows = torch.arange(q.shape[0], device="cuda")
+            assert bool(((q[rows, first] < rv[rows, first]) | ~neq.any(1)).all())      # all values are < 2^63: signed compare is the unsigned one
+            del rv, neq, first, rows
+        n_windows, n_distinct, n_min = st["n_windows"], st["n_distinct"], st["n_minimizers"]
+        growth = sum(1 for i in range(1, len(caps)) if caps[i] != caps[i - 1])
+        rec.update(total_bases=total_bases, nodes=n, distinct=n_distinct, windows=n_windows, minimizers=n_min, ingest_ms=t_ingest * 1e3, finalize_ms=t_fin * 1e3,
+                   gbases_per_s=total_bases / (t_ingest + t_fin) / 1e9, table_growth_events=growth, table_capacity_final=st["table_capacity"],
+                   peak_hbm_gb=(free0 - min_free) / 1e9, note="ingest_ms = sketch + windows + table per batch, inputs packed and resident; synth + pack are outside")
+        keys_sum = int(kk.sum(dtype=torch.int64))                         # (wraps: a checksum, compared below)
+        idx_sum = int(idx.sum()); ab_sum = int(ab.sum())
+        del kk, idx, ab, sl, sr
+        # second pass: the same eight batches into a table sized UP FRONT (no growth, no rehash) must give the same graph; on the way every
+        # shard is also run alone: windows are additive over batches (they never span reads)
+        w_sum = 0
+        with R.Mdbg(k, l, d, a, table_capacity_hint=n_distinct + 2 * (n_windows // W)) as g:      # the capacity rule counts a batch's windows as possibly new keys
+            for r in range(W):
+                with R.Mdbg(k, l, d, a) as f:
+                    db, do, nb = f.synth_reads_device(seed=1, genome_len=SHARD_GENOME * W, n_reads=SHARD_READS, first_read=r * SHARD_READS)
+                    torch.cuda.synchronize()
+                    assert f.pack_device(db, nb, words.data_ptr()) == 0
+                    f.ingest_packed_device(words.data_ptr(), do, SHARD_READS, nb, r * SHARD_READS)
+                    f.sync()
+                    stf = f.stats()
+                    w_sum += stf["n_windows"]
+                    assert stf["n_minimizers"] == rec["batches"][r]["minimizers_total"] - (rec["batches"][r - 1]["minimizers_total"] if r else 0)
+                    g.ingest_packed_device(words.data_ptr(), do, SHARD_READS, nb, r * SHARD_READS)
+                    g.sync()
+                    if r == 0:
+                        cap_g = g.stats()["table_capacity"]
+            ng = g.finalize_device()
+            stg = g.stats()
+            assert stg["table_capacity"] == cap_g, "the pre-sized table must not have grown"
+            assert int(ng.n) == n and stg["n_distinct"] == n_distinct and stg["n_windows"] == n_windows
+            kg = _dev(torch, ng.keys, n * k, torch.int64)
+            assert int(kg.sum(dtype=torch.int64)) == keys_sum
+            assert int((_dev(torch, ng.index, n, torch.int32).to(torch.int64) & 0xFFFFFFFF).sum()) == idx_sum
+            assert int((_dev(torch, ng.abundance, n, torch.int16).to(torch.int64) & 0xFFFF).sum()) == ab_sum
+            del kg
+    assert w_sum == n_windows
+    rec["second_pass_pre_sized_table"] = "equal (nodes, distinct, windows, key / index / abundance checksums)"
+    print("FULL_HUMAN " + json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out) and os.access(out, os.W_OK):
+        json.dump(rec, open(os.path.join(out, "r03_full_human.json"), "w"), indent=1)
