@@ -142,14 +142,17 @@ static int rank_main(seg_t* s, uint32_t rank, const job_t* j) {
     }
     mdbg_nodes nd; const uint64_t* d_row = NULL; uint64_t ng = 0;
     CHECK(mdbg_dist_finalize(d, &nd, &d_row, &ng));
-    /* partition -> segment: keys | index | abundance | seqlen | src_read | row */
-    const uint64_t need = nd.n * (nd.k * 8 + 4 + 2 + 4 + 8 + 8) + 64;
+    /* partition -> segment: keys | src_read | row | src_start | src_end | shift_full | index | seqlen | abundance */
+    const uint64_t need = nd.n * (nd.k * 8 + 4 + 2 + 4 + 8 + 8 + 8 + 8 + 16) + 64;
     if (need > PART_BYTES) { fprintf(stderr, "[rank %u] result area too small\n", rank); return 3; }
     unsigned char* o = part_of(s, rank);
     s->part_n[rank] = nd.n; s->part_global[rank] = ng; s->part_distinct[rank] = nd.n_distinct; s->part_k[rank] = nd.k;
     fetch(c, o, nd.keys, nd.n * nd.k * 8); o += nd.n * nd.k * 8;
     fetch(c, o, nd.src_read, nd.n * 8); o += nd.n * 8;
     fetch(c, o, d_row, nd.n * 8); o += nd.n * 8;
+    fetch(c, o, nd.src_start, nd.n * 8); o += nd.n * 8;
+    fetch(c, o, nd.src_end, nd.n * 8); o += nd.n * 8;
+    fetch(c, o, nd.shift_full, nd.n * 16); o += nd.n * 16;
     fetch(c, o, nd.index, nd.n * 4); o += nd.n * 4;
     fetch(c, o, nd.seqlen, nd.n * 4); o += nd.n * 4;
     fetch(c, o, nd.abundance, nd.n * 2);
@@ -211,13 +214,18 @@ int main(int argc, char** argv) {
         const uint64_t* keys = (const uint64_t*)o; o += n * ref.k * 8;
         const uint64_t* src_read = (const uint64_t*)o; o += n * 8;
         const uint64_t* row = (const uint64_t*)o; o += n * 8;
+        const uint64_t* src_start = (const uint64_t*)o; o += n * 8;
+        const uint64_t* src_end = (const uint64_t*)o; o += n * 8;
+        const uint64_t* shift_full = (const uint64_t*)o; o += n * 16;
         const uint32_t* index = (const uint32_t*)o; o += n * 4;
         const uint32_t* seqlen = (const uint32_t*)o; o += n * 4;
         const uint16_t* abundance = (const uint16_t*)o;
         for (uint64_t i = 0; i < n && ok; ++i) {
             const uint64_t rw = row[i];
             ok = rw < ref.n && !seen[rw] && index[i] == ref.index[rw] && abundance[i] == ref.abundance[rw] && seqlen[i] == ref.seqlen[rw] &&
-                 src_read[i] == ref.src_read[rw] && !memcmp(keys + i * ref.k, ref.keys + rw * ref.k, ref.k * 8);
+                 src_read[i] == ref.src_read[rw] && !memcmp(keys + i * ref.k, ref.keys + rw * ref.k, ref.k * 8) &&
+                 /* what needs the raw positions of the A-th sighting — fetched from the rank that sketched the read */
+                 src_start[i] == ref.src_start[rw] && src_end[i] == ref.src_end[rw] && !memcmp(shift_full + 2 * i, ref.shift_full + 2 * rw, 16);
             if (rw < ref.n) seen[rw] = 1;
         }
     }

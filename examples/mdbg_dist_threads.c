@@ -73,7 +73,8 @@ static int t_allreduce(void* self, uint64_t* d_buf, uint64_t n) {
 }
 
 /* ---- one rank -------------------------------------------------------------------------------------------------------------- */
-typedef struct part_t { uint64_t n, n_global, n_distinct; uint64_t* keys; uint32_t* index; uint16_t* abundance; uint32_t* seqlen; uint64_t* src_read; uint64_t* row; } part_t;
+typedef struct part_t { uint64_t n, n_global, n_distinct; uint64_t* keys; uint32_t* index; uint16_t* abundance; uint32_t* seqlen; uint64_t* src_read; uint64_t* row;
+                        uint64_t* src_start; uint64_t* src_end; uint64_t* shift_full; } part_t;
 typedef struct job_t { rank_t rk; mdbg_params P; uint64_t reads_per_rank, genome; int rounds, packed, chunks; part_t out; } job_t;
 
 static void fetch(mdbg_ctx* c, void* dst, const void* src, uint64_t bytes) { if (bytes) CHECK(mdbg_copy_to_host(c, dst, src, bytes)); }
@@ -124,6 +125,8 @@ static void* rank_main(void* arg) {
     o->n = nd.n; o->n_global = ng; o->n_distinct = nd.n_distinct;
     o->keys = (uint64_t*)malloc((nd.n * nd.k + 1) * 8); o->index = (uint32_t*)malloc((nd.n + 1) * 4); o->abundance = (uint16_t*)malloc((nd.n + 1) * 2);
     o->seqlen = (uint32_t*)malloc((nd.n + 1) * 4); o->src_read = (uint64_t*)malloc((nd.n + 1) * 8); o->row = (uint64_t*)malloc((nd.n + 1) * 8);
+    o->src_start = (uint64_t*)malloc((nd.n + 1) * 8); o->src_end = (uint64_t*)malloc((nd.n + 1) * 8); o->shift_full = (uint64_t*)malloc((nd.n + 1) * 16);
+    fetch(c, o->src_start, nd.src_start, nd.n * 8); fetch(c, o->src_end, nd.src_end, nd.n * 8); fetch(c, o->shift_full, nd.shift_full, nd.n * 16);
     fetch(c, o->keys, nd.keys, nd.n * nd.k * 8); fetch(c, o->index, nd.index, nd.n * 4); fetch(c, o->abundance, nd.abundance, nd.n * 2);
     fetch(c, o->seqlen, nd.seqlen, nd.n * 4); fetch(c, o->src_read, nd.src_read, nd.n * 8); fetch(c, o->row, d_row, nd.n * 8);
     pthread_barrier_wait(&w->bar);
@@ -176,7 +179,9 @@ int main(int argc, char** argv) {
         for (uint64_t i = 0; i < o->n && ok; ++i) {
             const uint64_t row = o->row[i];
             ok = row < ref.n && !seen[row] && o->index[i] == ref.index[row] && o->abundance[i] == ref.abundance[row] && o->seqlen[i] == ref.seqlen[row] &&
-                 o->src_read[i] == ref.src_read[row] && !memcmp(o->keys + i * ref.k, ref.keys + row * ref.k, ref.k * 8);
+                 o->src_read[i] == ref.src_read[row] && !memcmp(o->keys + i * ref.k, ref.keys + row * ref.k, ref.k * 8) &&
+                 /* what needs the raw positions of the A-th sighting — fetched from the rank that sketched the read */
+                 o->src_start[i] == ref.src_start[row] && o->src_end[i] == ref.src_end[row] && !memcmp(o->shift_full + 2 * i, ref.shift_full + 2 * row, 16);
             if (row < ref.n) seen[row] = 1;
         }
     }

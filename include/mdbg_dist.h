@@ -5,7 +5,9 @@
  * partitioning is the north star's: every rank sketches its own reads (mdbg_hip.h), the ranks exchange what the owners of the
  * k-min-mers need, every rank counts the keys it owns, and DbgEntry.index (NODE_INDEX, src/main.rs:598,661) is made global by
  * summing the ranks' first-sighting bitmaps.  Mode implemented here: the SKETCH exchange (profiles/r02_notes.md: 3x faster per rank
- * than routing expanded k-min-mer records): per round every rank sends each peer its sketch (12 bytes per minimizer) together with
+ * than routing expanded k-min-mer records): per round every rank sends each peer the HASHES of its sketch (8 bytes per minimizer; the
+ * raw positions stay home: a node's seqlen / shift / origin need four positions of ONE window, which mdbg_dist_finalize fetches from the
+ * rank that sketched the read — a few MB per finalize instead of 4 bytes per minimizer per round) together with
  * the list of the windows that peer owns (8 bytes per window, mdbg_owner_lists) in ONE grouped set of ncclSend / ncclRecv pairs —
  * xGMI is point to point, every pair of GPUs uses its own link — and the receives land directly in reserved regions of the
  * resident sketch store (mdbg_sketch_reserve: no staging copy).  Results are identical to a single context fed all reads
@@ -81,8 +83,13 @@ int mdbg_dist_ingest_batch_packed_device(mdbg_dist* d, const mdbg_packed_batch* 
  * the global table (= rank in DbgEntry.index order), so concatenating the partitions of all ranks and ordering by d_row gives the
  * single-GPU table; out->index holds the GLOBAL DbgEntry.index; out->n_distinct and *n_nodes_global are totals over all ranks. */
 int mdbg_dist_finalize(mdbg_dist* d, mdbg_nodes* out, const uint64_t** d_row, uint64_t* n_nodes_global);
-/* new_k = 0: drop everything; else re-window the resident GLOBAL sketch with new_k (no exchange needed: every rank holds it). */
+/* new_k = 0: drop everything; else re-window the resident GLOBAL sketch with new_k (no exchange needed: every rank holds the hashes;
+ * the positions the new nodes need are fetched at the next finalize). */
 int mdbg_dist_reset(mdbg_dist* d, uint32_t new_k);
+
+/* Bytes this rank has received / sent through the communicator's `exchange` since mdbg_dist_create or the last mdbg_dist_reset(d, 0)
+ * (sketch rounds + position fetches), and the number of position queries it sent: what a link budget is made of.  Any pointer may be NULL. */
+int mdbg_dist_traffic(mdbg_dist* d, uint64_t* bytes_in, uint64_t* bytes_out, uint64_t* position_queries);
 
 #ifdef __cplusplus
 }

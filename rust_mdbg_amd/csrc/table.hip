@@ -752,6 +752,70 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
     }
 }
 
+// ---- positions of remote sketches, fetched on demand (multi-GPU sketch exchange, include/mdbg_dist.h) ----------------------------------
+// The ranks exchange HASHES only (8 of the 12 bytes per minimizer).  Raw positions are needed for one thing: seqlen / shift / origin of
+// the A-th sighting of a solid node (fin_emit_kernel reads p[0], p[1], p[k-2], p[k-1] of that window), and only the rank that sketched
+// the read has them.  Before fin_emit every rank lists, per sketching rank, the A-th-sighting ordinals of its solid nodes that lie in
+// somebody else's reads (pos_query_kernel: count pass, then write pass), the sketching rank answers with the four positions
+// (pos_answer_kernel, through its own batch tables), and the answers are written into the local position array at the window's own
+// indices (pos_scatter_kernel) — fin_emit then runs unchanged.  A few MB per finalize instead of 4 bytes per minimizer per step.
+struct PosQueryArgs {
+    const u32* batch_src;          // [F.bt.n] sketching rank of every batch, in F.bt order (sorted by first ordinal)
+    u32 me, world, pass;           // pass 0: counts[peer] += 1; pass 1: write at offs[peer] + fill[peer]++
+    unsigned long long* counts; const u64* offs; unsigned long long* fill;
+    u64* q_ord; u64* q_idx;        // the query (ordinal of the A-th sighting) and the local store index of that window
+};
+__device__ inline u32 batch_of_ordinal(const FinArgs& F, u64 ord) {
+    const u64 ro = ord >> WIN_BITS;
+    u32 lo = 0, hi = F.bt.n - 1;
+    while (lo < hi) { const u32 mid = lo + ((hi - lo + 1) >> 1); if (F.bt.first_ordinal[mid] <= ro) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void pos_query_kernel(FinArgs F, u64 n_solid, PosQueryArgs Q) {
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_solid) return;
+    const u64 s = F.solid_list[q];
+    const Slot e = F.tab[s];
+    const SlotView v = slot_view(e, s, F.mx, F.casc, F.A, rep_ordinal(F, e.word), F.ath_override);
+    const u32 src = Q.batch_src[batch_of_ordinal(F, v.ath)];
+    if (src == Q.me || src >= Q.world) return;
+    if (Q.pass == 0) { atomicAdd(&Q.counts[src], 1ull); return; }
+    const u64 at = Q.offs[src] + atomicAdd(&Q.fill[src], 1ull);
+    u64 i, D; decode_ordinal(F, v.ath, i, D);
+    Q.q_ord[at] = v.ath; Q.q_idx[at] = i;
+}
+// answers: {p[0], p[1], p[k-2], p[k-1]} of the window with the given ordinal in THIS rank's store; *bad counts ordinals that are not
+// windows of a batch this rank sketched (a protocol error)
+__global__ __launch_bounds__(256) void pos_answer_kernel(FinArgs F, const u64* __restrict__ ords, u64 n, const u32* __restrict__ batch_src, u32 me, const u64* __restrict__ batch_m1,
+                                                         uint4* __restrict__ ans, unsigned long long* __restrict__ bad) {
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u64 ord = ords[q];
+    const u32 b = batch_of_ordinal(F, ord);
+    const u64 ro = ord >> WIN_BITS;
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (batch_src[b] != me || ro < F.bt.first_ordinal[b] || ro - F.bt.first_ordinal[b] >= F.bt.n_reads[b]) { atomicAdd(bad, 1ull); ans[q] = a; return; }
+    u64 i, D; decode_ordinal(F, ord, i, D);
+    if (i + F.k > batch_m1[b]) { atomicAdd(bad, 1ull); ans[q] = a; return; }
+    const u32* p = F.mpos + i;
+    ans[q] = make_uint4(p[0], p[1], p[F.k - 2], p[F.k - 1]);
+}
+__global__ __launch_bounds__(256) void pos_scatter_kernel(const u64* __restrict__ idx, const uint4* __restrict__ ans, u64 n, u32 k, u32* __restrict__ mpos) {
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u64 i = idx[q]; const uint4 a = ans[q];
+    mpos[i] = a.x; mpos[i + 1] = a.y; mpos[i + k - 2] = a.z; mpos[i + k - 1] = a.w;      // (k = 2: the same two entries twice, same values)
+}
+void launch_pos_query(const FinArgs& F, u64 n_solid, const PosQueryArgs& Q, hipStream_t s) {
+    if (n_solid) hipLaunchKernelGGL(pos_query_kernel, dim3((unsigned)((n_solid + 255) / 256)), dim3(256), 0, s, F, n_solid, Q);
+}
+void launch_pos_answer(const FinArgs& F, const u64* ords, u64 n, const u32* batch_src, u32 me, const u64* batch_m1, uint4* ans, unsigned long long* bad, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(pos_answer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, F, ords, n, batch_src, me, batch_m1, ans, bad);
+}
+void launch_pos_scatter(const u64* idx, const uint4* ans, u64 n, u32 k, u32* mpos, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(pos_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx, ans, n, k, mpos);
+}
+
 // exclusive prefix of popcounts over 64-bit words: pre[w] = sum_{v<w} popc(bm[v]); three kernels
 __global__ __launch_bounds__(1024) void popc_block_kernel(const u64* __restrict__ bm, u64 n_words, u32* __restrict__ block_sum) {
     __shared__ u32 ws[16];

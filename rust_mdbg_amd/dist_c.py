@@ -59,6 +59,7 @@ class DistMdbg:
         L.mdbg_dist_reset.argtypes = [C.c_void_p, C.c_uint32]
         L.mdbg_dist_set_pipeline.argtypes = [C.c_void_p, C.c_uint32]
         L.mdbg_dist_destroy.argtypes = [C.c_void_p]
+        L.mdbg_dist_traffic.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         self.comm, self.rccl = rccl_comm(rank, world, dist)
         vt = Comm()
         self._chk(L.mdbg_comm_rccl(self.comm, rank, world, C.byref(vt)))
@@ -93,6 +94,12 @@ class DistMdbg:
 
     def reset(self, new_k=0):
         self._chk(self.L.mdbg_dist_reset(self.h, new_k))
+
+    def traffic(self):
+        """-> (bytes received, bytes sent, position queries sent) by this rank since create / reset(0)"""
+        a, b, q = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.mdbg_dist_traffic(self.h, C.byref(a), C.byref(b), C.byref(q)))
+        return int(a.value), int(b.value), int(q.value)
 
     def close(self):
         if self.h:
