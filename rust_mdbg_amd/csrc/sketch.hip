@@ -36,6 +36,8 @@ struct SketchArgs {
     u32 tile0;                   // workgroup b runs tile tile0 + b
     Rec* slab; u32 slab_cap;     // records of workgroup b: slab[b * slab_cap ..), in position order
     u32* n_valid;                // [n_tiles] number of minimizers whose l-mer ENDS in the tile
+    u32* n_scan;                 // [n_tiles] slab slots the tile used when they are NOT all valid records (dense settings: rejected candidates
+                                 // stay in the slab with read = 0xFFFFFFFF and the gather squeezes them out), else 0
     u32* over_max;               // <- largest n_valid that did not fit its slab (0: none; the host then retries with larger slabs)
     const u64* t4;               // (2 << 2*BS_GS) x u64: {F, R} per 3-base group (bs_make_table)
     const u8* tile_flags;        // FMT_PLANES: nonzero = an exception falls into the tile's staged range (null: none)
@@ -232,6 +234,7 @@ __device__ inline void put_rec(const SketchArgs& a, Rec* slab, u32 rank, u64 has
 }
 __device__ inline void put_count(const SketchArgs& a, u32 gt, u32 n) {
     a.n_valid[gt] = n;
+    if (a.n_scan) a.n_scan[gt] = 0;
     if (n > a.slab_cap) atomicMax(a.over_max, n);
 }
 
@@ -497,7 +500,6 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
     if (a.stop_phase == 3) { if (tid == 0) a.n_valid[gt] = 0; return; }
 
     // ---- phase 4: exact evaluation, ranks, records -------------------------------------------------------------------
-    const int nw = tid == TT - 1 ? WPT + 1 : WPT;                     // words 4*tid .. ; the last thread also takes word RW
     auto count_words = [&]() -> u32 {                                 // cpre[] <- exclusive counts of the bitmap per word; returns the total
         const uint4 cw = *(const uint4*)(S.c.cand + WPT * tid);
         const u32 c0 = bs_popc(cw.x), c1 = bs_popc(cw.y), c2 = bs_popc(cw.z), c3 = bs_popc(cw.w);
@@ -509,25 +511,6 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
         if (tid == TT - 1) S.c.cpre[RW] = (u16)(o3 + c3);
         __syncthreads();
         return total;
-    };
-    // one round of candidates = whole words, at most QCAP candidates, starting at rank c0; list[] <- their END positions.
-    // returns the rank after the round
-    auto build_list = [&](u32 c0) -> u32 {
-        if (tid == 0) S.misc[16] = c0;
-        __syncthreads();
-        u32 hi = c0;
-        for (int i = 0; i < nw; ++i) {
-            const int D = WPT * tid + i;
-            u32 w = S.c.cand[D];
-            u32 r = S.c.cpre[D];
-            const u32 n = bs_popc(w);
-            if (n == 0 || r < c0 || r + n > c0 + QCAP) continue;
-            hi = r + n;
-            while (w) { const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b); S.c.list[r - c0] = (u16)(32 * D + b - (BS_B - 1)); ++r; }
-        }
-        if (hi > c0) atomicMax(&S.misc[16], hi);
-        __syncthreads();
-        return S.misc[16];
     };
     // tile-relative raw position of dense position r.  The kept fraction is nearly uniform along a tile, so r * RW / H lands within a word
     // or two of the raw word that holds r (round 2 kept a table of first raw words per dense word: 2 KB of LDS and five instructions
@@ -573,29 +556,25 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
         o.hash = h; o.pos = (u32)(rel_start - q0); o.read = r + a.read_base;
         return !crosses;
     };
-    auto eval = [&](u32 e, CandOut& o) -> bool {
-        const u64 h = exact(e);
-        return h <= a.bound && place(e, h, o);
-    };
     auto clear_bit = [&](u32 e) { const u32 x = e + BS_B - 1; atomicAnd(&S.c.cand[x >> 5], ~(0x80000000u >> (x & 31))); };
     auto rank_of = [&](u32 e) -> u32 { const u32 x = e + BS_B - 1, D = x >> 5, b = x & 31; return S.c.cpre[D] + (b ? bs_popc(S.c.cand[D] >> (32 - b)) : 0u); };
 
-    const u32 n_cand = S.misc[17];
-    if (n_cand <= QCAP) {
-        // every candidate sits in the list (any order).  Rounds of TT candidates, two stages each: (1) one lane per candidate evaluates
-        // the exact hash — about half fail (bit 55) —, the survivors are packed (wave-aggregated slot) into surv / their hashes; (2) one
-        // lane per SURVIVOR maps it to raw coordinates and its read, so the longer half of the work runs on full waves.  Failures
-        // leave the bitmap; the popcount scan of the bitmap then ranks the survivors in position order.
+    // One round over the candidates list[0 .. n): two stages per TT candidates — (1) one lane per candidate evaluates the exact hash
+    // (about half fail: bit 55), the survivors are packed (wave-aggregated slot) into surv / their hashes; (2) one lane per SURVIVOR maps
+    // it to raw coordinates and its read, so the longer half of the work runs on full waves.  Failures leave the bitmap; the popcount scan
+    // of the bitmap then ranks the survivors in position order (every bit in front of a survivor of this round is final: earlier rounds
+    // and this one) and they are written.  misc[18 .. 20] are zero on entry.  Returns the number of bits left in the bitmap.
+    auto process_list = [&](u32 n) -> u32 {
         constexpr int NR = (QCAP + TT - 1) / TT;
         CandOut keep[NR] = {}; u32 keep_e[NR] = {}; u32 keep_ok = 0;
         u64* const s_h = (u64*)S.c.cpre;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            if ((u32)(TT * i) < n_cand) {
-                if (i) __syncthreads();                               // the previous round's survivors have been read
+            if ((u32)(TT * i) < n) {
+                if (i) __syncthreads();                               // the previous sub-round's survivors have been read
                 const u32 j = tid + TT * i;
                 bool pass = false; u32 e = 0; u64 h = 0;
-                if (j < n_cand) { e = S.c.list[j]; h = exact(e); pass = h <= a.bound; if (!pass) clear_bit(e); }
+                if (j < n) { e = S.c.list[j]; h = exact(e); pass = h <= a.bound; if (!pass) clear_bit(e); }
                 const u64 bal = __ballot(pass);
                 if (bal) {
                     u32 base = 0;
@@ -613,31 +592,54 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
         }
         __syncthreads();
         MDBG_STAMP(4);
-        const u32 nv = n_cand ? count_words() : 0;
+        const u32 left = count_words();
         MDBG_STAMP(5);
 #pragma unroll
         for (int i = 0; i < NR; ++i) if ((keep_ok >> i) & 1u) put_rec(a, slab, rank_of(keep_e[i]), keep[i].hash, keep[i].pos, keep[i].read);
+        return left;
+    };
+
+    const u32 n_cand = S.misc[17];
+    if (n_cand <= QCAP) {
+        // every candidate sits in the (unordered) list of phase 3
+        const u32 nv = n_cand ? process_list(n_cand) : 0;
         if (tid == 0) { put_count(a, gt, nv); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; } }
     } else {
-        // dense settings: rounds of whole bitmap words; pass A validates, pass B (after the recount) writes
+        // Dense settings (more candidates than the list holds).  The candidates are dealt out evenly by their rank in the bitmap — a
+        // thread finds the word of its first one by binary search over the per-word counts and walks on from there —, evaluated once
+        // each, and written to the slab AT THEIR CANDIDATE RANK, the rejected ones with read = 0xFFFFFFFF: no lists, no rounds, no
+        // barriers, no second evaluation; the gather squeezes the holes out (it is a copy anyway).  Round 2 validated all candidates in
+        // one pass and evaluated the survivors again to write them; a first version of this round ran the two-stage rounds of the fast
+        // path over stretches of the bitmap: 0.43 Tbases/s at d = 0.1, most of it spent at ~100 barriers per tile.
         __syncthreads();
-        const u32 n_all = count_words();
-        for (u32 c0 = 0; c0 < n_all;) {
-            const u32 c1 = build_list(c0);
-            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; const u32 e = S.c.list[j]; if (!eval(e, o)) clear_bit(e); }
-            __syncthreads();
-            c0 = c1;
+        const u32 C = count_words();
+        const u32 per = (C + TT - 1) / TT;
+        const u32 r0 = (u32)tid * per < C ? (u32)tid * per : C, r1 = r0 + per < C ? r0 + per : C;
+        u32 surv = 0;
+        if (r0 < r1) {
+            u32 lo = 0, hi = RW;                                       // largest D with cpre[D] <= r0: the word that holds candidate r0
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (S.c.cpre[mid] <= r0) lo = mid; else hi = mid - 1; }
+            u32 D = lo, w = S.c.cand[D];
+            for (u32 skip = r0 - S.c.cpre[D]; skip; --skip) w &= ~(0x80000000u >> (u32)__clz(w));
+            for (u32 r = r0; r < r1; ++r) {
+                while (!w) { ++D; w = S.c.cand[D]; }
+                const u32 b = (u32)__clz(w); w &= ~(0x80000000u >> b);
+                const u32 e = 32 * D + b - (BS_B - 1);
+                const u64 h = exact(e);
+                CandOut o{}; bool ok = false;
+                if (h <= a.bound) ok = place(e, h, o);
+                Rec rec; rec.hash = ok ? o.hash : 0ull; rec.pos = ok ? o.pos : 0u; rec.read = ok ? o.read : 0xFFFFFFFFu;
+                surv += ok ? 1u : 0u;
+                if (r < a.slab_cap) slab[r] = rec;
+            }
         }
-        MDBG_STAMP(4);
-        const u32 nv = count_words();
-        MDBG_STAMP(5);
-        for (u32 c0 = 0; c0 < nv;) {
-            const u32 c1 = build_list(c0);
-            for (u32 j = tid; j < c1 - c0; j += TT) { CandOut o; if (eval(S.c.list[j], o)) put_rec(a, slab, c0 + j, o.hash, o.pos, o.read); }
-            __syncthreads();
-            c0 = c1;
+        u32 nv;
+        block_excl_scan_256(surv, S.misc, nv);
+        if (tid == 0) {
+            a.n_valid[gt] = nv; if (a.n_scan) a.n_scan[gt] = C;
+            if (C > a.slab_cap) atomicMax(a.over_max, C);
+            if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; }
         }
-        if (tid == 0) { put_count(a, gt, nv); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_all; a.dbg[(size_t)gt * 16 + 10] = nv; } }
     }
     MDBG_STAMP(7);
 #undef MDBG_STAMP
@@ -696,47 +698,61 @@ __global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* 
 // the nearest non-empty tile in front (a walk over n_valid, amortised one step per tile), or — in front of the launch — the last
 // entry an earlier launch of the batch wrote; the wave of the batch's LAST tile also fills the entries behind the last record.
 struct GatherArgs {
-    u32 tile0, n; const Rec* slab; u32 slab_cap; const u32* n_valid; const u64* tile_base;
+    u32 tile0, n; const Rec* slab; u32 slab_cap; const u32* n_valid; const u32* n_scan; const u64* tile_base;      // n_scan: see SketchArgs (null: every slab is compact)
     u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
     u64 m0; u32 slot0, n_reads; u64* off; u32 last_launch;        // m0: first store index of the batch
 };
+constexpr u32 REC_REJECTED = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
     const u32 b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= g.n) return;
     const u32 lane = threadIdx.x & 63;
     const u32 nv = g.n_valid[g.tile0 + b];
+    const u32 ns = g.n_scan ? g.n_scan[g.tile0 + b] : 0u;
+    const u32 slots = ns ? ns : nv;                                   // slab slots to look at (ns != 0: some hold rejected candidates)
     const bool tail = g.last_launch && b == g.n - 1;
-    if ((!nv && !tail) || nv > g.slab_cap) return;
+    if ((!nv && !tail) || slots > g.slab_cap) return;
     const Rec* s = g.slab + (size_t)b * g.slab_cap;
     const u64 base = g.tile_base[b];
     int64_t prev = (int64_t)g.slot0 - 1;                              // read of the record in front of this tile's first
     {
         int64_t q = (int64_t)b - 1;
         while (q >= 0 && g.n_valid[g.tile0 + q] == 0) --q;
-        if (q >= 0) { const u32 c = g.n_valid[g.tile0 + q]; if (c <= g.slab_cap) prev = (int64_t)g.slab[(size_t)q * g.slab_cap + c - 1].read; }
-        else { const u64 b0 = g.tile_base[0]; if (b0 > g.m0 && b0 <= g.out_cap) prev = (int64_t)g.out_read[b0 - 1]; }
+        if (q >= 0) {
+            const u32 cq = g.n_valid[g.tile0 + q], sq = g.n_scan ? g.n_scan[g.tile0 + q] : 0u;
+            int64_t j = (int64_t)(sq ? sq : cq) - 1;
+            if (j < (int64_t)g.slab_cap) {
+                const Rec* t = g.slab + (size_t)q * g.slab_cap;
+                while (j >= 0 && t[j].read == REC_REJECTED) --j;
+                if (j >= 0) prev = (int64_t)t[j].read;
+            }
+        } else { const u64 b0 = g.tile_base[0]; if (b0 > g.m0 && b0 <= g.out_cap) prev = (int64_t)g.out_read[b0 - 1]; }
     }
     const int64_t lo = (int64_t)g.slot0 - 1, hi = (int64_t)g.slot0 + g.n_reads;
     if (prev < lo) prev = lo;
-    for (u32 j0 = 0; j0 < nv; j0 += 64) {
+    u64 out = base;
+    for (u32 j0 = 0; j0 < slots; j0 += 64) {
         const u32 j = j0 + lane;
-        Rec r{}; r.read = 0;
-        if (j < nv) r = s[j];
-        int64_t pr = (int64_t)__shfl_up(r.read, 1, 64);
-        if (lane == 0) pr = prev;
-        prev = (int64_t)__shfl(r.read, 63, 64);                       // (only used when a further round follows: all 64 lanes hold records then)
-        if (j < nv) {
-            const u64 idx = base + j;
+        Rec r{}; r.read = REC_REJECTED;
+        if (j < slots) r = s[j];
+        const bool valid = r.read != REC_REJECTED;
+        const u64 bal = __ballot(valid);
+        const u64 lower = bal & ((1ull << lane) - 1ull);
+        const u32 from_lane = __shfl(r.read, lower ? 63 - __clzll((long long)lower) : 0, 64);      // the valid record in front of mine in this round
+        const int64_t pr = lower ? (int64_t)from_lane : prev;
+        const u32 last_valid = __shfl(r.read, bal ? 63 - __clzll((long long)bal) : 0, 64);
+        if (valid) {
+            const u64 idx = out + (u64)__popcll(lower);
             if (idx < g.out_cap) { g.out_hash[idx] = r.hash; g.out_pos[idx] = r.pos; g.out_read[idx] = r.read; }
             int64_t cur = (int64_t)r.read; if (cur > hi) cur = hi;
             for (int64_t x = pr + 1; x <= cur; ++x) g.off[x] = idx;
         }
+        if (bal) prev = (int64_t)last_valid;
+        out += (u64)__popcll(bal);
     }
     if (tail) {
-        int64_t last = nv ? (int64_t)s[nv - 1].read : prev;
-        if (last < lo) last = lo;
-        const u64 m_end = base + nv;
-        for (int64_t x = last + 1 + lane; x <= hi; x += 64) g.off[x] = m_end;
+        int64_t last = prev < lo ? lo : prev;
+        for (int64_t x = last + 1 + lane; x <= hi; x += 64) g.off[x] = out;
     }
 }
 
