@@ -45,6 +45,7 @@ struct SketchArgs {
     u32* err_flag; unsigned long long* slow_total;
     u32 read_base;               // slot index of the batch's first read in the resident store
     u64 bound; u32 l; u32 hpc; u32 btop;   // btop = top BS_B bits of the bound
+    u32 scheme, s;               // MDBG_SCHEME_SYNCMERS: s-mer length (0: every l-mer is a candidate); bound = floor(density * 4^l) then
     u32 force_slow;              // MDBG_FLAG_FORCE_GENERIC: every tile takes the generic exact walker
     u64* dbg;                    // diagnostic: per-tile phase timestamps [n_tiles][16] (null in production)
     u32 stop_phase;              // diagnostic (MDBG_STOP_PHASE): tiles stop after this phase and report no minimizers (0: run everything)
@@ -173,6 +174,11 @@ struct __attribute__((aligned(16))) TileLds {
     u32 pad_experiment[MDBG_LDS_PAD / 4];     // occupancy experiments only (scratch/build_variant.sh)
 #endif
 };
+template <int SCHEME> struct TileLdsS : TileLds {};
+template <> struct TileLdsS<1> : TileLds {
+    u32 ring[32][TILE_THREADS];               // the last <= 32 s-mer hashes of every thread's machine (column = thread)
+    u32 dstart[RW + 8];                       // bitmap over DENSE positions: a read starts here
+};
 // FMT_ASCII stages the half planes of its 16-base chunks (2 * RW words, phase 1 only) in memory that is idle then: the part of the dense
 // stream behind the read-start bitmap plus the keep masks (the stream part is zeroed again before phase 2 writes it)
 constexpr int STAGE_AT = 2 * (DPAD + RW + 4) + RW - 2 * RW;      // index into dense[]: the stage ends where kw[] ends
@@ -267,15 +273,167 @@ __device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab
     if (tid == 0) put_count(a, gt, running);
 }
 
+// ---- syncmer scheme (src/read.rs:215-352, --syncmers -s) -----------------------------------------------------------------
+// An l-mer of the (homopolymer-compressed) read is kept when the smallest of its w = l-s+1 canonical s-mer hashes sits at the middle
+// s-mer (index t-1, t = ceil(w/2)) and hash(canonical 2-bit l-mer) <= density * 4^l.  "Smallest" is the minimum TRACKED by the
+// reference's sliding deque (update_window, read.rs:55-80): leftmost minimum of the first full window; later a new s-mer replaces it
+// only when strictly smaller, and when the tracked s-mer leaves the window the window is rescanned from the back (rightmost minimum).
+// With s = 4 there are only 136 canonical s-mers, so tied minima are common and the history matters.  The state machine is
+// sequential, but it FORGETS: at any window whose minimum is unique the tracked position is that minimum whatever happened before.
+// Two implementations inside the tile kernel (SCHEME = 1).  Fast tiles run the machine over the tile's DENSE stream in LDS (phases 1-2 are
+// the density scheme's): one thread per stretch of ~94 dense positions, base codes straight from the bit planes, s-mer hashes in 32-bit
+// arithmetic, the last 32 hashes in an LDS ring — it starts some distance in front of its stretch and runs until a unique-minimum
+// window (or a read start) has been seen, from there on its state is the reference's; the selected window ends go to the candidate
+// bitmap, and the exact phase of the density scheme (exact hash of the canonical 2-bit l-mer, raw coordinates, ranks, records) takes over.
+// Tiles with bytes outside ACGT, or whose look-back window does not let every thread converge, run sync_slow_tile: the same machine
+// byte by byte through the input accessor, one thread per 127 raw positions, looking back 96, 384, ... positions, at most to the read start.
+constexpr int SYNC_KEEP = 8;                        // records a thread of the generic machine keeps between the count and the write (more: it runs a second time)
+__device__ inline u64 sync_hash(u64 key, u64 mask) {          // src/read.rs:43-52
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+// the same function on 32-bit values: with a mask of at most 32 bits every step only looks at the low 32 bits of its operands
+__device__ inline u32 sync_hash32(u32 key, u32 mask) {
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+__device__ inline u32 nt4_code(u8 c) {                         // src/read.rs:23-39 (SEQ_NT4_TABLE)
+    switch (c) {
+        case 0: case 'A': case 'a': return 0;
+        case 1: case 'C': case 'c': return 1;
+        case 2: case 'G': case 'g': return 2;
+        case 3: case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+// dq: per-thread ring of the last <= 32 s-mer hashes (s <= 16: 32 bits), column = thread; sc_tmp: 8 words of scan scratch + 1 flag
+template <bool HPC, class Src>
+__device__ void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[TILE_THREADS], u32* sc_tmp) {
+    constexpr u32 SEG = (TILE_STRIDE + TT - 1) / TT;           // raw positions per thread
+    u32& any_over = sc_tmp[8];
+    const int tid = threadIdx.x;
+    if (tid == 0) atomicAdd(a.slow_total, 1ull);
+    const u32 l = a.l, sm = a.s, w = l - sm + 1, t = (w + 1) / 2;
+    const u64 smask = sm ? ((1ull << (2 * sm)) - 1) : 0, lmask = (1ull << (2 * l)) - 1;
+    const u64 lshift = (u64)(l - 1) * 2, sshift = sm ? (u64)(sm - 1) * 2 : 0;
+    const u64 first_base = a.offsets[0];
+    const u64 t_lo = (u64)gt * TILE_STRIDE; u64 t_hi = t_lo + TILE_STRIDE; if (t_hi > a.n_bases) t_hi = a.n_bases;
+    u64 own_lo = t_lo + (u64)tid * SEG, own_hi = own_lo + SEG;      // the tile owns the l-mers whose LAST base (its run start) lies in [t_lo, t_hi)
+    if (own_lo < first_base) own_lo = first_base;
+    if (own_hi > t_hi) own_hi = t_hi;
+    if (tid == 0) any_over = 0;
+    __syncthreads();
+
+    // one run of the state machine over my segment; WRITE: records go to the slab from rank `base`, else up to SYNC_KEEP are kept
+    Rec keep[SYNC_KEEP]; u32 n_mine = 0;
+    auto run = [&](bool write, u32 base) {
+        n_mine = 0;
+        if (own_lo >= own_hi) return;
+        u32 r = find_read(a.offsets, 0, a.n_reads - 1, own_lo);
+        for (u64 look = 96;; look *= 4) {
+            // start: `look` positions in front of my segment, not before my first position's read (state is exact from a read start)
+            u64 rlo = a.offsets[r], rhi = a.offsets[r + 1];
+            u64 q = own_lo > rlo + look ? own_lo - look : rlo;
+            bool conv = q == rlo;                                 // the machine's state equals the reference's
+            u32 rr = r;
+            u64 xl0 = 0, xl1 = 0, min_val = ~0ull; u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, min_idx = 0, warm = 0;      // s <= 16: the s-mer fits 32 bits
+            u8 prev = q > rlo ? src.at(q - 1) : 0;
+            bool restart = false;
+            u64 clo = 0, chi = 0, cbase = ~0ull;                  // the 16 input bytes around q (one load per 16 positions instead of one per position)
+            for (; q < own_hi; ++q) {
+                while (q >= rhi) { ++rr; rlo = rhi; rhi = a.offsets[rr + 1]; lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; }   // next read: reset
+                if (q == own_lo && !conv) { restart = true; break; }
+                if ((q & ~15ull) != cbase) { cbase = q & ~15ull; src.chunk16(cbase, a.n_bases, clo, chi); }
+                const u32 bi = (u32)(q & 15);
+                const u8 c = (u8)(((bi & 8) ? chi : clo) >> (8 * (bi & 7)));
+                const bool kept = !HPC || q == rlo || !(c == prev && in_hpc_set(c));
+                prev = c;
+                if (!kept) continue;
+                const u32 code = nt4_code(c);
+                if (code >= 4) { lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; continue; }      // read.rs:334-341
+                xl0 = (xl0 << 2 | code) & lmask; xl1 = xl1 >> 2 | (u64)(3 - code) << lshift;
+                if (sm) { xs0 = (xs0 << 2 | code) & (u32)smask; xs1 = xs1 >> 2 | (3 - code) << (u32)sshift; }
+                ++lp; ++warm;
+                bool cand = false;
+                if (sm == 0) cand = lp >= l;
+                else if (lp >= sm) {
+                    const u32 hs = sync_hash32(xs0 < xs1 ? xs0 : xs1, (u32)smask);
+                    ++cnt;
+                    dq[cnt & 31][tid] = hs;
+                    if (cnt >= w) {
+                        if (cnt == w) {                            // first full window: leftmost minimum (read.rs:283-289)
+                            min_val = ~0ull;
+                            for (u32 j = cnt - w + 1; j <= cnt; ++j) { const u32 v = dq[j & 31][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
+                        } else if (min_idx == cnt - w) {           // the tracked s-mer left: rescan from the back (read.rs:63-72)
+                            min_val = ~0ull;
+                            for (u32 j = cnt; j + w > cnt; --j) { const u32 v = dq[j & 31][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
+                        } else if (hs < min_val) { min_val = hs; min_idx = cnt; }
+                        if (!conv && warm > l) {                   // everything in the window comes from bases behind my start: a unique minimum pins the state
+                            u32 ties = 0;
+                            for (u32 j = cnt - w + 1; j <= cnt; ++j) ties += dq[j & 31][tid] == (u32)min_val;
+                            conv = ties == 1;
+                        }
+                        cand = min_idx == cnt - w + t;
+                    }
+                }
+                if (sm == 0 && !conv && warm > l) conv = true;    // no tracked minimum in this mode: l genuine bases are all the state there is
+                if (cand && q >= own_lo) {
+                    const u64 hl = sync_hash(xl0 < xl1 ? xl0 : xl1, lmask);
+                    if (hl <= a.bound) {
+                        // raw position of the l-mer's first base: l-1 run starts back
+                        u64 st = q;
+                        for (u32 j = 1; j < l; ++j) {
+                            u64 q2 = st - 1;
+                            if (HPC) { const u8 c2 = src.at(q2); if (in_hpc_set(c2)) while (q2 > rlo && src.at(q2 - 1) == c2) --q2; }
+                            st = q2;
+                        }
+                        Rec rec; rec.hash = hl; rec.pos = (u32)(st - rlo); rec.read = rr + a.read_base;
+                        if (write) { if (base + n_mine < a.slab_cap) slab[base + n_mine] = rec; }
+                        else if (n_mine < SYNC_KEEP) keep[n_mine] = rec;
+                        ++n_mine;
+                    }
+                }
+            }
+            if (!restart) break;
+            n_mine = 0;
+        }
+    };
+    run(false, 0);
+    if (n_mine > SYNC_KEEP) any_over = 1;
+    u32 total;
+    const u32 base = block_excl_scan_256(n_mine, sc_tmp, total);          // (its barriers publish any_over)
+    if (!any_over) {
+        for (u32 i = 0; i < n_mine; ++i) if (base + i < a.slab_cap) slab[base + i] = keep[i];
+    } else run(true, base);
+    if (tid == 0) put_count(a, gt, total);
+}
+
+
 // ---- fast tile kernel ---------------------------------------------------------------------------------------------
 struct CandOut { u64 hash; u32 pos, read; };
 
 // One tile per workgroup.  (A persistent variant — workgroups looping over tiles with the next tile's words prefetched — was measured
 // and dropped: the loop makes the compiler keep ~100 more values live across the phases, 3-4 instead of 6 waves per SIMD, 3.4-4.9 ms
 // instead of 2.2 ms; capped to 80 registers it spills and is no better.  profiles/r02_notes.md.)
-template <int L>
-__global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
-    __shared__ TileLds S;
+// SCHEME 0: density scheme, L = l (compile-time: every shift of the bit-sliced filter is a constant).  SCHEME 1: syncmers, L = 0 and l
+// comes from the arguments (no bit-sliced filter: phase 3 is the window-minimum machine over the dense stream).
+template <int L, int SCHEME = 0>
+__global__ __launch_bounds__(TT, SCHEME ? 2 : 6) void sketch_bs_kernel(SketchArgs a) {
+    __shared__ TileLdsS<SCHEME> S;
+    const u32 Lr = SCHEME ? a.l : (u32)L;           // l
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t nb = (int64_t)a.n_bases;
     const int64_t n_pairs = (nb + 31) >> 5;
@@ -316,8 +474,13 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
     const u32 rl = rec->rl, rh_ = rec->rh;
     static_assert((2 * (DPAD + RW + 4)) % 4 == 0, "the dense stream is a whole number of 16-byte words");
     for (int i = tid; i < 2 * (DPAD + RW + 4) / 4; i += TT) ((uint4*)S.dense)[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < (2 << (2 * BS_GS))) S.t3[tid] = a.t4[tid];
-    if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[11] = 0; S.misc[17] = 0; S.misc[18] = 0; S.misc[19] = 0; S.misc[20] = 0; }
+    if (SCHEME == 0) { if (tid < (2 << (2 * BS_GS))) S.t3[tid] = a.t4[tid]; }
+    else {                                            // 8 bits -> 16 bits, bit i to bit 2 i: the exact phase interleaves the code planes with it
+        u32 v = 0;
+        for (int i = 0; i < 8; ++i) v |= ((u32)tid >> i & 1u) << (2 * i);
+        ((u16*)S.t3)[tid] = (u16)v;
+    }
+    if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[9] = 0; S.misc[11] = 0; S.misc[17] = 0; S.misc[18] = 0; S.misc[19] = 0; S.misc[20] = 0; }
     __syncthreads();
     if (rh_ - rl < (u32)TREC_N) {                       // the usual case: the read starts come with the tile's record
         if ((u32)tid <= rh_ - rl) {
@@ -353,7 +516,7 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
                 const int64_t pos = raw0 + 16 * (int64_t)(tid + TT * g);
                 for (int i = 0; i < 16; ++i) {
                     const int64_t q = pos + i;
-                    if (q >= 0 && q < nb) { const u8 c = a.bases[q]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') *a.err_flag = 1; }
+                    if (SCHEME == 0 && q >= 0 && q < nb) { const u8 c = a.bases[q]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') *a.err_flag = 1; }      // (syncmers: any other byte just resets the machine, src/read.rs:334-341)
                 }
             }
         }
@@ -427,19 +590,24 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
     if (a.stop_phase == 2) { if (tid == 0) a.n_valid[gt] = 0; return; }
     const u32 Hh = S.misc[11];
     const bool true_start = raw0 <= first_base;       // the stream begins inside this tile: nothing to look back at
-    if (S.misc[8] || (!true_start && Hh < (u32)L)) {
-        // N / foreign bytes, or the look-back window is one long homopolymer: exact generic walker for the whole tile
-        __syncthreads();
-        if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
-        else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
-        return;
-    }
+    auto run_slow_tile = [&]() {
+        // N / foreign bytes, or the look-back window is too short (one long homopolymer): exact generic path for the whole tile
+        if constexpr (SCHEME == 0) {
+            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
+            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
+        } else {
+            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, S.ring, S.misc); else sync_slow_tile<false>(a, src, gt, slab, S.ring, S.misc); }
+            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, S.ring, S.misc); else sync_slow_tile<false>(a, src, gt, slab, S.ring, S.misc); }
+        }
+    };
+    if (S.misc[8] || (!true_start && Hh < Lr)) { __syncthreads(); run_slow_tile(); return; }
 
     // ---- phase 3: bit-sliced filter over the dense stream -> candidate bitmap + (unordered) candidate list ---------------
     // candidate plane coordinate x = e + BS_B - 1; owned END positions e in [max(Hh, L-1), H)
-    const u32 e_lo = Hh > (u32)(L - 1) ? Hh : (u32)(L - 1);
+    const u32 e_lo = Hh > Lr - 1 ? Hh : Lr - 1;
     const u32 n_out = H ? ((H + BS_B - 2) >> 5) + 1 : 0;              // words of the candidate plane
-    {
+    const u32 n_rs = rh_ - rl + 1;                                     // reads that touch the staged range
+    if constexpr (SCHEME == 0) {
         u32 bmask[BS_B];
 #pragma unroll
         for (int i = 0; i < BS_B; ++i) bmask[i] = ((a.btop >> (BS_B - 1 - i)) & 1u) ? 0xFFFFFFFFu : 0u;
@@ -474,6 +642,75 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
             if (lane && (u32)D < n_out) S.c.cand[D] = cand;
         }
         for (u32 D = n_out + tid; D < RW + 8; D += TT) S.c.cand[D] = 0;
+    } else {
+        // ---- phase 3, syncmer scheme: the window-minimum machine (src/read.rs:215-352) over the dense stream -----------------------
+        const u32 l = a.l, sm = a.s, w = l - sm + 1, t = (w + 1) / 2;
+        const u32 smask = sm ? (sm >= 16 ? 0xFFFFFFFFu : (1u << (2 * sm)) - 1u) : 0u, sshift = sm ? 2 * (sm - 1) : 0;
+        for (int i = tid; i < RW + 8; i += TT) { S.dstart[i] = 0; S.c.cand[i] = 0; }
+        __syncthreads();
+        // read starts in DENSE coordinates (a start is a forced run start: its dense index is the number of kept bases in front of it)
+        auto mark_start = [&](int64_t rel) {
+            if (rel < 0 || rel >= (int64_t)RW * 32) return;
+            const u32 rw = (u32)rel >> 5, rb = (u32)rel & 31;
+            const u32 dp = S.rpre[rw] + (rb ? bs_popc(S.kw[rw] >> (32 - rb)) : 0u);
+            if (dp < H && ((S.kw[rw] << rb) & 0x80000000u)) atomicOr(&S.dstart[dp >> 5], 0x80000000u >> (dp & 31));
+        };
+        if (n_rs <= RS_CAP) { for (u32 i = tid; i < n_rs; i += TT) mark_start(i ? (int64_t)S.rs_rel[i] : S.rs0); }
+        else for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) mark_start((int64_t)a.offsets[r] - raw0);
+        __syncthreads();
+        // one thread per stretch of the owned END positions [e_lo, H)
+        const u32 n_own = H > e_lo ? H - e_lo : 0u, R = (n_own + TT - 1) / TT;
+        const u32 a0 = e_lo + (u32)tid * R < H ? e_lo + (u32)tid * R : H, b0 = a0 + R < H ? a0 + R : H;
+        if (a0 < b0) {
+            for (u32 look = 48;; look *= 4) {
+                const u32 q0 = a0 > look ? a0 - look : 0u;
+                bool conv = false, restart = false;                    // conv: the machine's state equals the reference's
+                u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, min_idx = 0, warm = 0; u64 min_val = ~0ull;
+                u32 P0 = 0, P1 = 0, ST = 0;
+                for (u32 p = q0; p < b0; ++p) {
+                    if (p == q0 || (p & 31u) == 0u) {
+                        const u32* dw = S.dense + 2 * (DPAD + (p >> 5));
+                        P1 = dw[1]; P0 = dw[0] ^ P1;                   // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
+                        ST = S.dstart[p >> 5];
+                    }
+                    const u32 sh = 31u - (p & 31u);
+                    if ((ST >> sh) & 1u) { lp = 0; cnt = 0; xs0 = xs1 = 0; min_val = ~0ull; conv = true; }      // a read starts here: exact state
+                    if (p == a0 && !conv) { restart = true; break; }
+                    const u32 c = ((P1 >> sh) & 1u) << 1 | ((P0 >> sh) & 1u);
+                    ++lp; ++warm;
+                    bool cand = false;
+                    if (sm == 0) { cand = lp >= l; if (!conv && warm > l) conv = true; }      // no tracked minimum: l genuine bases are all the state there is
+                    else {
+                        xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
+                        if (lp >= sm) {
+                            const u32 hs = sync_hash32(xs0 < xs1 ? xs0 : xs1, smask);
+                            ++cnt;
+                            S.ring[cnt & 31u][tid] = hs;
+                            if (cnt >= w) {
+                                if (cnt == w) {                        // first full window: leftmost minimum (read.rs:283-289)
+                                    min_val = ~0ull;
+                                    for (u32 j = cnt - w + 1; j <= cnt; ++j) { const u32 v = S.ring[j & 31u][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
+                                } else if (min_idx == cnt - w) {       // the tracked s-mer left: rescan from the back (read.rs:63-72)
+                                    min_val = ~0ull;
+                                    for (u32 j = cnt; j + w > cnt; --j) { const u32 v = S.ring[j & 31u][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
+                                } else if (hs < min_val) { min_val = hs; min_idx = cnt; }
+                                if (!conv && warm > l) {               // every s-mer of the window comes from bases behind my start: a unique minimum pins the state
+                                    u32 ties = 0;
+                                    for (u32 j = cnt - w + 1; j <= cnt; ++j) ties += S.ring[j & 31u][tid] == (u32)min_val;
+                                    conv = ties == 1;
+                                }
+                                cand = min_idx == cnt - w + t;
+                            }
+                        }
+                    }
+                    if (cand && p >= a0) { const u32 x = p + BS_B - 1; atomicOr(&S.c.cand[x >> 5], 0x80000000u >> (x & 31u)); }
+                }
+                if (!restart) break;
+                if (q0 == 0) { S.misc[9] = 1; break; }               // nothing further back in the staged stream: the tile takes the generic machine
+            }
+        }
+        __syncthreads();
+        if (S.misc[9]) { __syncthreads(); run_slow_tile(); return; }
     }
     __syncthreads();
     // the (unordered) candidate list: every thread expands the bitmap words 4 tid .. 4 tid + 3.  (Round 2 and the first version of this
@@ -523,18 +760,33 @@ __global__ __launch_bounds__(TT, 6) void sketch_bs_kernel(SketchArgs a) {
         while (S.rpre[w + 1] <= r) ++w;                                 // rpre[RW] = H > r
         return 32 * w + bs_select_msb(S.kw[w], r - S.rpre[w]);
     };
-    const u32 n_rs = rh_ - rl + 1;                                     // reads that touch the staged range
-    // exact 64-bit hash of the l-mer ending at dense position e (src/read.rs:196)
+    // exact 64-bit hash of the l-mer ending at dense position e: ntHash (src/read.rs:196), or — syncmers — the integer hash of the
+    // canonical 2-bit l-mer (src/read.rs:300-318): the two code planes are interleaved through the 8 -> 16 bit spread table in t3
     auto exact = [&](u32 e) -> u64 {
         const u32 wi = e >> 5, s = e & 31;
         const u32* dw = S.dense + 2 * (DPAD + wi);
-        const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);
-        return bs_exact_hash<BS_GS, L>(v0, v1, S.t3);
+        const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);      // bit u = dense position e - u
+        if constexpr (SCHEME == 0) return bs_exact_hash<BS_GS, L>(v0, v1, S.t3);
+        else {
+            const u32 lm = Lr >= 32 ? 0xFFFFFFFFu : (1u << Lr) - 1u;
+            const u32 r0 = (v0 ^ v1) & lm, r1 = v1 & lm;              // the reference's code bits of the base at distance u from the end
+            const u16* sp = (const u16*)S.t3;
+            const u32 lo = ((u32)sp[r0 & 255u] | (u32)sp[(r0 >> 8) & 255u] << 16) | ((u32)sp[r1 & 255u] | (u32)sp[(r1 >> 8) & 255u] << 16) << 1;
+            const u32 hi = ((u32)sp[(r0 >> 16) & 255u] | (u32)sp[r0 >> 24] << 16) | ((u32)sp[(r1 >> 16) & 255u] | (u32)sp[r1 >> 24] << 16) << 1;
+            const u64 lmask = (1ull << (2 * Lr)) - 1ull;
+            const u64 xl0 = (u64)hi << 32 | lo;                        // base at distance u in bit pair u (the newest base lowest: read.rs xl[0])
+            // xl[1]: complements (3 - code), pairs in reverse order inside the 2l-bit field
+            const u64 cm = ~xl0 & lmask;
+            u64 y = (u64)__brev((u32)cm) << 32 | (u64)__brev((u32)(cm >> 32));
+            y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+            const u64 xl1 = y >> (64 - 2 * Lr);
+            return sync_hash(xl0 < xl1 ? xl0 : xl1, lmask);
+        }
     };
     // raw coordinates of a selected l-mer (src/read.rs:196-208): its FIRST base decides the read; an l-mer that runs over the next
     // read's start (a forced run start, so its dense rank is the number of kept bases in front of it) belongs to no read
     auto place = [&](u32 e, u64 h, CandOut& o) -> bool {
-        const u32 sd = e - (u32)(L - 1);
+        const u32 sd = e - (Lr - 1);
         const int64_t rel_start = dense_to_raw(sd);
         u32 r; int64_t q0, q1;                                         // the read holding the first base; q0: its start, q1: the next read's, tile-relative
         if (n_rs <= RS_CAP) {
@@ -787,170 +1039,6 @@ __global__ void tile_flags_kernel(const u64* __restrict__ exc_pos, u32 n_exc, u3
     if (t + 1 < n_tiles && p + HALO_BASES >= (t + 1) * (u64)TILE_STRIDE) flags[t + 1] = 1;      // falls into the next tile's look-back window
 }
 
-// ---- syncmer scheme (src/read.rs:215-352, --syncmers -s) -----------------------------------------------------------------
-// An l-mer of the (homopolymer-compressed) read is kept when the smallest of its w = l-s+1 canonical s-mer hashes sits at the middle
-// s-mer (index t-1, t = ceil(w/2)) and hash(canonical 2-bit l-mer) <= density * 4^l.  "Smallest" is the minimum TRACKED by the
-// reference's sliding deque (update_window, read.rs:55-80): leftmost minimum of the first full window; later a new s-mer replaces it
-// only when strictly smaller, and when the tracked s-mer leaves the window the window is rescanned from the back (rightmost minimum).
-// With s = 4 there are only 136 canonical s-mers, so tied minima are common and the history matters.  The state machine is
-// sequential, but it FORGETS: at any window whose minimum is unique the tracked position is that minimum whatever happened before.
-// One thread per 256 raw positions: it starts the machine some distance in front of its segment and runs until a unique-minimum
-// window (or a reset: read start / a byte outside ACGTU) has been seen — from there on its state is the reference's — looking
-// further back (96, 384, ... positions, at most to the read start) in the rare case that it reaches its segment unconverged.
-constexpr int SYNC_SEG = 256;                       // raw positions per thread
-constexpr int SYNC_TILE = TT * SYNC_SEG;            // raw positions per workgroup
-constexpr int SYNC_KEEP = 8;                        // records a thread keeps between the count and the write (more: the tile runs a second time)
-struct SyncArgs {
-    const u8* bases; const uint2* planes; u32 fmt; const u64* exc_pos; const u8* exc_val; u32 n_exc;
-    u64 n_bases; const u64* offsets; u32 n_reads;
-    u32 tile0; Rec* slab; u32 slab_cap; u32* n_valid; u32* over_max;
-    u32 read_base; u32 l, s, hpc; u64 bound;        // bound = floor(density * 4^l), saturating (read.rs:218)
-};
-__device__ inline u64 sync_hash(u64 key, u64 mask) {          // src/read.rs:43-52
-    key = (~key + (key << 21)) & mask;
-    key = key ^ key >> 24;
-    key = ((key + (key << 3)) + (key << 8)) & mask;
-    key = key ^ key >> 14;
-    key = ((key + (key << 2)) + (key << 4)) & mask;
-    key = key ^ key >> 28;
-    key = (key + (key << 31)) & mask;
-    return key;
-}
-// the same function on 32-bit values: with a mask of at most 32 bits every step only looks at the low 32 bits of its operands
-__device__ inline u32 sync_hash32(u32 key, u32 mask) {
-    key = (~key + (key << 21)) & mask;
-    key = key ^ key >> 24;
-    key = ((key + (key << 3)) + (key << 8)) & mask;
-    key = key ^ key >> 14;
-    key = ((key + (key << 2)) + (key << 4)) & mask;
-    key = key ^ key >> 28;
-    key = (key + (key << 31)) & mask;
-    return key;
-}
-__device__ inline u32 nt4_code(u8 c) {                         // src/read.rs:23-39 (SEQ_NT4_TABLE)
-    switch (c) {
-        case 0: case 'A': case 'a': return 0;
-        case 1: case 'C': case 'c': return 1;
-        case 2: case 'G': case 'g': return 2;
-        case 3: case 'T': case 't': case 'U': case 'u': return 3;
-        default: return 4;
-    }
-}
-
-template <bool HPC, class Src>
-__global__ __launch_bounds__(TT) void syncmer_tile_kernel(SyncArgs a, Src src) {
-    __shared__ u32 dq[32][TT];                     // per-thread ring of the last <= 32 s-mer hashes (s <= 16: 32 bits), column = thread
-    __shared__ u32 sc_tmp[8];
-    __shared__ u32 any_over;
-    const int tid = threadIdx.x;
-    const u32 gt = a.tile0 + blockIdx.x;
-    Rec* const slab = a.slab + (size_t)blockIdx.x * a.slab_cap;
-    const u32 l = a.l, sm = a.s, w = l - sm + 1, t = (w + 1) / 2;
-    const u64 smask = sm ? ((1ull << (2 * sm)) - 1) : 0, lmask = (1ull << (2 * l)) - 1;
-    const u64 lshift = (u64)(l - 1) * 2, sshift = sm ? (u64)(sm - 1) * 2 : 0;
-    const u64 first_base = a.offsets[0];
-    u64 own_lo = (u64)gt * SYNC_TILE + (u64)tid * SYNC_SEG, own_hi = own_lo + SYNC_SEG;
-    if (own_lo < first_base) own_lo = first_base;
-    if (own_hi > a.n_bases) own_hi = a.n_bases;
-    if (tid == 0) any_over = 0;
-    __syncthreads();
-
-    // one run of the state machine over my segment; WRITE: records go to the slab from rank `base`, else up to SYNC_KEEP are kept
-    Rec keep[SYNC_KEEP]; u32 n_mine = 0;
-    auto run = [&](bool write, u32 base) {
-        n_mine = 0;
-        if (own_lo >= own_hi) return;
-        u32 r = find_read(a.offsets, 0, a.n_reads - 1, own_lo);
-        for (u64 look = 96;; look *= 4) {
-            // start: `look` positions in front of my segment, not before my first position's read (state is exact from a read start)
-            u64 rlo = a.offsets[r], rhi = a.offsets[r + 1];
-            u64 q = own_lo > rlo + look ? own_lo - look : rlo;
-            bool conv = q == rlo;                                 // the machine's state equals the reference's
-            u32 rr = r;
-            u64 xl0 = 0, xl1 = 0, min_val = ~0ull; u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, min_idx = 0, warm = 0;      // s <= 16: the s-mer fits 32 bits
-            u8 prev = q > rlo ? src.at(q - 1) : 0;
-            bool restart = false;
-            u64 clo = 0, chi = 0, cbase = ~0ull;                  // the 16 input bytes around q (one load per 16 positions instead of one per position)
-            for (; q < own_hi; ++q) {
-                while (q >= rhi) { ++rr; rlo = rhi; rhi = a.offsets[rr + 1]; lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; }   // next read: reset
-                if (q == own_lo && !conv) { restart = true; break; }
-                if ((q & ~15ull) != cbase) { cbase = q & ~15ull; src.chunk16(cbase, a.n_bases, clo, chi); }
-                const u32 bi = (u32)(q & 15);
-                const u8 c = (u8)(((bi & 8) ? chi : clo) >> (8 * (bi & 7)));
-                const bool kept = !HPC || q == rlo || !(c == prev && in_hpc_set(c));
-                prev = c;
-                if (!kept) continue;
-                const u32 code = nt4_code(c);
-                if (code >= 4) { lp = 0; cnt = 0; xl0 = xl1 = xs0 = xs1 = 0; min_val = ~0ull; conv = true; continue; }      // read.rs:334-341
-                xl0 = (xl0 << 2 | code) & lmask; xl1 = xl1 >> 2 | (u64)(3 - code) << lshift;
-                if (sm) { xs0 = (xs0 << 2 | code) & (u32)smask; xs1 = xs1 >> 2 | (3 - code) << (u32)sshift; }
-                ++lp; ++warm;
-                bool cand = false;
-                if (sm == 0) cand = lp >= l;
-                else if (lp >= sm) {
-                    const u32 hs = sync_hash32(xs0 < xs1 ? xs0 : xs1, (u32)smask);
-                    ++cnt;
-                    dq[cnt & 31][tid] = hs;
-                    if (cnt >= w) {
-                        if (cnt == w) {                            // first full window: leftmost minimum (read.rs:283-289)
-                            min_val = ~0ull;
-                            for (u32 j = cnt - w + 1; j <= cnt; ++j) { const u32 v = dq[j & 31][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
-                        } else if (min_idx == cnt - w) {           // the tracked s-mer left: rescan from the back (read.rs:63-72)
-                            min_val = ~0ull;
-                            for (u32 j = cnt; j + w > cnt; --j) { const u32 v = dq[j & 31][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
-                        } else if (hs < min_val) { min_val = hs; min_idx = cnt; }
-                        if (!conv && warm > l) {                   // everything in the window comes from bases behind my start: a unique minimum pins the state
-                            u32 ties = 0;
-                            for (u32 j = cnt - w + 1; j <= cnt; ++j) ties += dq[j & 31][tid] == (u32)min_val;
-                            conv = ties == 1;
-                        }
-                        cand = min_idx == cnt - w + t;
-                    }
-                }
-                if (sm == 0 && !conv && warm > l) conv = true;    // no tracked minimum in this mode: l genuine bases are all the state there is
-                if (cand && q >= own_lo) {
-                    const u64 hl = sync_hash(xl0 < xl1 ? xl0 : xl1, lmask);
-                    if (hl <= a.bound) {
-                        // raw position of the l-mer's first base: l-1 run starts back
-                        u64 st = q;
-                        for (u32 j = 1; j < l; ++j) {
-                            u64 q2 = st - 1;
-                            if (HPC) { const u8 c2 = src.at(q2); if (in_hpc_set(c2)) while (q2 > rlo && src.at(q2 - 1) == c2) --q2; }
-                            st = q2;
-                        }
-                        Rec rec; rec.hash = hl; rec.pos = (u32)(st - rlo); rec.read = rr + a.read_base;
-                        if (write) { if (base + n_mine < a.slab_cap) slab[base + n_mine] = rec; }
-                        else if (n_mine < SYNC_KEEP) keep[n_mine] = rec;
-                        ++n_mine;
-                    }
-                }
-            }
-            if (!restart) break;
-            n_mine = 0;
-        }
-    };
-    run(false, 0);
-    if (n_mine > SYNC_KEEP) any_over = 1;
-    u32 total;
-    const u32 base = block_excl_scan_256(n_mine, sc_tmp, total);          // (its barriers publish any_over)
-    if (!any_over) {
-        for (u32 i = 0; i < n_mine; ++i) if (base + i < a.slab_cap) slab[base + i] = keep[i];
-    } else run(true, base);
-    if (tid == 0) { a.n_valid[gt] = total; if (total > a.slab_cap) atomicMax(a.over_max, total); }
-}
-
-template <class Src> static void launch_sync_src(const SyncArgs& a, u32 n_wg, const Src& src, hipStream_t s) {
-    if (a.hpc) hipLaunchKernelGGL((syncmer_tile_kernel<true, Src>), dim3(n_wg), dim3(TT), 0, s, a, src);
-    else hipLaunchKernelGGL((syncmer_tile_kernel<false, Src>), dim3(n_wg), dim3(TT), 0, s, a, src);
-}
-void launch_syncmers(const SyncArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
-    if (!n_wg) return;
-    if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    if (a.fmt == FMT_ASCII) launch_sync_src(a, n_wg, AsciiSrc{a.bases}, s);
-    else launch_sync_src(a, n_wg, PlaneSrc{a.planes, a.exc_pos, a.exc_val, a.n_exc}, s);
-    if (ev_end) (void)hipEventRecord(ev_end, s);
-}
-
 // ---- ASCII -> 2-bit planes on the device (mdbg_pack_device) -------------------------------------------------------
 // one thread per 32 bases; bytes outside ACGT are appended (unordered) to the exception list
 __global__ __launch_bounds__(256) void pack_planes_kernel(const u8* __restrict__ bases, u64 n_bases, uint2* __restrict__ words,
@@ -1008,7 +1096,8 @@ template <int L> static void launch_bs(const SketchArgs& a, u32 n_wg, hipStream_
 void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (!n_wg) return;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    switch (a.l) {
+    if (a.scheme == 1) hipLaunchKernelGGL((sketch_bs_kernel<0, 1>), dim3(n_wg), dim3(TT), 0, s, a);      // syncmers: l is a run-time value
+    else switch (a.l) {
 #define MDBG_L(n) case n: launch_bs<n>(a, n_wg, s); break;
         MDBG_L(2) MDBG_L(3) MDBG_L(4) MDBG_L(5) MDBG_L(6) MDBG_L(7) MDBG_L(8) MDBG_L(9) MDBG_L(10) MDBG_L(11) MDBG_L(12) MDBG_L(13)
         MDBG_L(14) MDBG_L(15) MDBG_L(16) MDBG_L(17) MDBG_L(18) MDBG_L(19) MDBG_L(20) MDBG_L(21) MDBG_L(22) MDBG_L(23) MDBG_L(24)
