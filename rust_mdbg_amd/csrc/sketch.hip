@@ -175,10 +175,13 @@ struct __attribute__((aligned(16))) TileLds {
 #endif
 };
 template <int SCHEME> struct TileLdsS : TileLds {};
+// syncmers: + a bitmap over DENSE positions (a read starts here), padded to 32 KB: the generic machine of a flagged tile keeps its ring
+// of s-mer hashes (32 x 256 words) on top of the whole structure, which is dead by then
 template <> struct TileLdsS<1> : TileLds {
-    u32 ring[32][TILE_THREADS];               // the last <= 32 s-mer hashes of every thread's machine (column = thread)
-    u32 dstart[RW + 8];                       // bitmap over DENSE positions: a read starts here
+    u32 dstart[RW + 8];
+    u32 pad_to_ring[(32 * TILE_THREADS * 4 - sizeof(TileLds) - (RW + 8) * 4) / 4];
 };
+static_assert(sizeof(TileLdsS<1>) == 32 * TILE_THREADS * 4, "the ring of the generic syncmer machine covers the tile state exactly");
 // FMT_ASCII stages the half planes of its 16-base chunks (2 * RW words, phase 1 only) in memory that is idle then: the part of the dense
 // stream behind the read-start bitmap plus the keep masks (the stream part is zeroed again before phase 2 writes it)
 constexpr int STAGE_AT = 2 * (DPAD + RW + 4) + RW - 2 * RW;      // index into dense[]: the stage ends where kw[] ends
@@ -321,7 +324,7 @@ __device__ inline u32 nt4_code(u8 c) {                         // src/read.rs:23
 
 // dq: per-thread ring of the last <= 32 s-mer hashes (s <= 16: 32 bits), column = thread; sc_tmp: 8 words of scan scratch + 1 flag
 template <bool HPC, class Src>
-__device__ void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[TILE_THREADS], u32* sc_tmp) {
+__device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[TILE_THREADS], u32* sc_tmp) {
     constexpr u32 SEG = (TILE_STRIDE + TT - 1) / TT;           // raw positions per thread
     u32& any_over = sc_tmp[8];
     const int tid = threadIdx.x;
@@ -430,9 +433,12 @@ struct CandOut { u64 hash; u32 pos, read; };
 // instead of 2.2 ms; capped to 80 registers it spills and is no better.  profiles/r02_notes.md.)
 // SCHEME 0: density scheme, L = l (compile-time: every shift of the bit-sliced filter is a constant).  SCHEME 1: syncmers, L = 0 and l
 // comes from the arguments (no bit-sliced filter: phase 3 is the window-minimum machine over the dense stream).
-template <int L, int SCHEME = 0>
-__global__ __launch_bounds__(TT, SCHEME ? 2 : 6) void sketch_bs_kernel(SketchArgs a) {
+// WMAX (syncmers): the window w = l - s + 1 itself (1 .. 32): the register window of s-mer hashes and its loops are unrolled over exactly w entries
+// with static register indices
+template <int L, int SCHEME = 0, int WMAX = 1>
+__global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArgs a) {
     __shared__ TileLdsS<SCHEME> S;
+    __shared__ u32 sync_tmp[SCHEME ? 16 : 1];       // scan scratch of the generic syncmer machine (its ring covers S)
     const u32 Lr = SCHEME ? a.l : (u32)L;           // l
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t nb = (int64_t)a.n_bases;
@@ -596,8 +602,8 @@ __global__ __launch_bounds__(TT, SCHEME ? 2 : 6) void sketch_bs_kernel(SketchArg
             if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
             else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
         } else {
-            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, S.ring, S.misc); else sync_slow_tile<false>(a, src, gt, slab, S.ring, S.misc); }
-            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, S.ring, S.misc); else sync_slow_tile<false>(a, src, gt, slab, S.ring, S.misc); }
+            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); }
+            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); }
         }
     };
     if (S.misc[8] || (!true_start && Hh < Lr)) { __syncthreads(); run_slow_tile(); return; }
@@ -658,55 +664,91 @@ __global__ __launch_bounds__(TT, SCHEME ? 2 : 6) void sketch_bs_kernel(SketchArg
         if (n_rs <= RS_CAP) { for (u32 i = tid; i < n_rs; i += TT) mark_start(i ? (int64_t)S.rs_rel[i] : S.rs0); }
         else for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) mark_start((int64_t)a.offsets[r] - raw0);
         __syncthreads();
-        // one thread per stretch of the owned END positions [e_lo, H)
-        const u32 n_own = H > e_lo ? H - e_lo : 0u, R = (n_own + TT - 1) / TT;
+        // One thread per stretch of the owned END positions [e_lo, H).  Stretches are whole numbers of 32 positions and the look-back is a
+        // multiple of 32, and every lane runs the same number of iterations (positions in front of the stream or behind the stretch are
+        // idle ones): the iteration index `it` and (p mod 32) are the same in every lane, so word loads, bitmap flushes and the slot of
+        // the window that an iteration writes are uniform.  The window of the last w s-mer hashes lives in WMAX registers, slot =
+        // it mod WMAX (the loop is unrolled WMAX times: static register indices, nothing is shifted), and the rules of the reference's deque
+        // are evaluated branch-free from the window's minimum and the age of its rightmost occurrence:
+        //   the tracked s-mer leaves -> rightmost minimum (the rescan from the back);  a strictly smaller s-mer arrives -> the new one;
+        //   else unchanged;   first full window of a read -> leftmost minimum;   while the state is not known to be the reference's: a
+        //   unique minimum -> tracked = it, whatever happened before (the leftmost occurrence is only looked for in these two cases).
+        //   (A first version kept the hashes in an LDS ring and branched like the reference: every rare branch was taken by SOME lane
+        //   in nearly every iteration — 90 Gbases/s at 2 workgroups per CU, bound by LDS latency.)
+        const u32 n_own = H > e_lo ? H - e_lo : 0u, R = ((n_own + TT - 1) / TT + 31u) & ~31u;
         const u32 a0 = e_lo + (u32)tid * R < H ? e_lo + (u32)tid * R : H, b0 = a0 + R < H ? a0 + R : H;
-        if (a0 < b0) {
-            for (u32 look = 48;; look *= 4) {
-                const u32 q0 = a0 > look ? a0 - look : 0u;
-                bool conv = false, restart = false;                    // conv: the machine's state equals the reference's
-                u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, min_idx = 0, warm = 0; u64 min_val = ~0ull;
-                u32 P0 = 0, P1 = 0, ST = 0;
-                for (u32 p = q0; p < b0; ++p) {
-                    if (p == q0 || (p & 31u) == 0u) {
-                        const u32* dw = S.dense + 2 * (DPAD + (p >> 5));
-                        P1 = dw[1]; P0 = dw[0] ^ P1;                   // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
-                        ST = S.dstart[p >> 5];
-                    }
-                    const u32 sh = 31u - (p & 31u);
-                    if ((ST >> sh) & 1u) { lp = 0; cnt = 0; xs0 = xs1 = 0; min_val = ~0ull; conv = true; }      // a read starts here: exact state
-                    if (p == a0 && !conv) { restart = true; break; }
-                    const u32 c = ((P1 >> sh) & 1u) << 1 | ((P0 >> sh) & 1u);
-                    ++lp; ++warm;
-                    bool cand = false;
-                    if (sm == 0) { cand = lp >= l; if (!conv && warm > l) conv = true; }      // no tracked minimum: l genuine bases are all the state there is
-                    else {
-                        xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
-                        if (lp >= sm) {
-                            const u32 hs = sync_hash32(xs0 < xs1 ? xs0 : xs1, smask);
-                            ++cnt;
-                            S.ring[cnt & 31u][tid] = hs;
-                            if (cnt >= w) {
-                                if (cnt == w) {                        // first full window: leftmost minimum (read.rs:283-289)
-                                    min_val = ~0ull;
-                                    for (u32 j = cnt - w + 1; j <= cnt; ++j) { const u32 v = S.ring[j & 31u][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
-                                } else if (min_idx == cnt - w) {       // the tracked s-mer left: rescan from the back (read.rs:63-72)
-                                    min_val = ~0ull;
-                                    for (u32 j = cnt; j + w > cnt; --j) { const u32 v = S.ring[j & 31u][tid]; if (v < min_val) { min_val = v; min_idx = j; } }
-                                } else if (hs < min_val) { min_val = hs; min_idx = cnt; }
-                                if (!conv && warm > l) {               // every s-mer of the window comes from bases behind my start: a unique minimum pins the state
-                                    u32 ties = 0;
-                                    for (u32 j = cnt - w + 1; j <= cnt; ++j) ties += S.ring[j & 31u][tid] == (u32)min_val;
-                                    conv = ties == 1;
-                                }
-                                cand = min_idx == cnt - w + t;
-                            }
+        // s <= 4: the s-mer hash comes from a table (second half of t3: 256 x u16, filled here)
+        const bool use_lut = sm != 0 && sm <= 4;
+        u16* const lut = (u16*)S.t3 + 256;
+        if (use_lut) lut[tid] = (u16)sync_hash32((u32)tid & smask, smask);
+        __syncthreads();
+        {
+            for (u32 look = 64;; look *= 4) {
+                const int32_t q0 = (int32_t)a0 - (int32_t)look;        // may lie in front of the stream: idle iterations
+                bool conv = false, restart = false, mine = false;      // conv: the machine's state equals the reference's; mine: I reached my stretch without it
+                u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, warm = 0, ta = 0, mvp = 0;
+                u32 win[WMAX];
+#pragma unroll
+                for (int j = 0; j < WMAX; ++j) win[j] = 0;
+                u32 P0 = 0, P1 = 0, ST = 0, cbits = 0;
+                const u32 n_it = look + R;                             // the same for every lane
+                for (u32 it0 = 0; it0 < n_it && !restart; it0 += WMAX) {
+#pragma unroll
+                    for (int u = 0; u < WMAX; ++u) {
+                        const u32 it = it0 + (u32)u;
+                        const int32_t p = q0 + (int32_t)it;
+                        const bool live = p >= 0 && (u32)p < b0 && a0 < b0;      // (idle: in front of the stream, behind my stretch, or no stretch at all)
+                        if (((u32)p & 31u) == 0u || it == 0) {
+                            const bool in = p >= 0 && (u32)p < (u32)(RW + 4) * 32u;
+                            const u32* dw = S.dense + 2 * (DPAD + (in ? (u32)p >> 5 : 0u));
+                            P1 = in ? dw[1] : 0u; P0 = in ? dw[0] ^ P1 : 0u;      // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
+                            ST = in ? S.dstart[(u32)p >> 5] : 0u;
                         }
+                        const u32 sh = 31u - ((u32)p & 31u);
+                        if (live && ((ST >> sh) & 1u)) { lp = 0; cnt = 0; xs0 = xs1 = 0; conv = true; }      // a read starts here: exact state
+                        if (it == look && a0 < b0 && !conv) mine = true;         // (uniform iteration; the wave agrees on the restart at the end of the block)
+                        const u32 c = ((P1 >> sh) & 1u) << 1 | ((P0 >> sh) & 1u);
+                        lp += live ? 1u : 0u; warm += live ? 1u : 0u;
+                        bool cand = false;
+                        if (sm == 0) { cand = live && lp >= l; conv = conv || warm > l; }      // no tracked minimum: l genuine bases are all the state there is
+                        else {
+                            xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;      // (idle iterations only precede or follow the live ones: what they shift in is shifted out again before an s-mer counts)
+                            const bool push = live && lp >= sm;
+                            const u32 key = xs0 < xs1 ? xs0 : xs1;
+                            const u32 hs = use_lut ? (u32)lut[key & 255u] : sync_hash32(key, smask);
+                            cnt += push ? 1u : 0u;
+                            // the window holds hash << 5; OR-ing the age in makes ONE unsigned minimum find the smallest hash and, among
+                            // equal ones, the youngest (= rightmost) occurrence (s <= 13: 26 hash bits + 5 age bits)
+                            win[u] = hs << 5;                          // (slots written by idle iterations are never inside a full window: cnt counts consecutive pushes)
+                            u32 best = hs << 5;
+#pragma unroll
+                            for (int j = 1; j < WMAX; ++j) { const u32 kj = win[(u - j + WMAX) % WMAX] | (u32)j; best = kj < best ? kj : best; }
+                            const u32 mv = best >> 5, rm = best & 31u;
+                            const bool valid = push && cnt >= w, first = push && cnt == w;
+                            u32 lm = rm; bool uniq = false;
+                            if (!conv || first) {                      // rare: warm-up, or the first full window of a read
+#pragma unroll
+                                for (int j = 1; j < WMAX; ++j) { const u32 v = win[(u - j + WMAX) % WMAX] >> 5; lm = v == mv ? (u32)j : lm; }
+                                uniq = lm == rm;
+                            }
+                            const u32 older = ta + 1;
+                            const u32 ta_new = first ? lm : ((uniq || older >= w) ? rm : (hs < mvp ? 0u : older));
+                            ta = push ? ta_new : ta; mvp = push ? mv : mvp;
+                            conv = conv || (valid && uniq && warm > l);     // every s-mer of the window comes from bases behind my start: a unique minimum pins the state
+                            cand = valid && ta == w - t;
+                        }
+                        // candidate plane coordinate x = p + BS_B - 1; the bits of one word are collected and written once
+                        const u32 x = (u32)p + BS_B - 1;
+                        if (cand && live && !mine && (u32)p >= a0) cbits |= 0x80000000u >> (x & 31u);
+                        if ((x & 31u) == 31u || it + 1 == n_it) { if (cbits) atomicOr(&S.c.cand[x >> 5], cbits); cbits = 0; }
                     }
-                    if (cand && p >= a0) { const u32 x = p + BS_B - 1; atomicOr(&S.c.cand[x >> 5], 0x80000000u >> (x & 31u)); }
+                    restart = __any((int)mine) != 0;                   // leave together (the wave's control flow stays uniform)
                 }
                 if (!restart) break;
-                if (q0 == 0) { S.misc[9] = 1; break; }               // nothing further back in the staged stream: the tile takes the generic machine
+                // somebody reached its stretch unconverged: everybody looks further back (rare); nothing further back in the staged stream: the
+                // tile takes the generic machine
+                if (mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 4096u)) S.misc[9] = 1;
+                if (__any((int)(mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 4096u)))) break;
             }
         }
         __syncthreads();
@@ -1096,7 +1138,15 @@ template <int L> static void launch_bs(const SketchArgs& a, u32 n_wg, hipStream_
 void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (!n_wg) return;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    if (a.scheme == 1) hipLaunchKernelGGL((sketch_bs_kernel<0, 1>), dim3(n_wg), dim3(TT), 0, s, a);      // syncmers: l is a run-time value
+    if (a.scheme == 1) {                              // syncmers: l is a run-time value, the window a compile-time one
+        switch (a.l - a.s + 1) {
+#define MDBG_W(n) case n: hipLaunchKernelGGL((sketch_bs_kernel<0, 1, n>), dim3(n_wg), dim3(TT), 0, s, a); break;
+            MDBG_W(1) MDBG_W(2) MDBG_W(3) MDBG_W(4) MDBG_W(5) MDBG_W(6) MDBG_W(7) MDBG_W(8) MDBG_W(9) MDBG_W(10) MDBG_W(11) MDBG_W(12) MDBG_W(13) MDBG_W(14) MDBG_W(15) MDBG_W(16)
+            MDBG_W(17) MDBG_W(18) MDBG_W(19) MDBG_W(20) MDBG_W(21) MDBG_W(22) MDBG_W(23) MDBG_W(24) MDBG_W(25) MDBG_W(26) MDBG_W(27) MDBG_W(28) MDBG_W(29) MDBG_W(30) MDBG_W(31)
+#undef MDBG_W
+            default: hipLaunchKernelGGL((sketch_bs_kernel<0, 1, 32>), dim3(n_wg), dim3(TT), 0, s, a); break;
+        }
+    }
     else switch (a.l) {
 #define MDBG_L(n) case n: launch_bs<n>(a, n_wg, s); break;
         MDBG_L(2) MDBG_L(3) MDBG_L(4) MDBG_L(5) MDBG_L(6) MDBG_L(7) MDBG_L(8) MDBG_L(9) MDBG_L(10) MDBG_L(11) MDBG_L(12) MDBG_L(13)
