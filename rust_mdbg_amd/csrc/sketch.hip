@@ -680,6 +680,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         // s <= 4: the s-mer hash comes from a table (second half of t3: 256 x u16, filled here)
         const bool use_lut = sm != 0 && sm <= 4;
         u16* const lut = (u16*)S.t3 + 256;
+        const u32 e_lo_s = (u32)__builtin_amdgcn_readfirstlane((int)e_lo);      // a0 = e_lo + tid * R, R and the look-back multiples of 32: p mod 32 = (e_lo + it) mod 32 in every lane
         if (use_lut) lut[tid] = (u16)sync_hash32((u32)tid & smask, smask);
         __syncthreads();
         {
@@ -698,13 +699,14 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
                         const u32 it = it0 + (u32)u;
                         const int32_t p = q0 + (int32_t)it;
                         const bool live = p >= 0 && (u32)p < b0 && a0 < b0;      // (idle: in front of the stream, behind my stretch, or no stretch at all)
-                        if (((u32)p & 31u) == 0u || it == 0) {
+                        const u32 pm = (e_lo_s + it) & 31u;             // = p mod 32, a scalar
+                        if (pm == 0u || it == 0) {
                             const bool in = p >= 0 && (u32)p < (u32)(RW + 4) * 32u;
                             const u32* dw = S.dense + 2 * (DPAD + (in ? (u32)p >> 5 : 0u));
                             P1 = in ? dw[1] : 0u; P0 = in ? dw[0] ^ P1 : 0u;      // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
                             ST = in ? S.dstart[(u32)p >> 5] : 0u;
                         }
-                        const u32 sh = 31u - ((u32)p & 31u);
+                        const u32 sh = 31u - pm;
                         if (live && ((ST >> sh) & 1u)) { lp = 0; cnt = 0; xs0 = xs1 = 0; conv = true; }      // a read starts here: exact state
                         if (it == look && a0 < b0 && !conv) mine = true;         // (uniform iteration; the wave agrees on the restart at the end of the block)
                         const u32 c = ((P1 >> sh) & 1u) << 1 | ((P0 >> sh) & 1u);
@@ -739,8 +741,9 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
                         }
                         // candidate plane coordinate x = p + BS_B - 1; the bits of one word are collected and written once
                         const u32 x = (u32)p + BS_B - 1;
-                        if (cand && live && !mine && (u32)p >= a0) cbits |= 0x80000000u >> (x & 31u);
-                        if ((x & 31u) == 31u || it + 1 == n_it) { if (cbits) atomicOr(&S.c.cand[x >> 5], cbits); cbits = 0; }
+                        const u32 xm = (pm + BS_B - 1) & 31u;
+                        if (cand && live && !mine && (u32)p >= a0) cbits |= 0x80000000u >> xm;
+                        if (xm == 31u || it + 1 == n_it) { if (cbits) atomicOr(&S.c.cand[x >> 5], cbits); cbits = 0; }
                     }
                     restart = __any((int)mine) != 0;                   // leave together (the wave's control flow stays uniform)
                 }
