@@ -6,8 +6,11 @@ A "step" = one pass of the hot path over one batch already resident in HBM:
 Workload at N=1: BASELINE.json configs[2] (synthetic D. melanogaster: 140 Mb genome @50x, ~15 kb reads, 0.1 % errors,
 k=35 l=12 d=0.002 minabund=2).  For N>1: BASELINE.json configs[3] (synthetic human 3 Gb @52x over 8 GPUs = 375 Mb of genome
 and 19.5 Gbases of reads per GPU, k=35 l=14 d=0.003; weak scaling: the genome grows with N, coverage constant) and the
-table is partitioned by key range; the ranks exchange their sketches over RCCL send/recv pairs (default) or route the k-min-mer
-occurrences to their owner with one RCCL all-to-all per step (--dist-mode route; rust_mdbg_amd/dist.py).
+table is partitioned by key range; the ranks exchange the hashes of their sketches over RCCL send/recv pairs inside libmdbg_hip.so
+(include/mdbg_dist.h; default) or route the k-min-mer occurrences to their owner with one RCCL all-to-all per step (--dist-mode route;
+rust_mdbg_amd/dist.py).  `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, one rank per GPU) and exits
+non-zero when fewer than N GPUs are visible; under an external launcher WORLD_SIZE must equal --gpus; `n_gpus` in the line is the
+number of ranks that took part in an all-reduce.
 The reads sit in HBM in the north star's layout, packed 2 bits per base (--input ascii: one byte per base).
 
 Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_bs_kernel) as fed in the timed region and
@@ -43,7 +46,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
-                    help="multi-GPU mode: exchange of sketches + key-partitioned table (default inside a node: 3x faster per rank, profiles/r02_notes.md), or all-to-all of k-min-mer records by key range (the north star's wording)")
+                    help="multi-GPU mode: exchange of sketch hashes + key-partitioned table (default inside a node: 3.5x faster per rank and fewer bytes than records up to ~10 ranks, DESIGN.md 3.4), or all-to-all of k-min-mer records by key range (the north star's wording)")
     ap.add_argument("--dist-impl", choices=["py", "c"], default="c",
                     help="multi-GPU driver: the library's own C layer (include/mdbg_dist.h: direct RCCL send/recv groups, the product boundary; default), or "
                          "rust_mdbg_amd/dist.py over torch.distributed (the Python harness of the same protocol; the only driver of --dist-mode route)")
@@ -339,8 +342,9 @@ def main():
             if sq:
                 roof.update(valu_util=sq.get("valu_util"), valu_lane_ops_per_base=sq.get("valu_lane_ops_per_base"), sq_source=sq.get("source"))
             if packed:
-                roof["note"] = ("b_in = 0.25 B/base (2-bit packed input, the north-star layout): the kernel is bound by integer VALU issue, not by HBM "
-                                "(valu_util, valu_lane_ops_per_base; traffic = 1.09x the algorithmic bytes); the same kernel on the b_in = 1.0 accounting is in roofline_ascii")
+                roof["note"] = ("b_in = 0.25 B/base (2-bit packed input, the north-star layout): the kernel is bound by instruction issue (integer VALU, LDS, scalar), "
+                                "not by HBM (valu_lane_ops_per_base%s); the same kernel on the b_in = 1.0 accounting is in roofline_ascii"
+                                % ("; traffic = %.2fx the algorithmic bytes" % (roof["traffic"] / roof["algorithmic_bytes_per_launch"]) if roof["traffic"] else ""))
         roof_ascii = None
         if packed and not routed:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
             for _ in range(2):
