@@ -38,6 +38,8 @@ struct SketchArgs {
     u32* n_valid;                // [n_tiles] number of minimizers whose l-mer ENDS in the tile
     u32* n_scan;                 // [n_tiles] slab slots the tile used when they are NOT all valid records (dense settings: rejected candidates
                                  // stay in the slab with read = 0xFFFFFFFF and the gather squeezes them out), else 0
+    u32* last_read;              // [n_tiles] read of the tile's last minimizer (LAST_NONE: the tile has none; LAST_IN_SLAB: look at the slab), so that
+                                 // the gather need not chase the slab in front of it (one more dependent round trip per tile)
     u32* over_max;               // <- largest n_valid that did not fit its slab (0: none; the host then retries with larger slabs)
     const u64* t4;               // (2 << 2*BS_GS) x u64: {F, R} per 3-base group (bs_make_table)
     const u8* tile_flags;        // FMT_PLANES: nonzero = an exception falls into the tile's staged range (null: none)
@@ -241,8 +243,10 @@ __device__ inline u32 lds_fetch_add(u32* p, u32 v) {
 __device__ inline void put_rec(const SketchArgs& a, Rec* slab, u32 rank, u64 hash, u32 pos, u32 read) {
     if (rank < a.slab_cap) { Rec r; r.hash = hash; r.pos = pos; r.read = read; slab[rank] = r; }
 }
-__device__ inline void put_count(const SketchArgs& a, u32 gt, u32 n) {
+constexpr u32 LAST_NONE = 0xFFFFFFFFu, LAST_IN_SLAB = 0xFFFFFFFEu;
+__device__ inline void put_count(const SketchArgs& a, u32 gt, u32 n, bool last_known = false) {
     a.n_valid[gt] = n;
+    if (a.last_read && !(last_known && n)) a.last_read[gt] = n ? LAST_IN_SLAB : LAST_NONE;
     if (a.n_scan) a.n_scan[gt] = 0;
     if (n > a.slab_cap) atomicMax(a.over_max, n);
 }
@@ -892,7 +896,11 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         const u32 left = count_words();
         MDBG_STAMP(5);
 #pragma unroll
-        for (int i = 0; i < NR; ++i) if ((keep_ok >> i) & 1u) put_rec(a, slab, rank_of(keep_e[i]), keep[i].hash, keep[i].pos, keep[i].read);
+        for (int i = 0; i < NR; ++i) if ((keep_ok >> i) & 1u) {
+            const u32 rank = rank_of(keep_e[i]);
+            put_rec(a, slab, rank, keep[i].hash, keep[i].pos, keep[i].read);
+            if (rank + 1 == left && a.last_read) a.last_read[gt] = keep[i].read;
+        }
         return left;
     };
 
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
     if (n_cand <= QCAP) {
         // every candidate sits in the (unordered) list of phase 3
         const u32 nv = n_cand ? process_list(n_cand) : 0;
-        if (tid == 0) { put_count(a, gt, nv); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; } }
+        if (tid == 0) { put_count(a, gt, nv, true); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; } }
     } else {
         // Dense settings (more candidates than the list holds).  The candidates are dealt out evenly by their rank in the bitmap — a
         // thread finds the word of its first one by binary search over the per-word counts and walks on from there —, evaluated once
@@ -934,6 +942,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         block_excl_scan_256(surv, S.misc, nv);
         if (tid == 0) {
             a.n_valid[gt] = nv; if (a.n_scan) a.n_scan[gt] = C;
+            if (a.last_read) a.last_read[gt] = nv ? LAST_IN_SLAB : LAST_NONE;
             if (C > a.slab_cap) atomicMax(a.over_max, C);
             if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; }
         }
@@ -996,6 +1005,7 @@ __global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* 
 // entry an earlier launch of the batch wrote; the wave of the batch's LAST tile also fills the entries behind the last record.
 struct GatherArgs {
     u32 tile0, n; const Rec* slab; u32 slab_cap; const u32* n_valid; const u32* n_scan; const u64* tile_base;      // n_scan: see SketchArgs (null: every slab is compact)
+    const u32* last_read;                                         // see SketchArgs (null: always look at the slabs)
     u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
     u64 m0; u32 slot0, n_reads; u64* off; u32 last_launch;        // m0: first store index of the batch
 };
@@ -1004,24 +1014,36 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
     const u32 b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= g.n) return;
     const u32 lane = threadIdx.x & 63;
+    // everything that depends on b alone is requested at once (the kernel is a chain of dependent round trips, 13 waves deep per SIMD):
+    // the counts, the base, the read in front, and the first 128 slots of the slab whatever they hold
+    const Rec* s = g.slab + (size_t)b * g.slab_cap;
     const u32 nv = g.n_valid[g.tile0 + b];
     const u32 ns = g.n_scan ? g.n_scan[g.tile0 + b] : 0u;
+    const u64 base = g.tile_base[b];
+    u32 lr = LAST_IN_SLAB;
+    if (g.last_read && b) lr = g.last_read[g.tile0 + b - 1];
+    Rec pre[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { pre[u] = Rec{}; if (64 * u + lane < g.slab_cap) pre[u] = s[64 * u + lane]; }
     const u32 slots = ns ? ns : nv;                                   // slab slots to look at (ns != 0: some hold rejected candidates)
     const bool tail = g.last_launch && b == g.n - 1;
     if ((!nv && !tail) || slots > g.slab_cap) return;
-    const Rec* s = g.slab + (size_t)b * g.slab_cap;
-    const u64 base = g.tile_base[b];
     int64_t prev = (int64_t)g.slot0 - 1;                              // read of the record in front of this tile's first
-    {
+    if (b && lr < LAST_IN_SLAB) prev = (int64_t)lr;
+    else {
         int64_t q = (int64_t)b - 1;
         while (q >= 0 && g.n_valid[g.tile0 + q] == 0) --q;
         if (q >= 0) {
-            const u32 cq = g.n_valid[g.tile0 + q], sq = g.n_scan ? g.n_scan[g.tile0 + q] : 0u;
-            int64_t j = (int64_t)(sq ? sq : cq) - 1;
-            if (j < (int64_t)g.slab_cap) {
-                const Rec* t = g.slab + (size_t)q * g.slab_cap;
-                while (j >= 0 && t[j].read == REC_REJECTED) --j;
-                if (j >= 0) prev = (int64_t)t[j].read;
+            const u32 lq = g.last_read ? g.last_read[g.tile0 + q] : LAST_IN_SLAB;
+            if (lq < LAST_IN_SLAB) prev = (int64_t)lq;
+            else {
+                const u32 cq = g.n_valid[g.tile0 + q], sq = g.n_scan ? g.n_scan[g.tile0 + q] : 0u;
+                int64_t j = (int64_t)(sq ? sq : cq) - 1;
+                if (j < (int64_t)g.slab_cap) {
+                    const Rec* t = g.slab + (size_t)q * g.slab_cap;
+                    while (j >= 0 && t[j].read == REC_REJECTED) --j;
+                    if (j >= 0) prev = (int64_t)t[j].read;
+                }
             }
         } else { const u64 b0 = g.tile_base[0]; if (b0 > g.m0 && b0 <= g.out_cap) prev = (int64_t)g.out_read[b0 - 1]; }
     }
@@ -1031,7 +1053,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
     for (u32 j0 = 0; j0 < slots; j0 += 64) {
         const u32 j = j0 + lane;
         Rec r{}; r.read = REC_REJECTED;
-        if (j < slots) r = s[j];
+        if (j < slots) r = j0 == 0 ? pre[0] : j0 == 64 ? pre[1] : s[j];
         const bool valid = r.read != REC_REJECTED;
         const u64 bal = __ballot(valid);
         const u64 lower = bal & ((1ull << lane) - 1ull);

@@ -83,6 +83,7 @@ struct TableArgs {
     u32 own_world, own_rank;      // replicated-sketch mode: insert only windows owned by own_rank (own_world <= 1: all)
     u32* probe_err;               // set when a probe sequence visited every slot: the table was sized from a wrong window count
     u64* own_inserted;            // sharded counter: owned windows actually inserted (checked against the senders' counts)
+    u32 exp;                      // diagnostic (MDBG_INSERT_EXP): parts of insert_windows_kernel switched off to time the rest (results are wrong)
 };
 
 // Home slot of a key hash: range reduction by multiplication, so the capacity need not be a power of two.  It is fed
@@ -139,6 +140,27 @@ __device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, b
         for (u32 j = 0; j < k; ++j) diff |= rp[j] ^ wl[cross ? k - 1 - j : j];
         return !diff;
     }
+    if (k >= 16) {
+        // sixteen values per round trip (eight 16-byte loads in flight): k = 35 takes three dependent rounds instead of five
+        for (u32 j = 0;; j += 16) {
+            if (j + 16 > k) j = k - 16;
+            u64x2_a8 a[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a[t] = *(const u64x2_a8*)(rp + j + 2 * t);
+            u64 diff = 0;
+            if (!cross) {
+                const u64* m = wl + j;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) diff |= (a[t].x ^ m[2 * t]) | (a[t].y ^ m[2 * t + 1]);
+            } else {
+                const u64* m = wl + (k - 16 - j);      // m[15-t] pairs with rp[j+t]
+#pragma unroll
+                for (int t = 0; t < 8; ++t) diff |= (a[t].x ^ m[15 - 2 * t]) | (a[t].y ^ m[14 - 2 * t]);
+            }
+            if (diff) return false;
+            if (j + 16 >= k) return true;
+        }
+    }
     for (u32 j = 0;; j += 8) {
         if (j + 8 > k) j = k - 8;
         const u64x2_a8 a0 = *(const u64x2_a8*)(rp + j), a1 = *(const u64x2_a8*)(rp + j + 2),
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
         const u32 li = u * 256 + threadIdx.x;
         const u64 i = b0 + li;
         bool mine = false;
-        if (i + k <= i1 && window_owner(sh_keys + li, k, T.own_world) == T.own_rank) {       // ownership first: it needs no further loads
+        if (i + k <= i1 && (T.own_world <= 1 || window_owner(sh_keys + li, k, T.own_world) == T.own_rank)) {       // ownership first: it needs no further loads
             const u32 slot = mread[i];
             const u64 rs = roff[slot], re = roff[slot + 1];
             mine = re - rs > k && i + k <= re;
@@ -211,12 +233,13 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
         const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
         const u64* w = sh_keys + li;
         const bool rev = window_reversed(w, k);
-        const u64 h = key_hash_window(w, k, rev);
+        const u64 h = (T.exp & 8u) ? fmix64(w[0] + 3 * w[k - 1] + 5 * w[k / 2]) : key_hash_window(w, k, rev);
+        if (T.exp & 16u) { if (h == 12345u) *cap_err = 1; continue; }
         bool claimed;
-        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return (T.exp & 1u) ? true : same_key_window(T.ks, word, w, rev); }, claimed);
         if (claimed || s == ~0ull) continue;
-        atomicAdd(&T.tab[s].count, 1u);
-        push_ordinal(T, s, ord);
+        if (!(T.exp & 4u)) atomicAdd(&T.tab[s].count, 1u);
+        if (!(T.exp & 2u)) push_ordinal(T, s, ord);
     }
 }
 
@@ -438,7 +461,10 @@ struct FinArgs {
     const Slot* tab; u64 cap; const u64* mx; u32 A; u32 casc; u32 k; u32 l;   // A: abundance filter; casc: ordinals tracked per slot (= A up to 8, else 1)
     const u64* mh; const u32* mpos; const u64* roff; const u32* mread; const u64* arena;
     BatchTab bt;
-    u64* solid_list; u64* solid_count;       // compact list of solid slots (fin_mark -> fin_emit)
+    u64* solid_list; u64* solid_count;       // compact list of solid slots (fin_mark -> fin_emit), any order
+    u64* solid_dense;                        // dense ordered index of each listed slot's first sighting (-> its row, fin_order_kernel)
+    const u64* order;                        // non-null: slot of the node in row q (fin_emit then writes its rows in order: whole lines instead of
+                                             // eleven scattered 2..8-byte stores per node)
     u64* o_row;                              // non-null: write node q at position q and its global row here (partitioned table)
     const u64* ath_override;                 // [Slot.pad - 1]: sighting whose metadata a node that wrapped its u16 abundance keeps (null: none)
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
@@ -495,42 +521,65 @@ __device__ inline SlotView slot_view(const Slot& e, u64 s, const u64* mx, u32 ca
     return v;
 }
 
+// FIN_SPT slots per thread, all requested before the first is looked at: the kernel is a chain of dependent round trips (slot -> read
+// offsets of the smallest ordinal -> bitmap atomic), and with one slot per thread its 9,700 workgroups went through it 19 deep
+constexpr int FIN_SPT = 4;
 __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
-    __shared__ u32 wcnt[16];
+    __shared__ u32 wcnt[16 * FIN_SPT];
     __shared__ u64 bbase;
-    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    bool occ = false, solid = false, wrapped = false;
-    if (s < F.cap) {
-        const Slot e = F.tab[s];
-        if (e.word != EMPTY) {
-            const u32 count = e.count + 1u;
-            occ = true; solid = F.A == 1 || (u16)count >= (u16)F.A; wrapped = count >= 65536u;          // as slot_view
+    const u64 s0 = (u64)blockIdx.x * (1024 * FIN_SPT) + threadIdx.x;
+    Slot e[FIN_SPT];
+#pragma unroll
+    for (int u = 0; u < FIN_SPT; ++u) { const u64 s = s0 + 1024ull * u; e[u].word = EMPTY; if (s < F.cap) e[u] = F.tab[s]; }
+    u32 n_occ = 0, n_wrapped = 0; bool solid[FIN_SPT]; u64 m[FIN_SPT], dense[FIN_SPT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int u = 0; u < FIN_SPT; ++u) {
+        solid[u] = false;
+        u64 D = 0;
+        if (e[u].word != EMPTY) {
+            const u32 count = e[u].count + 1u;
+            ++n_occ; solid[u] = F.A == 1 || (u16)count >= (u16)F.A; n_wrapped += count >= 65536u ? 1u : 0u;          // as slot_view
             // first sighting: the claimer's window or the smallest ordinal the others pushed.  Most keys are seen once (sequencing
             // errors), and the claimer's dense index follows from `rep` alone: no read map / offset lookups for them
-            u64 D;
-            if (e.word & (1ull << 33)) { u64 i; decode_ordinal(F, rep_ordinal(F, e.word) < e.m1 ? rep_ordinal(F, e.word) : e.m1, i, D); }   // routed record
+            if (e[u].word & (1ull << 33)) { u64 i; const u64 ro = rep_ordinal(F, e[u].word); decode_ordinal(F, ro < e[u].m1 ? ro : e[u].m1, i, D); }   // routed record
             else {
-                D = dense_of_index(F, (u32)e.word);
-                if (e.count) { u64 i, D1; decode_ordinal(F, e.m1, i, D1); if (D1 < D) D = D1; }
+                D = dense_of_index(F, (u32)e[u].word);
+                if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < D) D = D1; }
             }
             atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
-            if (solid) atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
+            if (solid[u]) atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
         }
+        dense[u] = D;
+        m[u] = __ballot(solid[u]);
+        if (lane == 0) wcnt[16 * u + wv] = (u32)__popcll(m[u]);
     }
-    wave_count_add(occ, F.sh_distinct);
-    wave_count_add(wrapped, F.sh_wrapped);
-    // compact list of solid slots: one allocation atomic per block
-    const u64 m = __ballot(solid);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wcnt[wv] = (u32)__popcll(m);
+    for (int d = 32; d; d >>= 1) { n_occ += __shfl_down(n_occ, d, 64); n_wrapped += __shfl_down(n_wrapped, d, 64); }
+    if (lane == 0) {
+        if (n_occ) atomicAdd((unsigned long long*)ctr_shard(F.sh_distinct), (unsigned long long)n_occ);
+        if (n_wrapped) atomicAdd((unsigned long long*)ctr_shard(F.sh_wrapped), (unsigned long long)n_wrapped);
+    }
+    // compact list of solid slots (any order): one allocation atomic per block
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 tot = 0;
-        for (int i = 0; i < 16; ++i) { const u32 c = wcnt[i]; wcnt[i] = tot; tot += c; }
+        for (int i = 0; i < 16 * FIN_SPT; ++i) { const u32 c = wcnt[i]; wcnt[i] = tot; tot += c; }
         bbase = tot ? atomicAdd((unsigned long long*)F.solid_count, (unsigned long long)tot) : 0;
     }
     __syncthreads();
-    if (solid) F.solid_list[bbase + wcnt[wv] + __popcll(m & ((1ull << lane) - 1))] = s;
+#pragma unroll
+    for (int u = 0; u < FIN_SPT; ++u)
+        if (solid[u]) {
+            const u64 j = bbase + wcnt[16 * u + wv] + __popcll(m[u] & ((1ull << lane) - 1));
+            F.solid_list[j] = s0 + 1024ull * u; F.solid_dense[j] = dense[u];
+        }
+}
+// row of every listed solid slot (rank of its first sighting among the solid ones) -> order[row] = slot
+__global__ __launch_bounds__(256) void fin_order_kernel(FinArgs F, u64 n_solid, u64* __restrict__ order) {
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_solid) return;
+    const u64 D = F.solid_dense[q];
+    order[F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & ((1ull << (D & 63)) - 1))] = F.solid_list[q];
 }
 
 // ---- nodes whose u16 abundance wrapped (src/main.rs:676-684) ------------------------------------------
@@ -715,7 +764,7 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
     const u64 q0 = (u64)blockIdx.x * 256, q = q0 + threadIdx.x;
     const u32 k = F.k;
     if (q < n_solid) {
-        const u64 s = F.solid_list[q];
+        const u64 s = F.order ? F.order[q] : F.solid_list[q];
         const Slot e = F.tab[s];
         const SlotView v = slot_view(e, s, F.mx, F.casc, F.A, rep_ordinal(F, e.word), F.ath_override);
         u64 i1, D; decode_ordinal(F, v.first, i1, D);
@@ -743,12 +792,19 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
     // the keys: one wavefront per node, lane j copies element j (contiguous on both sides, no index arithmetic per element)
     const u32 nodes = (u32)(n_solid - q0 < 256 ? n_solid - q0 : 256);
     const u32 lane = threadIdx.x & 63;
-    for (u32 g = threadIdx.x >> 6; g < nodes; g += 4) {
-        const u64 src = sh_src[g];
-        const u64 i = src & ~(1ull << 63);
-        const bool rev = (src >> 63) != 0;
-        u64* const dst = F.o_keys + sh_row[g] * k;
-        for (u32 j = lane; j < k; j += 64) dst[j] = F.mh[i + (rev ? k - 1 - j : j)];
+    // (EMIT_NB nodes per wave and round, loads before stores: one node at a time was one full round trip per node, 64 in a row per wave)
+    constexpr int EMIT_NB = 8;
+    for (u32 g0 = (threadIdx.x >> 6) * EMIT_NB; g0 < nodes; g0 += 4 * EMIT_NB) {
+        for (u32 j = lane; j < k; j += 64) {
+            u64 v[EMIT_NB];
+#pragma unroll
+            for (int u = 0; u < EMIT_NB; ++u) {
+                const u64 src = sh_src[g0 + u < nodes ? g0 + u : nodes - 1];
+                v[u] = F.mh[(src & ~(1ull << 63)) + ((src >> 63) ? k - 1 - j : j)];
+            }
+#pragma unroll
+            for (int u = 0; u < EMIT_NB; ++u) if (g0 + u < nodes) F.o_keys[sh_row[g0 + u] * k + j] = v[u];
+        }
     }
 }
 
@@ -958,8 +1014,11 @@ void launch_count_windows(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* o
     if (!n_reads) return;
     hipLaunchKernelGGL(count_windows_kernel, dim3((n_reads + 1023) / 1024), dim3(1024), 0, s, roff, slot0, n_reads, k, out);
 }
+void launch_fin_order(const FinArgs& F, u64 n_solid, u64* order, hipStream_t s) {
+    if (n_solid) hipLaunchKernelGGL(fin_order_kernel, dim3((unsigned)((n_solid + 255) / 256)), dim3(256), 0, s, F, n_solid, order);
+}
 void launch_fin_mark(const FinArgs& F, hipStream_t s) {
-    hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 1023) / 1024)), dim3(1024), 0, s, F);
+    hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 1024 * FIN_SPT - 1) / (1024 * FIN_SPT))), dim3(1024), 0, s, F);
 }
 void launch_wrap_list(Slot* tab, u64 cap, u32 A, bool all_solid, u64* w_jstar, u32* w_count, unsigned long long* counters, hipStream_t s) {
     hipLaunchKernelGGL(wrap_list_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, tab, cap, A, all_solid, w_jstar, w_count, counters);
