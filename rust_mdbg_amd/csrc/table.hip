@@ -948,6 +948,27 @@ __global__ __launch_bounds__(256) void sum_shards_kernel(const u64* __restrict__
     if (threadIdx.x == 0) out[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
+// What the host reads between the stages, in one launch: scalars[idx] = sum of one shard array, then all n scalars -> pinned host memory
+// (was: the sum kernel, a copy kernel and the runtime's staging of a pageable destination — three steps in front of every host decision)
+// host[n] = seq is written last (system-scope fence in between): the host polls that word instead of waiting for the queue's completion signal
+__global__ __launch_bounds__(256) void publish_scalars_kernel(const u64* __restrict__ shards, u64* __restrict__ scalars, u32 idx, u32 n, u64* __restrict__ host, u64 seq) {
+    __shared__ u64 ws[4];
+    u64 v = 0;
+    for (int i = threadIdx.x; i < CTR_SHARDS; i += 256) v += shards[i];
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const u64 sum = ws[0] + ws[1] + ws[2] + ws[3];
+    if (threadIdx.x == 0) scalars[idx] = sum;
+    if (threadIdx.x < n) __hip_atomic_store(host + threadIdx.x, threadIdx.x == idx ? sum : scalars[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host + n, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish_scalars(const u64* shards, u64* scalars, u32 idx, u32 n, u64* host, u64 seq, hipStream_t s) {
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(256), 0, s, shards, scalars, idx, n, host, seq);
+}
+
 // ---- host launchers -------------------------------------------------------------------------------
 void launch_sum_shards(const u64* shards, u32 n_arrays, u64* out, hipStream_t s) {
     hipLaunchKernelGGL(sum_shards_kernel, dim3(n_arrays), dim3(256), 0, s, shards, out);
