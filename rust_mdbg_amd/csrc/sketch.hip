@@ -688,7 +688,9 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         if (use_lut) lut[tid] = (u16)sync_hash32((u32)tid & smask, smask);
         __syncthreads();
         {
-            for (u32 look = 64;; look *= 4) {
+            // first look-back: l positions until every s-mer of the window comes from bases behind the start, and some windows to meet a unique
+            // minimum in (with s = 4 about nine windows in ten have one)
+            for (u32 look = (l + 16u + 31u) & ~31u;; look *= 4) {
                 const int32_t q0 = (int32_t)a0 - (int32_t)look;        // may lie in front of the stream: idle iterations
                 bool conv = false, restart = false, mine = false;      // conv: the machine's state equals the reference's; mine: I reached my stretch without it
                 u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, warm = 0, ta = 0, mvp = 0;
@@ -754,8 +756,8 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
                 if (!restart) break;
                 // somebody reached its stretch unconverged: everybody looks further back (rare); nothing further back in the staged stream: the
                 // tile takes the generic machine
-                if (mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 4096u)) S.misc[9] = 1;
-                if (__any((int)(mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 4096u)))) break;
+                if (mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 2048u)) S.misc[9] = 1;
+                if (__any((int)(mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 2048u)))) break;
             }
         }
         __syncthreads();
