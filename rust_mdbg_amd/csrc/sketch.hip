@@ -59,15 +59,7 @@ __device__ inline u32 find_read(const u64* __restrict__ off, u32 lo, u32 hi, u64
     return lo;
 }
 
-// bread[t] = read containing the first staged base of tile t (t <= n_tiles + 1, clamped to the batch)
-__global__ void bread_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bases, u32 n_entries, u32* __restrict__ bread) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_entries) return;
-    int64_t p = (int64_t)t * TILE_STRIDE - HALO_BASES;
-    if (p < 0) p = 0;
-    if ((u64)p >= n_bases) p = n_bases ? (int64_t)n_bases - 1 : 0;
-    bread[t] = find_read(off, 0, n_reads - 1, (u64)p);
-}
+// bread[t] = read containing the first staged base of tile t (t <= n_tiles + 1, clamped to the batch): written by tile_rec_kernel
 
 // What a tile needs to know about the reads it touches, prepared once per batch so that the tile kernel reads ONE record instead of
 // chasing bread[] -> offsets[]: the reads [rl, rh] that overlap the staged range and, when there are at most TREC_N of them, their
@@ -76,12 +68,33 @@ constexpr int TREC_N = 7;
 struct __attribute__((aligned(16))) TileRec { u32 rl, rh; int64_t start0; int32_t rel[TREC_N - 1]; int64_t first_base; };     // start0: read rl (may lie far in front); rel[i]: read rl+1+i;
                                                                                                                                  // first_base = offsets[0] (the tile kernel would otherwise chase it through a second scalar load before it can issue its loads)
 static_assert(sizeof(TileRec) == 48, "three 16-byte words");
-__global__ void tile_rec_kernel(const u64* __restrict__ off, const u32* __restrict__ bread, u32 n_tiles, TileRec* __restrict__ recs) {
+// bread[] and the records in ONE launch: thread t runs the searches for entries t and t + 2 side by side (two dependent chains of ~20
+// loads each in flight together; two kernels in a row were 10 + 6 us and a launch)
+// init: scalars the sketch starts from (three zeroed, one set), folded in here: one launch less in front of the tile kernel
+struct SketchInit { u64* zero[3]; u64* set_p; u64 set_v; };
+__global__ void tile_rec_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bases, u32 n_tiles, u32* __restrict__ bread, TileRec* __restrict__ recs, SketchInit init) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { for (int i = 0; i < 3; ++i) if (init.zero[i]) *init.zero[i] = 0; if (init.set_p) *init.set_p = init.set_v; }
+    if (t >= n_tiles + 2) return;
+    auto first_pos = [&](u32 e) -> u64 {
+        int64_t p = (int64_t)e * TILE_STRIDE - HALO_BASES;
+        if (p < 0) p = 0;
+        if ((u64)p >= n_bases) p = n_bases ? (int64_t)n_bases - 1 : 0;
+        return (u64)p;
+    };
+    const u64 p0 = first_pos(t), p2 = first_pos(t + 2);
+    u32 lo0 = 0, hi0 = n_reads - 1, lo2 = 0, hi2 = n_reads - 1;
+    while (lo0 < hi0 || lo2 < hi2) {
+        const u32 m0 = lo0 + ((hi0 - lo0 + 1) >> 1), m2 = lo2 + ((hi2 - lo2 + 1) >> 1);
+        const u64 v0 = off[m0], v2 = off[m2];
+        if (lo0 < hi0) { if (v0 <= p0) lo0 = m0; else hi0 = m0 - 1; }
+        if (lo2 < hi2) { if (v2 <= p2) lo2 = m2; else hi2 = m2 - 1; }
+    }
+    bread[t] = lo0;
     if (t >= n_tiles) return;
     const int64_t raw0 = (int64_t)t * TILE_STRIDE - HALO_BASES;
     TileRec r;
-    r.rl = bread[t]; r.rh = bread[t + 2];
+    r.rl = lo0; r.rh = lo2;
     r.start0 = (int64_t)off[r.rl] - raw0;
     for (int i = 0; i < TREC_N - 1; ++i) {
         int64_t v = r.rl + 1 + i <= r.rh ? (int64_t)off[r.rl + 1 + i] - raw0 : 0x7FFFFFFF;
@@ -988,14 +1001,27 @@ __global__ __launch_bounds__(256) void tile_scan_top_kernel(u32 n_blocks, u64* _
     }
     if (tid == 0) carry[0] = run;
 }
-__global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base) {
+// self_base: block_base holds the plain block sums (at most 256 blocks of 1024 tiles, no tile_scan_top launch): the workgroup adds up the
+// sums in front of its block itself (the gather's last wave then moves the running total on)
+__global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base,
+                                                              u32 self_base, const u64* __restrict__ carry) {
     __shared__ u32 tmp[8];
+    __shared__ u64 ws[4];
     const u32 i0 = blockIdx.x * 1024 + threadIdx.x * 4;
     u32 v[4], mine = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { v[q] = i0 + q < n ? n_valid[i0 + q] : 0u; mine += v[q]; }
+    u64 bb;
+    if (self_base) {
+        u64 x = threadIdx.x < blockIdx.x ? block_base[threadIdx.x] : 0ull;
+        for (int d = 32; d; d >>= 1) x += __shfl_down(x, d, 64);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = x;
+        __syncthreads();
+        bb = carry[0] + ws[0] + ws[1] + ws[2] + ws[3];
+    } else bb = block_base[blockIdx.x];
     u32 total;
-    u64 b = block_base[blockIdx.x] + block_excl_scan_256(mine, tmp, total);
+    u64 b = bb + block_excl_scan_256(mine, tmp, total);
+
 #pragma unroll
     for (int q = 0; q < 4; ++q) { if (i0 + q < n) tile_base[i0 + q] = b; b += v[q]; }
 }
@@ -1010,6 +1036,7 @@ struct GatherArgs {
     const u32* last_read;                                         // see SketchArgs (null: always look at the slabs)
     u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
     u64 m0; u32 slot0, n_reads; u64* off; u32 last_launch;        // m0: first store index of the batch
+    u64* carry;                                                   // non-null: <- running total behind this launch's last tile (the scan ran without tile_scan_top)
 };
 constexpr u32 REC_REJECTED = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
@@ -1029,6 +1056,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
     for (int u = 0; u < 2; ++u) { pre[u] = Rec{}; if (64 * u + lane < g.slab_cap) pre[u] = s[64 * u + lane]; }
     const u32 slots = ns ? ns : nv;                                   // slab slots to look at (ns != 0: some hold rejected candidates)
     const bool tail = g.last_launch && b == g.n - 1;
+    if (g.carry && b == g.n - 1 && lane == 0) *g.carry = base + nv;
     if ((!nv && !tail) || slots > g.slab_cap) return;
     int64_t prev = (int64_t)g.slot0 - 1;                              // read of the record in front of this tile's first
     if (b && lr < LAST_IN_SLAB) prev = (int64_t)lr;
@@ -1143,10 +1171,9 @@ void launch_pack_planes(const u8* bases, u64 n_bases, uint2* words, u64* exc_pos
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
-void launch_bread(const u64* offsets, u32 n_reads, u64 n_bases, u32 n_tiles, u32* bread, TileRec* recs, hipStream_t s) {
+void launch_bread(const u64* offsets, u32 n_reads, u64 n_bases, u32 n_tiles, u32* bread, TileRec* recs, const SketchInit& init, hipStream_t s) {
     const u32 n = n_tiles + 2;
-    hipLaunchKernelGGL(bread_kernel, dim3((n + 255) / 256), dim3(256), 0, s, offsets, n_reads, n_bases, n, bread);
-    hipLaunchKernelGGL(tile_rec_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, offsets, bread, n_tiles, recs);
+    hipLaunchKernelGGL(tile_rec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, offsets, n_reads, n_bases, n_tiles, bread, recs, init);
 }
 void launch_tile_flags(const u64* exc_pos, u32 n_exc, u32 n_tiles, u8* flags, hipStream_t s) {
     if (n_exc) hipLaunchKernelGGL(tile_flags_kernel, dim3((n_exc + 255) / 256), dim3(256), 0, s, exc_pos, n_exc, n_tiles, flags);
@@ -1190,9 +1217,10 @@ void launch_gather(const GatherArgs& g, u64* scan_tmp, u64* tile_base, u64* carr
     if (!g.n) return;
     const u32 n = g.n, nb = (n + 1023) / 1024;
     hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp);
-    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
-    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp, tile_base);
-    GatherArgs a = g; a.tile_base = tile_base;
+    const u32 self_base = nb <= 256 ? 1u : 0u;      // up to 262,144 tiles = 8.6 Gbases per launch: two scan launches instead of three
+    if (!self_base) hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
+    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp, tile_base, self_base, carry);
+    GatherArgs a = g; a.tile_base = tile_base; a.carry = self_base ? carry : nullptr;
     hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, a);
 }
 

@@ -404,9 +404,21 @@ void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u
 
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch
 // the insert speculatively and needs one round trip per batch instead of two.  Same rule as slots_for() in api.inc.
-__global__ void reserve_check_kernel(const u64* __restrict__ n_distinct, const u64* __restrict__ batch_windows, u64 cap, u32* __restrict__ too_small) {
-    const u64 n = *n_distinct + *batch_windows;
-    *too_small = n + n / 2 + 1024 > cap ? 1u : 0u;
+// The number of keys in the table is summed from its shards here (one launch less in front of every insertion).
+__global__ __launch_bounds__(256) void reserve_check_kernel(const u64* __restrict__ distinct_shards, u64* __restrict__ n_distinct, const u64* __restrict__ batch_windows, u64 cap,
+                                                            u32* __restrict__ too_small) {
+    __shared__ u64 ws[4];
+    u64 v = 0;
+    for (int i = threadIdx.x; i < CTR_SHARDS; i += 256) v += distinct_shards[i];
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 nd = ws[0] + ws[1] + ws[2] + ws[3];
+        *n_distinct = nd;
+        const u64 n = nd + *batch_windows;
+        *too_small = n + n / 2 + 1024 > cap ? 1u : 0u;
+    }
 }
 
 // routed records (k canonical u64, ordinal, key hash) sitting in the arena at record index r0..
@@ -872,18 +884,21 @@ void launch_pos_scatter(const u64* idx, const uint4* ans, u64 n, u32 k, u32* mpo
     if (n) hipLaunchKernelGGL(pos_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx, ans, n, k, mpos);
 }
 
-// exclusive prefix of popcounts over 64-bit words: pre[w] = sum_{v<w} popc(bm[v]); three kernels
-__global__ __launch_bounds__(1024) void popc_block_kernel(const u64* __restrict__ bm, u64 n_words, u32* __restrict__ block_sum) {
-    __shared__ u32 ws[16];
+// exclusive prefix of popcounts over 64-bit words, for the two finalize bitmaps at once: pre[w] = sum_{v<w} popc(bm[v]).  Block sums, scan
+// of the block sums, per-word prefix — and with at most 1024 blocks (64 M bits) the last kernel adds up the sums in front of its block
+// itself: two launches for both bitmaps where there were six (small kernels in a row cost ~5 us each on the device, more on the host)
+__global__ __launch_bounds__(1024) void popc_block_kernel(const u64* __restrict__ bm0, const u64* __restrict__ bm1, u64 n_words, u32* __restrict__ block_sum, u32 n_blocks) {
+    __shared__ u32 ws[2][16];
     const u64 w = (u64)blockIdx.x * 1024 + threadIdx.x;
-    u32 v = w < n_words ? __popcll(bm[w]) : 0;
-    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    u32 v0 = w < n_words ? __popcll(bm0[w]) : 0, v1 = w < n_words ? __popcll(bm1[w]) : 0;
+    for (int d = 32; d; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = v0; ws[1][threadIdx.x >> 6] = v1; }
     __syncthreads();
-    if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < 16; ++i) t += ws[i]; block_sum[blockIdx.x] = t; }
+    if (threadIdx.x < 2) { u32 t = 0; for (int i = 0; i < 16; ++i) t += ws[threadIdx.x][i]; block_sum[threadIdx.x * n_blocks + blockIdx.x] = t; }
 }
-__global__ __launch_bounds__(1024) void popc_scan_blocks_kernel(u32* __restrict__ block_sum, u32 n_blocks) {
+__global__ __launch_bounds__(1024) void popc_scan_blocks_kernel(u32* __restrict__ block_sum_all, u32 n_blocks) {
     __shared__ u32 ws[16]; __shared__ u32 run;
+    u32* const block_sum = block_sum_all + (size_t)blockIdx.x * n_blocks;        // one workgroup per bitmap
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) run = 0;
     __syncthreads();
@@ -901,17 +916,27 @@ __global__ __launch_bounds__(1024) void popc_scan_blocks_kernel(u32* __restrict_
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(1024) void popc_prefix_kernel(const u64* __restrict__ bm, u64 n_words, const u32* __restrict__ block_base, u32* __restrict__ pre) {
-    __shared__ u32 ws[16];
+// self_base: block_sum holds the plain sums (no scan kernel ran; n_blocks <= 1024)
+__global__ __launch_bounds__(1024) void popc_prefix_kernel(const u64* __restrict__ bm0, const u64* __restrict__ bm1, u64 n_words, const u32* __restrict__ block_sum, u32 n_blocks,
+                                                           u32 self_base, u32* __restrict__ pre0, u32* __restrict__ pre1) {
+    __shared__ u32 ws[2][16], bs[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 w = (u64)blockIdx.x * 1024 + tid;
-    const u32 v = w < n_words ? __popcll(bm[w]) : 0;
-    const u32 inc = wave_incl_scan(v);
-    if (lane == 63) ws[wv] = inc;
+    const u32 v0 = w < n_words ? __popcll(bm0[w]) : 0, v1 = w < n_words ? __popcll(bm1[w]) : 0;
+    const u32 i0 = wave_incl_scan(v0), i1 = wave_incl_scan(v1);
+    u32 s0 = 0, s1 = 0;
+    if (self_base) {
+        if ((u32)tid < blockIdx.x) { s0 = block_sum[tid]; s1 = block_sum[n_blocks + tid]; }
+        for (int d = 32; d; d >>= 1) { s0 += __shfl_down(s0, d, 64); s1 += __shfl_down(s1, d, 64); }
+    }
+    if (lane == 63) { ws[0][wv] = i0; ws[1][wv] = i1; }
+    if (lane == 0) { bs[0][wv] = s0; bs[1][wv] = s1; }
     __syncthreads();
-    u32 b = block_base[blockIdx.x];
-    for (int q = 0; q < wv; ++q) b += ws[q];
-    if (w < n_words) pre[w] = b + inc - v;
+    u32 b0, b1;
+    if (self_base) { b0 = 0; b1 = 0; for (int q = 0; q < 16; ++q) { b0 += bs[0][q]; b1 += bs[1][q]; } }
+    else { b0 = block_sum[blockIdx.x]; b1 = block_sum[n_blocks + blockIdx.x]; }
+    for (int q = 0; q < wv; ++q) { b0 += ws[0][q]; b1 += ws[1][q]; }
+    if (w < n_words) { pre0[w] = b0 + i0 - v0; pre1[w] = b1 + i1 - v1; }
 }
 
 // imported sketches: mread[i] = slot of the read minimizer i belongs to (one wave per read)
@@ -948,25 +973,31 @@ __global__ __launch_bounds__(256) void sum_shards_kernel(const u64* __restrict__
     if (threadIdx.x == 0) out[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// What the host reads between the stages, in one launch: scalars[idx] = sum of one shard array, then all n scalars -> pinned host memory
-// (was: the sum kernel, a copy kernel and the runtime's staging of a pageable destination — three steps in front of every host decision)
+// What the host reads between the stages, in one launch: scalars[idx[j]] = sum of shard array j (up to three), then all n scalars -> pinned
+// host memory (was: the sum kernels, a copy kernel and the runtime's staging of a pageable destination in front of every host decision).
 // host[n] = seq is written last (system-scope fence in between): the host polls that word instead of waiting for the queue's completion signal
-__global__ __launch_bounds__(256) void publish_scalars_kernel(const u64* __restrict__ shards, u64* __restrict__ scalars, u32 idx, u32 n, u64* __restrict__ host, u64 seq) {
-    __shared__ u64 ws[4];
-    u64 v = 0;
-    for (int i = threadIdx.x; i < CTR_SHARDS; i += 256) v += shards[i];
-    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+struct PublishArgs { const u64* shards[3]; u32 idx[3]; u32 n_arrays; u64* scalars; u32 n; u32 zero_idx; u64* host; u64 seq; };      // zero_idx: scalar reset once it has been published (>= n: none)
+__global__ __launch_bounds__(256) void publish_scalars_kernel(PublishArgs p) {
+    __shared__ u64 ws[3][4];
+    for (u32 j = 0; j < p.n_arrays; ++j) {
+        u64 v = 0;
+        for (int i = threadIdx.x; i < CTR_SHARDS; i += 256) v += p.shards[j][i];
+        for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+        if ((threadIdx.x & 63) == 0) ws[j][threadIdx.x >> 6] = v;
+    }
     __syncthreads();
-    const u64 sum = ws[0] + ws[1] + ws[2] + ws[3];
-    if (threadIdx.x == 0) scalars[idx] = sum;
-    if (threadIdx.x < n) __hip_atomic_store(host + threadIdx.x, threadIdx.x == idx ? sum : scalars[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < p.n) {
+        u64 v = p.scalars[threadIdx.x];
+        for (u32 j = 0; j < p.n_arrays; ++j) if (threadIdx.x == p.idx[j]) { v = ws[j][0] + ws[j][1] + ws[j][2] + ws[j][3]; p.scalars[threadIdx.x] = v; }
+        __hip_atomic_store(p.host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == p.zero_idx) p.scalars[threadIdx.x] = 0;
+    }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(host + n, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(p.host + p.n, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void launch_publish_scalars(const u64* shards, u64* scalars, u32 idx, u32 n, u64* host, u64 seq, hipStream_t s) {
-    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(256), 0, s, shards, scalars, idx, n, host, seq);
+void launch_publish_scalars(const PublishArgs& p, hipStream_t s) {
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(256), 0, s, p);
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
@@ -999,8 +1030,8 @@ void launch_zero_regions(const ZeroList& z, hipStream_t s) {
     const unsigned blocks = (unsigned)std::min<u64>(1024, (mx + 255) / 256);
     hipLaunchKernelGGL(zero_regions_kernel, dim3(blocks), dim3(256), 0, s, z);
 }
-void launch_reserve_check(const u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s) {
-    hipLaunchKernelGGL(reserve_check_kernel, dim3(1), dim3(1), 0, s, n_distinct, batch_windows, cap, too_small);
+void launch_reserve_check(const u64* distinct_shards, u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s) {
+    hipLaunchKernelGGL(reserve_check_kernel, dim3(1), dim3(256), 0, s, distinct_shards, n_distinct, batch_windows, cap, too_small);
 }
 void launch_insert_records(const TableArgs& T, u64 r0, u64 r1, u64* n_windows, hipStream_t s) {
     if (r1 <= r0) return;
@@ -1009,12 +1040,14 @@ void launch_insert_records(const TableArgs& T, u64 r0, u64 r1, u64* n_windows, h
 void launch_rehash(const Slot* old, u64 old_cap, const u64* old_mx, const TableArgs& T, hipStream_t s) {
     hipLaunchKernelGGL(rehash_kernel, dim3((unsigned)((old_cap + 255) / 256)), dim3(256), 0, s, old, old_cap, old_mx, T);
 }
-void launch_popc_prefix(const u64* bm, u64 n_words, u32* block_tmp, u32* pre, hipStream_t s) {
+// block_tmp: 2 * ceil(n_words / 1024) u32
+void launch_popc_prefix2(const u64* bm0, const u64* bm1, u64 n_words, u32* block_tmp, u32* pre0, u32* pre1, hipStream_t s) {
     if (!n_words) return;
     const u32 nb = (u32)((n_words + 1023) / 1024);
-    hipLaunchKernelGGL(popc_block_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp);
-    hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_tmp, nb);
-    hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm, n_words, block_tmp, pre);
+    const u32 self_base = nb <= 1024 ? 1u : 0u;
+    hipLaunchKernelGGL(popc_block_kernel, dim3(nb), dim3(1024), 0, s, bm0, bm1, n_words, block_tmp, nb);
+    if (!self_base) hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(2), dim3(1024), 0, s, block_tmp, nb);
+    hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm0, bm1, n_words, block_tmp, nb, self_base, pre0, pre1);
 }
 void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32 rank, u64* out_shards, hipStream_t s) {
     if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, rank, out_shards);
