@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--dist-impl", choices=["py", "c"], default="c",
                     help="multi-GPU driver: the library's own C layer (include/mdbg_dist.h: direct RCCL send/recv groups, the product boundary; default), or "
                          "rust_mdbg_amd/dist.py over torch.distributed (the Python harness of the same protocol; the only driver of --dist-mode route)")
+    ap.add_argument("--dist-exchange", choices=["segments", "whole"], default="segments",
+                    help="C layer: what a round ships to a peer: its window list + only the hashes those windows need (default), or every sketch entire (mdbg_dist_set_exchange)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="multi-GPU: chunks per step; the exchange of chunk c overlaps the sketch of chunk c+1 (0 = 4 in replicate mode, 1 in route mode)")
     ap.add_argument("--profile-dist", action="store_true", help="print a per-stage wall-time breakdown of the routed path to stderr (adds syncs)")
@@ -228,6 +230,7 @@ def main():
         cdist = dist_c.DistMdbg(args.k, args.l, args.density, args.minabund, rank, world, dist, device=local_rank)
         n_chunks = args.chunks if args.chunks > 0 else 4
         cdist.set_pipeline(n_chunks)          # the exchange of chunk i overlaps the tile kernel of chunk i+1 (mdbg_dist_set_pipeline)
+        cdist.set_exchange(args.dist_exchange == "whole")
     if routed and cdist is None:
         from rust_mdbg_amd import dist as D
         dev = torch.device("cuda", local_rank)

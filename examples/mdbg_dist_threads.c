@@ -75,7 +75,7 @@ static int t_allreduce(void* self, uint64_t* d_buf, uint64_t n) {
 /* ---- one rank -------------------------------------------------------------------------------------------------------------- */
 typedef struct part_t { uint64_t n, n_global, n_distinct; uint64_t* keys; uint32_t* index; uint16_t* abundance; uint32_t* seqlen; uint64_t* src_read; uint64_t* row;
                         uint64_t* src_start; uint64_t* src_end; uint64_t* shift_full; } part_t;
-typedef struct job_t { rank_t rk; mdbg_params P; uint64_t reads_per_rank, genome; int rounds, packed, chunks; part_t out; } job_t;
+typedef struct job_t { rank_t rk; mdbg_params P; uint64_t reads_per_rank, genome; int rounds, packed, chunks, whole, reset_rc; uint64_t bytes_in; part_t out; } job_t;
 
 static void fetch(mdbg_ctx* c, void* dst, const void* src, uint64_t bytes) { if (bytes) CHECK(mdbg_copy_to_host(c, dst, src, bytes)); }
 
@@ -88,6 +88,7 @@ static void* rank_main(void* arg) {
     mdbg_dist* d = mdbg_dist_create(&j->P, &comm, &err);
     if (!d) { fprintf(stderr, "mdbg_dist_create: %d\n", err); exit(2); }
     if (j->chunks > 1) CHECK(mdbg_dist_set_pipeline(d, (uint32_t)j->chunks));      /* every ingest call below is cut into that many rounds */
+    if (j->whole) CHECK(mdbg_dist_set_exchange(d, MDBG_EXCHANGE_WHOLE));            /* default: segments (only the hashes a peer's windows need) */
     mdbg_ctx* c = mdbg_dist_ctx(d);
     w->ctx[j->rk.rank] = c;
     pthread_barrier_wait(&w->bar);
@@ -123,12 +124,16 @@ static void* rank_main(void* arg) {
     CHECK(mdbg_dist_finalize(d, &nd, &d_row, &ng));
     part_t* o = &j->out;
     o->n = nd.n; o->n_global = ng; o->n_distinct = nd.n_distinct;
+    CHECK(mdbg_dist_traffic(d, &j->bytes_in, NULL, NULL));
     o->keys = (uint64_t*)malloc((nd.n * nd.k + 1) * 8); o->index = (uint32_t*)malloc((nd.n + 1) * 4); o->abundance = (uint16_t*)malloc((nd.n + 1) * 2);
     o->seqlen = (uint32_t*)malloc((nd.n + 1) * 4); o->src_read = (uint64_t*)malloc((nd.n + 1) * 8); o->row = (uint64_t*)malloc((nd.n + 1) * 8);
     o->src_start = (uint64_t*)malloc((nd.n + 1) * 8); o->src_end = (uint64_t*)malloc((nd.n + 1) * 8); o->shift_full = (uint64_t*)malloc((nd.n + 1) * 16);
     fetch(c, o->src_start, nd.src_start, nd.n * 8); fetch(c, o->src_end, nd.src_end, nd.n * 8); fetch(c, o->shift_full, nd.shift_full, nd.n * 16);
     fetch(c, o->keys, nd.keys, nd.n * nd.k * 8); fetch(c, o->index, nd.index, nd.n * 4); fetch(c, o->abundance, nd.abundance, nd.n * 2);
     fetch(c, o->seqlen, nd.seqlen, nd.n * 4); fetch(c, o->src_read, nd.src_read, nd.n * 8); fetch(c, o->row, d_row, nd.n * 8);
+    pthread_barrier_wait(&w->bar);
+    /* another k on the resident sketches: possible after a whole-sketch exchange, refused (nothing is changed) after segments, which hold only this k's windows */
+    j->reset_rc = mdbg_dist_reset(d, j->P.k + 2);
     pthread_barrier_wait(&w->bar);
     mdbg_destroy(gen);
     mdbg_dist_destroy(d);
@@ -141,6 +146,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 3 ? atoi(argv[3]) : 2;
     const int packed = argc > 4 ? atoi(argv[4]) : 0;
     const int chunks = argc > 5 ? atoi(argv[5]) : 1;          /* > 1: mdbg_dist_set_pipeline */
+    const int whole = argc > 6 ? atoi(argv[6]) : 0;           /* 1: MDBG_EXCHANGE_WHOLE */
     if (chunks < 1 || chunks > 64) { fprintf(stderr, "bad arguments\n"); return 1; }
     if (W < 1 || W > MAXW || rounds < 1 || rpr % (uint64_t)rounds) { fprintf(stderr, "bad arguments\n"); return 1; }
     mdbg_params P; memset(&P, 0, sizeof P);
@@ -150,7 +156,7 @@ int main(int argc, char** argv) {
     job_t* jobs = (job_t*)calloc(W, sizeof(job_t));
     pthread_t th[MAXW];
     const uint64_t genome = 150000;
-    for (uint32_t r = 0; r < W; ++r) { jobs[r].rk.w = &w; jobs[r].rk.rank = r; jobs[r].P = P; jobs[r].reads_per_rank = rpr; jobs[r].genome = genome; jobs[r].rounds = rounds; jobs[r].packed = packed; jobs[r].chunks = chunks; }
+    for (uint32_t r = 0; r < W; ++r) { jobs[r].rk.w = &w; jobs[r].rk.rank = r; jobs[r].P = P; jobs[r].reads_per_rank = rpr; jobs[r].genome = genome; jobs[r].rounds = rounds; jobs[r].packed = packed; jobs[r].chunks = chunks; jobs[r].whole = whole; }
     for (uint32_t r = 0; r < W; ++r) pthread_create(&th[r], NULL, rank_main, &jobs[r]);
     for (uint32_t r = 0; r < W; ++r) pthread_join(th[r], NULL);
 
@@ -188,6 +194,8 @@ int main(int argc, char** argv) {
     printf("world %u, %llu reads per rank in %d rounds (x %d pipelined chunks), %s input: %llu nodes (%llu distinct k-min-mers); partitions", W, (unsigned long long)rpr, rounds, chunks,
            packed ? "packed" : "ASCII", (unsigned long long)ref.n, (unsigned long long)ref.n_distinct);
     for (uint32_t r = 0; r < W; ++r) printf(" %llu", (unsigned long long)jobs[r].out.n);
+    { uint64_t bi = 0; for (uint32_t r = 0; r < W; ++r) bi += jobs[r].bytes_in; printf("; %s exchange, bytes received by all ranks: %llu", whole ? "whole-sketch" : "segment", (unsigned long long)bi); }
+    { int same = 1; for (uint32_t r = 1; r < W; ++r) same = same && jobs[r].reset_rc == jobs[0].reset_rc; printf("; reset(k + 2): %d%s", jobs[0].reset_rc, same ? "" : " (ranks differ)"); }
     printf(" -> %s\n", ok ? "EQUAL to the single-context table" : "MISMATCH");
     mdbg_destroy(one); mdbg_destroy(gen);
     return ok ? 0 : 4;

@@ -72,6 +72,17 @@ mdbg_ctx* mdbg_dist_ctx(mdbg_dist* d);
  * round in about the time the sketch kernel needs for it, so this hides most of the exchange.  Default 1 (no cutting); 1..64. */
 int mdbg_dist_set_pipeline(mdbg_dist* d, uint32_t chunks);
 
+/* What a round ships to the peers (the same value on every rank; not while a round is in flight):
+ * MDBG_EXCHANGE_SEGMENTS (default): per peer the list of the windows it owns (8 bytes each) and ONLY the hashes those windows need.  A
+ *   k-min-mer is owned by the rank its smallest minimizer hash maps to; consecutive windows of a read share that hash for about (k + 1) / 2
+ *   steps, so a rank's windows come in runs and a run of r windows needs r + k - 1 hashes: a few hashes per window, and a volume per rank
+ *   that does not grow with the number of ranks.  The foreign sketches are then resident only where this k needs them:
+ *   mdbg_dist_reset(d, new_k != k) returns MDBG_E_STATE.
+ * MDBG_EXCHANGE_WHOLE: every rank receives every sketch entire (8 bytes per minimizer and peer: what round 2 did); needed for re-windowing
+ *   the resident global sketch at another k without a new exchange. */
+enum { MDBG_EXCHANGE_SEGMENTS = 0, MDBG_EXCHANGE_WHOLE = 1 };
+int mdbg_dist_set_exchange(mdbg_dist* d, uint32_t mode);
+
 /* One round: sketch this rank's batch (DEVICE buffers, as mdbg_ingest_batch_device / mdbg_ingest_batch_packed_device), exchange
  * sketches and window lists with every peer, insert the windows this rank owns.  first_read_ordinal is GLOBAL (position of the
  * batch's first record in the whole input), ordinal ranges of different ranks and rounds must not overlap. */
@@ -84,7 +95,7 @@ int mdbg_dist_ingest_batch_packed_device(mdbg_dist* d, const mdbg_packed_batch* 
  * single-GPU table; out->index holds the GLOBAL DbgEntry.index; out->n_distinct and *n_nodes_global are totals over all ranks. */
 int mdbg_dist_finalize(mdbg_dist* d, mdbg_nodes* out, const uint64_t** d_row, uint64_t* n_nodes_global);
 /* new_k = 0: drop everything; else re-window the resident GLOBAL sketch with new_k (no exchange needed: every rank holds the hashes;
- * the positions the new nodes need are fetched at the next finalize). */
+ * the positions the new nodes need are fetched at the next finalize) — MDBG_EXCHANGE_WHOLE only, see mdbg_dist_set_exchange. */
 int mdbg_dist_reset(mdbg_dist* d, uint32_t new_k);
 
 /* Bytes this rank has received / sent through the communicator's `exchange` since mdbg_dist_create or the last mdbg_dist_reset(d, 0)

@@ -1213,6 +1213,14 @@ void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_b
 }
 
 // scan + gather of the tiles [tile0, tile0 + n) of one launch; carry[0] in/out = running total of minimizers
+// out[i] = carry[0] + sum of v[0 .. i) (n values; scan_tmp: n / 1024 + 2 u64); carry[0] <- carry[0] + total
+void launch_excl_scan_u32(const u32* v, u32 n, u64* scan_tmp, u64* out, u64* carry, hipStream_t s) {
+    if (!n) return;
+    const u32 nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(256), 0, s, n, v, scan_tmp);
+    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
+    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, v, scan_tmp, out, 0u, carry);
+}
 void launch_gather(const GatherArgs& g, u64* scan_tmp, u64* tile_base, u64* carry, hipStream_t s) {
     if (!g.n) return;
     const u32 n = g.n, nb = (n + 1023) / 1024;

@@ -81,6 +81,7 @@ struct TableArgs {
     u64* n_distinct;              // device counter
     KeySrc ks;
     u32 own_world, own_rank;      // replicated-sketch mode: insert only windows owned by own_rank (own_world <= 1: all)
+    double own_inv_bound;         // see OwnerSpec
     u32* probe_err;               // set when a probe sequence visited every slot: the table was sized from a wrong window count
     u64* own_inserted;            // sharded counter: owned windows actually inserted (checked against the senders' counts)
     u32 exp;                      // diagnostic (MDBG_INSERT_EXP): parts of insert_windows_kernel switched off to time the rest (results are wrong)
@@ -178,11 +179,31 @@ __device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, b
     }
 }
 
-// Owner of a k-min-mer in the replicated-sketch multi-GPU mode: an O(1) function of the canonical key (both ends and the
-// middle are invariant under reversal as unordered sets), so every rank can decide ownership of every window cheaply.
-__device__ inline u32 window_owner(const u64* __restrict__ w, u32 k, u32 world) {
-    const u64 x = w[0] + w[k - 1] + w[(k - 1) >> 1] + w[k >> 1];
-    return (u32)__umul64hi(fmix64(x), (u64)world);
+// Owner of a k-min-mer in the replicated-sketch multi-GPU mode: a function of the SMALLEST of its k minimizer hashes (the same for the key
+// and its reverse).  Consecutive windows of a read share their smallest hash for (k + 1) / 2 steps on average, so a rank's windows come in
+// runs: a run of r windows needs r + k - 1 hashes of the read and nothing else of it, which is what the sketching rank ships to the owner
+// (mdbg_dist, "segments") — a few hashes per window instead of the whole sketch to every rank.  (Round 2 hashed both ends and the middle: an
+// O(1) function, but neighbouring windows went to unrelated ranks and every rank needed every hash.)
+// The smallest of k values that are uniform on [0, bound] (the selected minimizers' hashes) has the distribution function
+// 1 - (1 - v / bound)^k, and a minimizer that is small is the smallest of MANY windows: hashing the value to a rank left one of eight
+// ranks with 43 % more nodes than the mean (l = 12: the few hundred smallest l-mer hashes carry most windows).  Cutting [0, 1) of that
+// distribution function into `world` equal parts gives every rank the same expected share whatever the weights: 1.05 instead of 1.43.
+struct OwnerSpec { u32 world; double inv_bound; };      // inv_bound = 1 / hash bound of the sketch (0: unknown, fall back to hashing the value)
+__device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os);
+__device__ inline u32 window_owner(const u64* __restrict__ w, u32 k, OwnerSpec os) {
+    if (os.world <= 1) return 0;
+    u64 m = w[0];
+    for (u32 j = 1; j < k; ++j) { const u64 x = w[j]; m = x < m ? x : m; }
+    return owner_of_min(m, k, os);
+}
+__device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os) {
+    if (os.world <= 1) return 0;
+    if (!(os.inv_bound > 0.0)) return (u32)__umul64hi(fmix64(m), (u64)os.world);
+    double x = (double)m * os.inv_bound;
+    x = x < 1.0 ? x : 1.0;
+    const double cdf = 1.0 - exp((double)k * log1p(-x * (1.0 - 1e-12)));
+    const u32 o = (u32)(cdf * (double)os.world);
+    return o < os.world ? o : os.world - 1;
 }
 
 // Windows of the minimizers [i0, i1) of a batch -> counting table.  src/main.rs:756 — only reads with MORE than k minimizers contribute,
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
         const u32 li = u * 256 + threadIdx.x;
         const u64 i = b0 + li;
         bool mine = false;
-        if (i + k <= i1 && (T.own_world <= 1 || window_owner(sh_keys + li, k, T.own_world) == T.own_rank)) {       // ownership first: it needs no further loads
+        if (i + k <= i1 && (T.own_world <= 1 || window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_inv_bound}) == T.own_rank)) {       // ownership first: it needs no further loads
             const u32 slot = mread[i];
             const u64 rs = roff[slot], re = roff[slot + 1];
             mine = re - rs > k && i + k <= re;
@@ -258,39 +279,121 @@ __device__ inline bool window_starts_at(const u32* __restrict__ mread, const u64
     const u64 rs = roff[slot], re = roff[slot + 1];
     return re - rs > k && i + k <= re;
 }
+// The count pass also leaves every window start's owner in owner_of[] (0xFF: no window starts there) for the write pass.  The smallest hash
+// of all the span's windows comes from LDS: the span's hashes are staged once and reduced by doubling (min over 2, 4, ... p <= k values; a
+// window of k is two overlapping stretches of p) — read from HBM window by window it was 35 loads each, 1.4 ms per 6.6 M windows.
+constexpr u32 OWNL_LDS_MAX_K = 1024;          // longer k: the plain loop (2 x (OWNL_SPAN + k) values have to fit the default 64 KB of dynamic LDS)
 __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                               u32 k, u32 world, u32* __restrict__ blk_cnt) {
+                                                               u32 k, u32 world, double inv_bound, u32* __restrict__ blk_cnt, u8* __restrict__ owner_of) {
+    extern __shared__ u64 sh_min[];               // two buffers of OWNL_SPAN + k - 1 values (k <= OWNL_LDS_MAX_K)
     __shared__ u32 hist[OWNL_MAX_WORLD];
     if (threadIdx.x < world) hist[threadIdx.x] = 0;
-    __syncthreads();
     const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
+    const bool staged = k <= OWNL_LDS_MAX_K;
+    const u32 nv = OWNL_SPAN + k - 1;
+    const u64* cur = sh_min; u32 p = 1;
+    if (staged) {
+        u64* a = sh_min; u64* b = sh_min + nv;
+        for (u32 t = threadIdx.x; t < nv; t += 256) a[t] = b0 + t < i1 ? mh[b0 + t] : ~0ull;
+        __syncthreads();
+        for (; 2 * p <= k; p *= 2) {
+            for (u32 t = threadIdx.x; t < nv; t += 256) { const u64 x = a[t], y = t + p < nv ? a[t + p] : ~0ull; b[t] = x < y ? x : y; }
+            __syncthreads();
+            u64* const sw = a; a = b; b = sw;
+        }
+        cur = a;
+    } else __syncthreads();
+    const OwnerSpec os{world, inv_bound};
 #pragma unroll
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
-        const u64 i = b0 + u * 256 + threadIdx.x;
-        if (window_starts_at(mread, roff, i, i1, k)) atomicAdd(&hist[window_owner(mh + i, k, world)], 1u);
+        const u32 li = u * 256 + threadIdx.x;
+        const u64 i = b0 + li;
+        u32 o = 0xFFu;
+        if (window_starts_at(mread, roff, i, i1, k)) {
+            if (staged) { const u64 x = cur[li], y = cur[li + k - p]; o = owner_of_min(x < y ? x : y, k, os); }
+            else o = window_owner(mh + i, k, os);
+            atomicAdd(&hist[o], 1u);
+        }
+        if (i < i1) owner_of[i - i0] = (u8)o;
     }
     __syncthreads();
     if (threadIdx.x < world) blk_cnt[(size_t)blockIdx.x * world + threadIdx.x] = hist[threadIdx.x];
 }
+// Every owner's bucket comes out sorted by window start (the segments below are differences of neighbouring entries): the entries of a
+// workgroup's span are ranked per owner in index order — lanes of a wave by ballots, the 32 (iteration, wave) groups by a prefix in LDS.
 __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                               u32 k, u32 world, u32 slot0, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list) {
-    __shared__ u32 lcnt[OWNL_MAX_WORLD];
-    if (threadIdx.x < world) lcnt[threadIdx.x] = 0;
+                                                               u32 k, u32 world, double inv_bound, u32 slot0, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list,
+                                                               const u8* __restrict__ owner_of) {
+    constexpr int NG = OWNL_SPAN / 64;
+    __shared__ u32 grp[NG][OWNL_MAX_WORLD];
+    for (int t = threadIdx.x; t < NG * (int)OWNL_MAX_WORLD; t += 256) ((u32*)grp)[t] = 0;
     __syncthreads();
     const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr u32 NONE = 0xFFFFFFFFu;
+    u32 own[OWNL_SPAN / 256], rank[OWNL_SPAN / 256], slot_of[OWNL_SPAN / 256];
 #pragma unroll
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
         const u64 i = b0 + u * 256 + threadIdx.x;
-        if (i >= i1) continue;
-        const u32 slot = mread[i];
-        const u64 rs = roff[slot], re = roff[slot + 1];
-        if (re - rs > k && i + k <= re) {
-            const u32 o = window_owner(mh + i, k, world);
-            const u32 r = atomicAdd(&lcnt[o], 1u);
-            uint2* const e = (uint2*)list + (bases.b[o] + blk_off[(size_t)blockIdx.x * world + o] + r);
-            *e = make_uint2((u32)(i - i0), slot - slot0);        // window start and its read, both relative to the batch
+        u32 o = NONE, slot = 0;
+        if (i < i1) { const u32 ob = owner_of[i - i0]; if (ob != 0xFFu) { o = ob; slot = mread[i]; } }      // (the count pass decided which starts are windows, and whose)
+        u32 r = 0;
+        for (u64 todo = __ballot(o != NONE); todo;) {
+            const u32 oo = (u32)__shfl((int)o, __ffsll((unsigned long long)todo) - 1, 64);
+            const u64 m = __ballot(o == oo);
+            if (o == oo) { r = (u32)__popcll(m & ((1ull << lane) - 1)); if (r == 0) grp[u * 4 + wv][oo] = (u32)__popcll(m); }
+            todo &= ~m;
         }
+        own[u] = o; rank[u] = r; slot_of[u] = slot;
     }
+    __syncthreads();
+    if (threadIdx.x < world) { u32 run = 0; for (int g = 0; g < NG; ++g) { const u32 c = grp[g][threadIdx.x]; grp[g][threadIdx.x] = run; run += c; } }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < OWNL_SPAN / 256; ++u) {
+        const u32 o = own[u];
+        if (o == NONE) continue;
+        const u64 i = b0 + u * 256 + threadIdx.x;
+        uint2* const e = (uint2*)list + (bases.b[o] + blk_off[(size_t)blockIdx.x * world + o] + grp[u * 4 + wv][o] + rank[u]);
+        *e = make_uint2((u32)(i - i0), slot_of[u] - slot0);        // window start and its read, both relative to the batch
+    }
+}
+
+// ---- segments: the hashes a rank's listed windows need, without the rest of the sketch -----------------------------------------------------------
+// A bucket of the owner lists is sorted by window start w; the union of the windows' [w, w + k) is shipped as, per entry, the hashes it adds
+// to the entries in front of it: all k when the window in front (same bucket) starts k or more earlier, else the last (w - w_prev) ones.  Both
+// sides derive the same counts and their prefix from the list alone, so nothing but the list and the packed hashes travels.
+// buckets: [n_buckets + 1] first entries (ascending); src / dst: hash index of window start 0 of every bucket.
+struct SegBuckets { u64 start[OWNL_MAX_WORLD + 1]; u64 base[OWNL_MAX_WORLD]; u64 lim[OWNL_MAX_WORLD]; u32 n; };      // lim: hashes of the bucket's sketch (a window past it is skipped)
+__device__ inline u32 seg_bucket_of(const SegBuckets& B, u64 j) {
+    u32 lo = 0, hi = B.n - 1;
+    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (B.start[mid] <= j) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void seg_add_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, u32* __restrict__ add) {
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    u32 a = k;
+    if (j && B.start[seg_bucket_of(B, j)] != j) { const u32 d = list[j].x - list[j - 1].x; if (d < k) a = d; }
+    add[j] = a;
+}
+// pack (to_store = 0): payload[pre[j] ..) <- the last add[j] hashes of window j read from the store; scatter (to_store = 1): the other way
+__global__ __launch_bounds__(256) void seg_copy_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, const u32* __restrict__ add, const u64* __restrict__ pre,
+                                                       u64* __restrict__ store, u64* __restrict__ payload, u32 to_store) {
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const u32 a = add[j], b = seg_bucket_of(B, j);
+    if ((u64)list[j].x + k > B.lim[b]) return;             // (a wrong list: the count check of the insertion reports it)
+    u64* const h = store + B.base[b] + list[j].x + (k - a);
+    u64* const p = payload + pre[j];
+    if (to_store) for (u32 t = 0; t < a; ++t) h[t] = p[t];
+    else for (u32 t = 0; t < a; ++t) p[t] = h[t];
+}
+__global__ void seg_pick_kernel(const u64* __restrict__ pre, const u32* __restrict__ add, u64 n, SegBuckets B, u64* __restrict__ out) {      // out[b] = first payload index of bucket b, out[n] = total
+    const u32 b = threadIdx.x;
+    if (b > B.n) return;
+    const u64 j = b < B.n ? B.start[b] : n;
+    out[b] = j < n ? pre[j] : (n ? pre[n - 1] + add[n - 1] : 0);
 }
 // inserts exactly the listed windows of the batch whose minimizers start at m0 (keys are read from the resident store)
 __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
@@ -307,7 +410,7 @@ __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T,
     }
     if (ok) {                                      // a wrong list is caught by the count check
         rs = roff[slot]; const u64 re = roff[slot + 1];
-        ok = i >= rs && re - rs > k && i + k <= re && window_owner(mh + i, k, T.own_world) == T.own_rank;
+        ok = i >= rs && re - rs > k && i + k <= re && window_owner(mh + i, k, OwnerSpec{T.own_world, T.own_inv_bound}) == T.own_rank;
     }
     wave_count_add(ok, T.own_inserted);
     if (!ok) return;
@@ -361,7 +464,7 @@ __global__ __launch_bounds__(256) void insert_listed_span_kernel(TableArgs T, co
         }
         if (ok) {                                  // a wrong list is caught by the count check
             rs = roff[slot]; const u64 re = roff[slot + 1];
-            ok = i >= rs && re - rs > k && i + k <= re && window_owner(sh_keys + li, k, T.own_world) == T.own_rank;
+            ok = i >= rs && re - rs > k && i + k <= re && window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_inv_bound}) == T.own_rank;
         }
         wave_count_add(ok, T.own_inserted);
         if (!ok) continue;
@@ -385,11 +488,12 @@ void launch_list_segments(const u32* list, u64 n, u32 n_spans, u32* seg, hipStre
     (void)hipMemsetD32Async((hipDeviceptr_t)seg, (int)(u32)n, (size_t)n_spans + 1, s);
     if (n && n_spans) hipLaunchKernelGGL(list_segments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, list, n, n_spans, seg);
 }
-void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32* blk_cnt, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, blk_cnt);
+void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u32* blk_cnt, u8* owner_of, hipStream_t s) {
+    const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k - 1) * sizeof(u64) : 0;
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), lds, s, mh, mread, roff, i0, i1, k, world, inv_bound, blk_cnt, owner_of);
 }
-void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, slot0, blk_off, bases, list);
+void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, const u8* owner_of, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, inv_bound, slot0, blk_off, bases, list, owner_of);
 }
 // list: n pairs (window start, read), seg: launch_list_segments of it
 void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, const u32* seg, u64 n, u32 slot0,
@@ -652,12 +756,31 @@ __global__ __launch_bounds__(256) void wrap_scan_windows_kernel(TableArgs T, con
     __syncthreads();
     if (!active) return;
     const u64* w = sh_keys + threadIdx.x;
-    if (T.own_world > 1 && window_owner(w, k, T.own_world) != T.own_rank) return;
+    if (T.own_world > 1 && window_owner(w, k, OwnerSpec{T.own_world, T.own_inv_bound}) != T.own_rank) return;
     const bool rev = window_reversed(w, k);
     const u64 s = find_slot(T, key_hash_window(w, k, rev), [&](u64 word) { return same_key_window(T.ks, word, w, rev); });
     if (s == ~0ull) return;
     const u32 pad = T.tab[s].pad;
     if (pad) occ[w_start[pad - 1] + atomicAdd(&w_fill[pad - 1], 1u)] = ord;
+}
+// the same over the LISTED windows of a batch (a foreign sketch of which only the listed windows' hashes are resident)
+__global__ __launch_bounds__(256) void wrap_scan_listed_kernel(TableArgs T, const u64* __restrict__ mh, const u64* __restrict__ roff, u64 m0, u64 m1, const u32* __restrict__ list, u64 n,
+                                                               u32 slot0, u32 n_reads, u64 first_ordinal, const u32* __restrict__ w_start, u32* __restrict__ w_fill, u64* __restrict__ occ) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 k = T.ks.k;
+    const uint2 e = ((const uint2*)list)[j];
+    const u64 i = m0 + e.x; const u32 slot = slot0 + e.y;
+    if (e.y >= n_reads || i + k > m1) return;
+    const u64 rs = roff[slot], re = roff[slot + 1];
+    if (!(i >= rs && re - rs > k && i + k <= re && i - rs <= WIN_MASK)) return;
+    const u64* w = mh + i;
+    if (window_owner(w, k, OwnerSpec{T.own_world, T.own_inv_bound}) != T.own_rank) return;
+    const bool rev = window_reversed(w, k);
+    const u64 s = find_slot(T, key_hash_window(w, k, rev), [&](u64 word) { return same_key_window(T.ks, word, w, rev); });
+    if (s == ~0ull) return;
+    const u32 pad = T.tab[s].pad;
+    if (pad) occ[w_start[pad - 1] + atomicAdd(&w_fill[pad - 1], 1u)] = ((first_ordinal + e.y) << WIN_BITS) | (i - rs);
 }
 // --read_stats (src/main.rs:939-1004): abundance of the k-min-mer that starts at minimizer i in the FILTERED table, 0 when it
 // is absent or below the abundance filter; NO_WINDOW where no window starts (fewer than k minimizers left in the read, or
@@ -715,7 +838,7 @@ __global__ void wrap_pick_kernel(u32 n_w, const u32* __restrict__ w_start, const
 // number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
 // the same, counting only the windows owned by `rank` (replicated-sketch mode); one thread per minimizer index
 __global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                                  u32 k, u32 world, u32 rank, u64* __restrict__ out) {
+                                                                  u32 k, u32 world, double inv_bound, u32 rank, u64* __restrict__ out) {
     constexpr int WPT = 4;                   // four candidates per thread: their dependent loads overlap
     const u64 b0 = i0 + (u64)blockIdx.x * (256 * WPT);
     u32 slot[WPT]; bool ok[WPT];
@@ -727,7 +850,7 @@ __global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __r
         const u64 i = b0 + u * 256 + threadIdx.x;
         if (ok[u]) {
             const u64 rs = roff[slot[u]], re = roff[slot[u] + 1];
-            if (re - rs > k && i + k <= re && window_owner(mh + i, k, world) == rank) ++mine;
+            if (re - rs > k && i + k <= re && window_owner(mh + i, k, OwnerSpec{world, inv_bound}) == rank) ++mine;
         }
     }
     for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d, 64);
@@ -735,7 +858,7 @@ __global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __r
 }
 // per-owner window counts of a batch (what a rank tells its peers, so that nobody has to re-count a foreign sketch)
 __global__ __launch_bounds__(256) void owner_hist_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                         u32 k, u32 world, u64* __restrict__ counts) {
+                                                         u32 k, u32 world, double inv_bound, u64* __restrict__ counts) {
     extern __shared__ u32 hist[];
     for (u32 t = threadIdx.x; t < world; t += 256) hist[t] = 0;
     __syncthreads();
@@ -747,7 +870,7 @@ __global__ __launch_bounds__(256) void owner_hist_kernel(const u64* __restrict__
         if (i < i1) {
             const u32 slot = mread[i];
             const u64 rs = roff[slot], re = roff[slot + 1];
-            if (re - rs > k && i + k <= re) atomicAdd(&hist[window_owner(mh + i, k, world)], 1u);
+            if (re - rs > k && i + k <= re) atomicAdd(&hist[window_owner(mh + i, k, OwnerSpec{world, inv_bound})], 1u);
         }
     }
     __syncthreads();
@@ -1051,11 +1174,11 @@ void launch_popc_prefix2(const u64* bm0, const u64* bm1, u64 n_words, u32* block
     if (!self_base) hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(2), dim3(1024), 0, s, block_tmp, nb);
     hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm0, bm1, n_words, block_tmp, nb, self_base, pre0, pre1);
 }
-void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u32 rank, u64* out_shards, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, rank, out_shards);
+void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u32 rank, u64* out_shards, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, inv_bound, rank, out_shards);
 }
-void launch_owner_hist(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, u64* counts, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(owner_hist_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), world * sizeof(u32), s, mh, mread, roff, i0, i1, k, world, counts);
+void launch_owner_hist(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u64* counts, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_hist_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), world * sizeof(u32), s, mh, mread, roff, i0, i1, k, world, inv_bound, counts);
 }
 void launch_fill_mread(const u64* roff, u32 slot0, u32 n_reads, u32* mread, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(fill_mread_kernel, dim3((n_reads + 3) / 4), dim3(256), 0, s, roff, slot0, n_reads, mread);
@@ -1083,6 +1206,19 @@ void launch_wrap_scan_windows(const TableArgs& T, const u64* mh, const u32* mrea
                               const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {
     if (i1 > i0) hipLaunchKernelGGL(wrap_scan_windows_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), (256 + T.ks.k) * sizeof(u64), s, T, mh, mread, roff,
                                     i0, i1, slot0, first_ordinal, w_start, w_fill, occ);
+}
+void launch_wrap_scan_listed(const TableArgs& T, const u64* mh, const u64* roff, u64 m0, u64 m1, const u32* list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
+                             const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(wrap_scan_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, w_start, w_fill, occ);
+}
+void launch_seg_add(const u32* list, u64 n, u32 k, const SegBuckets& B, u32* add, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(seg_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint2*)list, n, k, B, add);
+}
+void launch_seg_copy(const u32* list, u64 n, u32 k, const SegBuckets& B, const u32* add, const u64* pre, u64* store, u64* payload, bool to_store, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(seg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint2*)list, n, k, B, add, pre, store, payload, to_store ? 1u : 0u);
+}
+void launch_seg_pick(const u64* pre, const u32* add, u64 n, const SegBuckets& B, u64* out, hipStream_t s) {
+    hipLaunchKernelGGL(seg_pick_kernel, dim3(1), dim3(128), 0, s, pre, add, n, B, out);
 }
 void launch_wrap_scan_records(const TableArgs& T, u64 n_records, const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {
     if (n_records) hipLaunchKernelGGL(wrap_scan_records_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, T, n_records, w_start, w_fill, occ);

@@ -58,6 +58,7 @@ class DistMdbg:
         L.mdbg_dist_finalize.argtypes = [C.c_void_p, C.POINTER(api.Nodes), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.mdbg_dist_reset.argtypes = [C.c_void_p, C.c_uint32]
         L.mdbg_dist_set_pipeline.argtypes = [C.c_void_p, C.c_uint32]
+        L.mdbg_dist_set_exchange.argtypes = [C.c_void_p, C.c_uint32]
         L.mdbg_dist_destroy.argtypes = [C.c_void_p]
         L.mdbg_dist_traffic.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         self.comm, self.rccl = rccl_comm(rank, world, dist)
@@ -78,6 +79,11 @@ class DistMdbg:
     def set_pipeline(self, chunks):
         """cut every ingest call into `chunks` rounds whose exchange overlaps the next chunk's sketch kernel (same value on every rank)"""
         self._chk(self.L.mdbg_dist_set_pipeline(self.h, chunks))
+
+    def set_exchange(self, whole):
+        """whole = False (default): per peer its window list and only the hashes those windows need; True: every sketch entire to every rank
+        (needed for reset(new_k) on the resident sketches)"""
+        self._chk(self.L.mdbg_dist_set_exchange(self.h, 1 if whole else 0))
 
     def ingest_device(self, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal):
         self._chk(self.L.mdbg_dist_ingest_batch_device(self.h, d_bases, d_offsets, n_reads, n_bases, first_read_ordinal))

@@ -30,6 +30,28 @@ def test_c_program_drives_ranks_through_mdbg_dist(exe, world, reads, rounds, pac
     assert "EQUAL to the single-context table" in r.stdout
 
 
+def _bytes_in(stdout):
+    return int(stdout.split("bytes received by all ranks: ")[1].split()[0].rstrip(";"))
+
+
+@pytest.mark.parametrize("world,reads,rounds,packed,chunks", [(2, 300, 2, 0, 1), (8, 160, 2, 1, 1), (3, 300, 1, 1, 2)])
+def test_whole_sketch_exchange_gives_the_same_table_and_moves_more(exe, world, reads, rounds, packed, chunks):
+    """mdbg_dist_set_exchange: the default ships per peer the window list and only the hashes its windows need (segments); WHOLE ships every
+    sketch to every rank.  Same table either way; from four ranks on the segments are the smaller exchange by a wide margin (k = 9 here: a run
+    of r windows needs r + 8 hashes)"""
+    out = {}
+    for whole in (0, 1):
+        r = subprocess.run([exe, str(world), str(reads), str(rounds), str(packed), str(chunks), str(whole)], capture_output=True, text=True, timeout=90)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "EQUAL to the single-context table" in r.stdout and ("whole-sketch exchange" if whole else "segment exchange") in r.stdout
+        out[whole] = _bytes_in(r.stdout)
+        # re-windowing the resident sketches at another k: fine with whole sketches, MDBG_E_STATE (-6) when only this k's segments are resident
+        assert ("reset(k + 2): 0 " in r.stdout) if whole else ("reset(k + 2): -" in r.stdout and "ranks differ" not in r.stdout), r.stdout
+    assert out[0] > 0 and out[1] > 0
+    if world >= 8:
+        assert out[0] < 0.6 * out[1], out
+
+
 @pytest.fixture(scope="module")
 def exe_procs(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("distp") / "mdbg_dist_procs")
