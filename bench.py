@@ -228,7 +228,7 @@ def main():
     if routed and args.dist_impl == "c":
         from rust_mdbg_amd import dist_c
         cdist = dist_c.DistMdbg(args.k, args.l, args.density, args.minabund, rank, world, dist, device=local_rank)
-        n_chunks = args.chunks if args.chunks > 0 else 4
+        n_chunks = args.chunks if args.chunks > 0 else (4 if args.dist_exchange == "whole" else 2)      # segments: a rank's share of a round is a few tens of MB per link
         cdist.set_pipeline(n_chunks)          # the exchange of chunk i overlaps the tile kernel of chunk i+1 (mdbg_dist_set_pipeline)
         cdist.set_exchange(args.dist_exchange == "whole")
     if routed and cdist is None:

@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __rest
 // to the entries in front of it: all k when the window in front (same bucket) starts k or more earlier, else the last (w - w_prev) ones.  Both
 // sides derive the same counts and their prefix from the list alone, so nothing but the list and the packed hashes travels.
 // buckets: [n_buckets + 1] first entries (ascending); src / dst: hash index of window start 0 of every bucket.
-struct SegBuckets { u64 start[OWNL_MAX_WORLD + 1]; u64 base[OWNL_MAX_WORLD]; u64 lim[OWNL_MAX_WORLD]; u32 n; };      // lim: hashes of the bucket's sketch (a window past it is skipped)
+struct SegBuckets { u64 start[OWNL_MAX_WORLD + 1]; u64 base[OWNL_MAX_WORLD]; u64 lim[OWNL_MAX_WORLD]; u32 n; u32 skip; };      // lim: hashes of the bucket's sketch (a window past
+                                                                                                                                // it is skipped); skip: a bucket that ships nothing (the sender's own), or ~0
 __device__ inline u32 seg_bucket_of(const SegBuckets& B, u64 j) {
     u32 lo = 0, hi = B.n - 1;
     while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (B.start[mid] <= j) lo = mid; else hi = mid - 1; }
@@ -374,7 +375,9 @@ __global__ __launch_bounds__(256) void seg_add_kernel(const uint2* __restrict__ 
     const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     u32 a = k;
-    if (j && B.start[seg_bucket_of(B, j)] != j) { const u32 d = list[j].x - list[j - 1].x; if (d < k) a = d; }
+    const u32 b = seg_bucket_of(B, j);
+    if (b == B.skip) a = 0;
+    else if (j && B.start[b] != j) { const u32 d = list[j].x - list[j - 1].x; if (d < k) a = d; }
     add[j] = a;
 }
 // pack (to_store = 0): payload[pre[j] ..) <- the last add[j] hashes of window j read from the store; scatter (to_store = 1): the other way
@@ -1164,6 +1167,14 @@ void launch_insert_records(const TableArgs& T, u64 r0, u64 r1, u64* n_windows, h
 }
 void launch_rehash(const Slot* old, u64 old_cap, const u64* old_mx, const TableArgs& T, hipStream_t s) {
     hipLaunchKernelGGL(rehash_kernel, dim3((unsigned)((old_cap + 255) / 256)), dim3(256), 0, s, old, old_cap, old_mx, T);
+}
+// out[0], out[1] = bits set in the two bitmaps (last prefix + popcount of the last word)
+__global__ void bitmap_totals_kernel(const u64* __restrict__ bm0, const u32* __restrict__ pre0, const u64* __restrict__ bm1, const u32* __restrict__ pre1, u64 n_words, u64* __restrict__ out) {
+    if (threadIdx.x == 0) out[0] = n_words ? (u64)pre0[n_words - 1] + (u64)__popcll(bm0[n_words - 1]) : 0;
+    if (threadIdx.x == 1) out[1] = n_words ? (u64)pre1[n_words - 1] + (u64)__popcll(bm1[n_words - 1]) : 0;
+}
+void launch_bitmap_totals(const u64* bm0, const u32* pre0, const u64* bm1, const u32* pre1, u64 n_words, u64* out, hipStream_t s) {
+    hipLaunchKernelGGL(bitmap_totals_kernel, dim3(1), dim3(64), 0, s, bm0, pre0, bm1, pre1, n_words, out);
 }
 // block_tmp: 2 * ceil(n_words / 1024) u32
 void launch_popc_prefix2(const u64* bm0, const u64* bm1, u64 n_words, u32* block_tmp, u32* pre0, u32* pre1, hipStream_t s) {

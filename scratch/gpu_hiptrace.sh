@@ -2,7 +2,7 @@
 # host API timeline of one bench step (rocprofv3 --hip-trace): which runtime calls sit between the kernels
 R=$(pwd); O=$R/gpurun_out/$1; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --hip-trace --kernel-trace --output-format csv -d $O/tr -o t -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $O/trace.log 2>&1
+rocprofv3 --hip-trace --kernel-trace --output-format csv -d $O/tr -o t -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 $BENCH_ARGS > $O/trace.log 2>&1
 ls $O/tr
 python - $O/tr <<'PY' | tee $O/api_timeline.txt
 import csv, sys, os
