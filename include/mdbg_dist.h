@@ -5,10 +5,12 @@
  * partitioning is the north star's: every rank sketches its own reads (mdbg_hip.h), the ranks exchange what the owners of the
  * k-min-mers need, every rank counts the keys it owns, and DbgEntry.index (NODE_INDEX, src/main.rs:598,661) is made global by
  * summing the ranks' first-sighting bitmaps.  Mode implemented here: the SKETCH exchange (profiles/r02_notes.md: 3x faster per rank
- * than routing expanded k-min-mer records): per round every rank sends each peer the HASHES of its sketch (8 bytes per minimizer; the
- * raw positions stay home: a node's seqlen / shift / origin need four positions of ONE window, which mdbg_dist_finalize fetches from the
- * rank that sketched the read — a few MB per finalize instead of 4 bytes per minimizer per round) together with
- * the list of the windows that peer owns (8 bytes per window, mdbg_owner_lists) in ONE grouped set of ncclSend / ncclRecv pairs —
+ * than routing expanded k-min-mer records): per round every rank sends each peer the list of the windows that peer owns (8 bytes per window,
+ * mdbg_owner_lists; a k-min-mer belongs to the rank its smallest minimizer hash maps to) and the HASHES those windows need — by default only
+ * those (segments: a peer's windows come in runs, a run of r windows needs r + k - 1 hashes), see mdbg_dist_set_exchange.  The raw
+ * positions stay home: a node's seqlen / shift / origin need four positions of ONE window, which mdbg_dist_finalize fetches from the
+ * rank that sketched the read — a few MB per finalize instead of 4 bytes per minimizer per round.  All of a round travels
+ * in ONE grouped set of ncclSend / ncclRecv pairs —
  * xGMI is point to point, every pair of GPUs uses its own link — and the receives land directly in reserved regions of the
  * resident sketch store (mdbg_sketch_reserve: no staging copy).  Results are identical to a single context fed all reads
  * (tests/test_gpu_dist_c.py, examples/mdbg_dist_threads.c).

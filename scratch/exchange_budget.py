@@ -28,5 +28,25 @@ for W in (2, 4, 8):
     out["worlds"].append(row)
 out["compute_ms_per_rank_per_step"] = {"measured": "profiles/r02_notes.md: 13.9 / 15.0 / 15.9 ms for W = 1 / 2 / 4 (emulated, GPU time per rank, round 2's kernels)",
                                        "note": "the exchange runs in 4 chunks on its own stream under the tile kernel of the next chunk and (this round) under the insertion of the previous one"}
+# segments (the default exchange from the second half of round 3): measured, not modelled — W thread-ranks of the C layer on one GPU
+# (scratch/measure_dist_traffic.py -> profiles/r03_dist_traffic.jsonl), bytes into the busiest rank per step incl. the position fetch at finalize
+seg = {"what": "mdbg_dist_set_exchange(MDBG_EXCHANGE_SEGMENTS): window lists + only the hashes the listed windows need; owner = rank of the window's smallest hash",
+       "source": "profiles/r03_dist_traffic.jsonl (measured through mdbg_dist_traffic; config 2 = 7.0 Gbases per rank l=12 d=0.002, config 3 = 19.5 Gbases per rank l=14 d=0.003)", "rows": []}
+for line in open(os.path.join(ROOT, "profiles", "r03_dist_traffic.jsonl")):
+    j = json.loads(line); W = j["world"]
+    row = {"world": W, "config": j["config"]}
+    for mode in ("segments", "whole"):
+        m = j[mode]
+        row[mode] = {"bytes_in_busiest_rank": m["bytes_in_per_rank_per_step_max"], "bytes_in_mean": m["bytes_in_per_rank_per_step_mean"],
+                     "per_peer_wire_ms_at_76.8_GBps": m["bytes_in_per_rank_per_step_max"] / (W - 1) / 76.8e9 * 1e3, "per_peer_wire_ms_at_60_GBps": m["bytes_in_per_rank_per_step_max"] / (W - 1) / 60e9 * 1e3}
+    nl = j["segments"]["nodes_local"]
+    row["nodes_per_rank_max_over_mean"] = max(nl) / (sum(nl) / W)
+    seg["rows"].append(row)
+s3 = [r for r in seg["rows"] if r["config"] == 3]
+if s3:
+    r = s3[-1]; W = r["world"]; per_rank_out = r["segments"]["bytes_in_mean"] * W / (W - 1)
+    seg["extrapolated_config3_world8"] = {"note": "the segment volume a rank SENDS does not depend on W (its windows' hashes go out once, to whoever owns them); a rank receives (W-1)/W of the mean",
+                                           "bytes_in_mean": per_rank_out * 7 / 8, "per_peer_wire_ms_at_76.8_GBps": per_rank_out / 8 / 76.8e9 * 1e3, "per_peer_wire_ms_at_60_GBps": per_rank_out / 8 / 60e9 * 1e3}
+out["segments_measured"] = seg
 json.dump(out, sys.stdout, indent=1)
 print()
