@@ -212,7 +212,10 @@ __device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os) {
 // local indices of the windows this rank has to insert, and then works the list off densely, so the long find-or-claim chains run on
 // full wavefronts (0.80 -> 0.64 ms per 6.6 M windows against one thread per minimizer index).  Orientation, hash and the own side of the
 // key comparison read the staged values.
-constexpr int OWN_SPAN = 2048;
+#ifndef OWN_SPAN_V
+#define OWN_SPAN_V 2048
+#endif
+constexpr int OWN_SPAN = OWN_SPAN_V;
 __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
                                                                    const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
                                                                    u32* __restrict__ cap_err) {
