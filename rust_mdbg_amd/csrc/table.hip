@@ -385,11 +385,11 @@ __global__ __launch_bounds__(256) void seg_add_kernel(const uint2* __restrict__ 
 }
 // pack (to_store = 0): payload[pre[j] ..) <- the last add[j] hashes of window j read from the store; scatter (to_store = 1): the other way
 __global__ __launch_bounds__(256) void seg_copy_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, const u32* __restrict__ add, const u64* __restrict__ pre,
-                                                       u64* __restrict__ store, u64* __restrict__ payload, u32 to_store) {
+                                                       u64* __restrict__ store, u64* __restrict__ payload, u64 payload_n, u32 to_store) {
     const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const u32 a = add[j], b = seg_bucket_of(B, j);
-    if ((u64)list[j].x + k > B.lim[b]) return;             // (a wrong list: the count check of the insertion reports it)
+    if ((u64)list[j].x + k > B.lim[b] || pre[j] + a > payload_n) return;             // (a wrong list: reported by the size check of the round / the count check of the insertion)
     u64* const h = store + B.base[b] + list[j].x + (k - a);
     u64* const p = payload + pre[j];
     if (to_store) for (u32 t = 0; t < a; ++t) h[t] = p[t];
@@ -1228,8 +1228,8 @@ void launch_wrap_scan_listed(const TableArgs& T, const u64* mh, const u64* roff,
 void launch_seg_add(const u32* list, u64 n, u32 k, const SegBuckets& B, u32* add, hipStream_t s) {
     if (n) hipLaunchKernelGGL(seg_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint2*)list, n, k, B, add);
 }
-void launch_seg_copy(const u32* list, u64 n, u32 k, const SegBuckets& B, const u32* add, const u64* pre, u64* store, u64* payload, bool to_store, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(seg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint2*)list, n, k, B, add, pre, store, payload, to_store ? 1u : 0u);
+void launch_seg_copy(const u32* list, u64 n, u32 k, const SegBuckets& B, const u32* add, const u64* pre, u64* store, u64* payload, u64 payload_n, bool to_store, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(seg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint2*)list, n, k, B, add, pre, store, payload, payload_n, to_store ? 1u : 0u);
 }
 void launch_seg_pick(const u64* pre, const u32* add, u64 n, const SegBuckets& B, u64* out, hipStream_t s) {
     hipLaunchKernelGGL(seg_pick_kernel, dim3(1), dim3(128), 0, s, pre, add, n, B, out);
