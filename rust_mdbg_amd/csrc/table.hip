@@ -81,7 +81,7 @@ struct TableArgs {
     u64* n_distinct;              // device counter
     KeySrc ks;
     u32 own_world, own_rank;      // replicated-sketch mode: insert only windows owned by own_rank (own_world <= 1: all)
-    double own_inv_bound;         // see OwnerSpec
+    const u64* own_thr;           // see OwnerSpec
     u32* probe_err;               // set when a probe sequence visited every slot: the table was sized from a wrong window count
     u64* own_inserted;            // sharded counter: owned windows actually inserted (checked against the senders' counts)
     u32 exp;                      // diagnostic (MDBG_INSERT_EXP): parts of insert_windows_kernel switched off to time the rest (results are wrong)
@@ -188,7 +188,7 @@ __device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, b
 // 1 - (1 - v / bound)^k, and a minimizer that is small is the smallest of MANY windows: hashing the value to a rank left one of eight
 // ranks with 43 % more nodes than the mean (l = 12: the few hundred smallest l-mer hashes carry most windows).  Cutting [0, 1) of that
 // distribution function into `world` equal parts gives every rank the same expected share whatever the weights: 1.05 instead of 1.43.
-struct OwnerSpec { u32 world; double inv_bound; };      // inv_bound = 1 / hash bound of the sketch (0: unknown, fall back to hashing the value)
+struct OwnerSpec { u32 world; const u64* thr; };      // thr[0 .. world - 1): ascending; rank r owns the minima v with thr[r - 1] <= v < thr[r] (null: hash the value)
 __device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os);
 __device__ inline u32 window_owner(const u64* __restrict__ w, u32 k, OwnerSpec os) {
     if (os.world <= 1) return 0;
@@ -197,13 +197,25 @@ __device__ inline u32 window_owner(const u64* __restrict__ w, u32 k, OwnerSpec o
     return owner_of_min(m, k, os);
 }
 __device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os) {
+    (void)k;
     if (os.world <= 1) return 0;
-    if (!(os.inv_bound > 0.0)) return (u32)__umul64hi(fmix64(m), (u64)os.world);
-    double x = (double)m * os.inv_bound;
-    x = x < 1.0 ? x : 1.0;
-    const double cdf = 1.0 - exp((double)k * log1p(-x * (1.0 - 1e-12)));
-    const u32 o = (u32)(cdf * (double)os.world);
-    return o < os.world ? o : os.world - 1;
+    if (!os.thr) return (u32)__umul64hi(fmix64(m), (u64)os.world);
+    u32 lo = 0, hi = os.world - 1;                  // number of thresholds <= m
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (os.thr[mid] <= m) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// thr[r - 1] = bound * (1 - (1 - r / world)^(1 / k)), r = 1 .. world - 1: the values at which the distribution function of the window minimum,
+// 1 - (1 - v / bound)^k, passes r / world.  Computed ONCE per (k, world, bound) on the device (every rank runs the same code on the same
+// hardware: identical thresholds without any host floating point), the windows are then placed by integer comparisons.
+__global__ void owner_thresholds_kernel(double bound, u32 k, u32 world, u64* __restrict__ thr) {
+    const u32 r = threadIdx.x + 1;
+    if (r >= world) return;
+    const double x = -expm1(log1p(-(double)r / (double)world) / (double)k);
+    double v = x * bound;
+    thr[r - 1] = v >= 18446744073709549568.0 ? ~0ull : (u64)v;
+}
+void launch_owner_thresholds(double bound, u32 k, u32 world, u64* thr, hipStream_t s) {
+    if (world > 1) hipLaunchKernelGGL(owner_thresholds_kernel, dim3(1), dim3(64), 0, s, bound, k, world, thr);
 }
 
 // Windows of the minimizers [i0, i1) of a batch -> counting table.  src/main.rs:756 — only reads with MORE than k minimizers contribute,
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
         const u32 li = u * 256 + threadIdx.x;
         const u64 i = b0 + li;
         bool mine = false;
-        if (i + k <= i1 && (T.own_world <= 1 || window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_inv_bound}) == T.own_rank)) {       // ownership first: it needs no further loads
+        if (i + k <= i1 && (T.own_world <= 1 || window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank)) {       // ownership first: it needs no further loads
             const u32 slot = mread[i];
             const u64 rs = roff[slot], re = roff[slot + 1];
             mine = re - rs > k && i + k <= re;
@@ -287,7 +299,7 @@ __device__ inline bool window_starts_at(const u32* __restrict__ mread, const u64
 // window of k is two overlapping stretches of p) — read from HBM window by window it was 35 loads each, 1.4 ms per 6.6 M windows.
 constexpr u32 OWNL_LDS_MAX_K = 1024;          // longer k: the plain loop (2 x (OWNL_SPAN + k) values have to fit the default 64 KB of dynamic LDS)
 __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                               u32 k, u32 world, double inv_bound, u32* __restrict__ blk_cnt, u8* __restrict__ owner_of) {
+                                                               u32 k, u32 world, const u64* thr, u32* __restrict__ blk_cnt, u8* __restrict__ owner_of) {
     extern __shared__ u64 sh_min[];               // two buffers of OWNL_SPAN + k - 1 values (k <= OWNL_LDS_MAX_K)
     __shared__ u32 hist[OWNL_MAX_WORLD];
     if (threadIdx.x < world) hist[threadIdx.x] = 0;
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __rest
         }
         cur = a;
     } else __syncthreads();
-    const OwnerSpec os{world, inv_bound};
+    const OwnerSpec os{world, thr};
 #pragma unroll
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
         const u32 li = u * 256 + threadIdx.x;
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __rest
 // Every owner's bucket comes out sorted by window start (the segments below are differences of neighbouring entries): the entries of a
 // workgroup's span are ranked per owner in index order — lanes of a wave by ballots, the 32 (iteration, wave) groups by a prefix in LDS.
 __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                               u32 k, u32 world, double inv_bound, u32 slot0, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list,
+                                                               u32 k, u32 world, const u64* thr, u32 slot0, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list,
                                                                const u8* __restrict__ owner_of) {
     constexpr int NG = OWNL_SPAN / 64;
     __shared__ u32 grp[NG][OWNL_MAX_WORLD];
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T,
     }
     if (ok) {                                      // a wrong list is caught by the count check
         rs = roff[slot]; const u64 re = roff[slot + 1];
-        ok = i >= rs && re - rs > k && i + k <= re && window_owner(mh + i, k, OwnerSpec{T.own_world, T.own_inv_bound}) == T.own_rank;
+        ok = i >= rs && re - rs > k && i + k <= re && window_owner(mh + i, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank;
     }
     wave_count_add(ok, T.own_inserted);
     if (!ok) return;
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256) void insert_listed_span_kernel(TableArgs T, co
         }
         if (ok) {                                  // a wrong list is caught by the count check
             rs = roff[slot]; const u64 re = roff[slot + 1];
-            ok = i >= rs && re - rs > k && i + k <= re && window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_inv_bound}) == T.own_rank;
+            ok = i >= rs && re - rs > k && i + k <= re && window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank;
         }
         wave_count_add(ok, T.own_inserted);
         if (!ok) continue;
@@ -494,12 +506,12 @@ void launch_list_segments(const u32* list, u64 n, u32 n_spans, u32* seg, hipStre
     (void)hipMemsetD32Async((hipDeviceptr_t)seg, (int)(u32)n, (size_t)n_spans + 1, s);
     if (n && n_spans) hipLaunchKernelGGL(list_segments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, list, n, n_spans, seg);
 }
-void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u32* blk_cnt, u8* owner_of, hipStream_t s) {
+void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u32* blk_cnt, u8* owner_of, hipStream_t s) {
     const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k - 1) * sizeof(u64) : 0;
-    if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), lds, s, mh, mread, roff, i0, i1, k, world, inv_bound, blk_cnt, owner_of);
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), lds, s, mh, mread, roff, i0, i1, k, world, thr, blk_cnt, owner_of);
 }
-void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, const u8* owner_of, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, inv_bound, slot0, blk_off, bases, list, owner_of);
+void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, const u8* owner_of, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, thr, slot0, blk_off, bases, list, owner_of);
 }
 // list: n pairs (window start, read), seg: launch_list_segments of it
 void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, const u32* seg, u64 n, u32 slot0,
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(256) void wrap_scan_windows_kernel(TableArgs T, con
     __syncthreads();
     if (!active) return;
     const u64* w = sh_keys + threadIdx.x;
-    if (T.own_world > 1 && window_owner(w, k, OwnerSpec{T.own_world, T.own_inv_bound}) != T.own_rank) return;
+    if (T.own_world > 1 && window_owner(w, k, OwnerSpec{T.own_world, T.own_thr}) != T.own_rank) return;
     const bool rev = window_reversed(w, k);
     const u64 s = find_slot(T, key_hash_window(w, k, rev), [&](u64 word) { return same_key_window(T.ks, word, w, rev); });
     if (s == ~0ull) return;
@@ -781,7 +793,7 @@ __global__ __launch_bounds__(256) void wrap_scan_listed_kernel(TableArgs T, cons
     const u64 rs = roff[slot], re = roff[slot + 1];
     if (!(i >= rs && re - rs > k && i + k <= re && i - rs <= WIN_MASK)) return;
     const u64* w = mh + i;
-    if (window_owner(w, k, OwnerSpec{T.own_world, T.own_inv_bound}) != T.own_rank) return;
+    if (window_owner(w, k, OwnerSpec{T.own_world, T.own_thr}) != T.own_rank) return;
     const bool rev = window_reversed(w, k);
     const u64 s = find_slot(T, key_hash_window(w, k, rev), [&](u64 word) { return same_key_window(T.ks, word, w, rev); });
     if (s == ~0ull) return;
@@ -844,7 +856,7 @@ __global__ void wrap_pick_kernel(u32 n_w, const u32* __restrict__ w_start, const
 // number of k-min-mer occurrences of a batch: sum over its reads of (n > k ? n - k + 1 : 0)   (src/main.rs:756-759)
 // the same, counting only the windows owned by `rank` (replicated-sketch mode); one thread per minimizer index
 __global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                                  u32 k, u32 world, double inv_bound, u32 rank, u64* __restrict__ out) {
+                                                                  u32 k, u32 world, const u64* thr, u32 rank, u64* __restrict__ out) {
     constexpr int WPT = 4;                   // four candidates per thread: their dependent loads overlap
     const u64 b0 = i0 + (u64)blockIdx.x * (256 * WPT);
     u32 slot[WPT]; bool ok[WPT];
@@ -856,7 +868,7 @@ __global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __r
         const u64 i = b0 + u * 256 + threadIdx.x;
         if (ok[u]) {
             const u64 rs = roff[slot[u]], re = roff[slot[u] + 1];
-            if (re - rs > k && i + k <= re && window_owner(mh + i, k, OwnerSpec{world, inv_bound}) == rank) ++mine;
+            if (re - rs > k && i + k <= re && window_owner(mh + i, k, OwnerSpec{world, thr}) == rank) ++mine;
         }
     }
     for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d, 64);
@@ -864,7 +876,7 @@ __global__ __launch_bounds__(256) void count_owned_windows_kernel(const u64* __r
 }
 // per-owner window counts of a batch (what a rank tells its peers, so that nobody has to re-count a foreign sketch)
 __global__ __launch_bounds__(256) void owner_hist_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
-                                                         u32 k, u32 world, double inv_bound, u64* __restrict__ counts) {
+                                                         u32 k, u32 world, const u64* thr, u64* __restrict__ counts) {
     extern __shared__ u32 hist[];
     for (u32 t = threadIdx.x; t < world; t += 256) hist[t] = 0;
     __syncthreads();
@@ -876,7 +888,7 @@ __global__ __launch_bounds__(256) void owner_hist_kernel(const u64* __restrict__
         if (i < i1) {
             const u32 slot = mread[i];
             const u64 rs = roff[slot], re = roff[slot + 1];
-            if (re - rs > k && i + k <= re) atomicAdd(&hist[window_owner(mh + i, k, OwnerSpec{world, inv_bound})], 1u);
+            if (re - rs > k && i + k <= re) atomicAdd(&hist[window_owner(mh + i, k, OwnerSpec{world, thr})], 1u);
         }
     }
     __syncthreads();
@@ -1188,11 +1200,11 @@ void launch_popc_prefix2(const u64* bm0, const u64* bm1, u64 n_words, u32* block
     if (!self_base) hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(2), dim3(1024), 0, s, block_tmp, nb);
     hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm0, bm1, n_words, block_tmp, nb, self_base, pre0, pre1);
 }
-void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u32 rank, u64* out_shards, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, inv_bound, rank, out_shards);
+void launch_count_owned_windows(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u32 rank, u64* out_shards, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(count_owned_windows_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, thr, rank, out_shards);
 }
-void launch_owner_hist(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, double inv_bound, u64* counts, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(owner_hist_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), world * sizeof(u32), s, mh, mread, roff, i0, i1, k, world, inv_bound, counts);
+void launch_owner_hist(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u64* counts, hipStream_t s) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_hist_kernel, dim3((unsigned)((i1 - i0 + 1023) / 1024)), dim3(256), world * sizeof(u32), s, mh, mread, roff, i0, i1, k, world, thr, counts);
 }
 void launch_fill_mread(const u64* roff, u32 slot0, u32 n_reads, u32* mread, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(fill_mread_kernel, dim3((n_reads + 3) / 4), dim3(256), 0, s, roff, slot0, n_reads, mread);
