@@ -306,6 +306,14 @@ def main():
         loc = torch.tensor([(cdist if cdist is not None else runner).last_local], device="cuda", dtype=torch.int64)
         dist.all_reduce(loc)
         consistent = bool(int(loc.item()) == int(n_nodes))
+    exchange = None
+    if cdist is not None:    # what went over the links in the last step, and how even the partition is (mdbg_dist_traffic; outside the timed region)
+        b_in, b_out, n_q = cdist.traffic()
+        tmax = torch.tensor([b_in, int(cdist.last_local)], device="cuda", dtype=torch.int64)
+        tsum = tmax.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tsum)
+        exchange = {"mode": args.dist_exchange, "chunks_per_step": n_chunks, "bytes_in_busiest_rank_per_step": int(tmax[0].item()), "bytes_in_mean_per_step": float(tsum[0].item()) / world,
+                    "nodes_busiest_rank_over_mean": (float(tmax[1].item()) * world / float(tsum[1].item())) if int(tsum[1].item()) else None}
     st = m.stats()          # stats of the last step only (reset clears the timers)
     if cdist is not None:
         m_stats = api_stats_of(cdist)
@@ -381,14 +389,14 @@ def main():
                                       "synthetic D. melanogaster %.0f Mb @%.0fx per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1%% errors" % (args.genome_mb, args.coverage),
                           "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
                           "bases_per_gpu": n_bases, "input_format": args.input,
-                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("sketches + window lists exchanged by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h) in %d chunks overlapping the tile kernel" % n_chunks) if cdist is not None else (("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records"))) if routed else "single GPU"},
+                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("%s exchanged by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h) in %d chunks overlapping the tile kernel" % ("window lists + the sketch hashes they need" if args.dist_exchange == "segments" else "whole sketches + window lists", n_chunks)) if cdist is not None else (("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records"))) if routed else "single GPU"},
                "roofline": roof, "roofline_ascii": roof_ascii, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
                          "checked_against_recorded_counts": want is not None,
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent},
-               "edges_after_timed_region": edges}
+               "exchange": exchange, "edges_after_timed_region": edges}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     if cdist is not None:
