@@ -188,7 +188,14 @@ __device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, b
 // 1 - (1 - v / bound)^k, and a minimizer that is small is the smallest of MANY windows: hashing the value to a rank left one of eight
 // ranks with 43 % more nodes than the mean (l = 12: the few hundred smallest l-mer hashes carry most windows).  Cutting [0, 1) of that
 // distribution function into `world` equal parts gives every rank the same expected share whatever the weights: 1.05 instead of 1.43.
-struct OwnerSpec { u32 world; const u64* thr; };      // thr[0 .. world - 1): ascending; rank r owns the minima v with thr[r - 1] <= v < thr[r] (null: hash the value)
+// Owner parameters in device memory (u64 units): [0] = bin multiplier (0: no table), [1 .. 64) thresholds, ascending: rank r owns the minima v with
+// thr[r - 1] <= v < thr[r]; from [64]: OWNER_BINS bytes, the owner of every bin of the value range (bin = mulhi64(v, multiplier)) — a MEASURED
+// assignment: the multi-GPU layer counts the window minima of its first round per bin, sums the counts over the ranks and deals the bins out
+// heaviest first to the least loaded rank (dist_api.inc, build_owner_table), so that a handful of very frequent small hashes (l = 12: ~700 distinct
+// homopolymer-compressed 12-mers under the threshold, the smallest one the minimum of 5 % of all windows) cannot leave one rank with 20 % more
+// than its share.  Neighbouring windows still share their owner (it is still a function of the smallest hash alone).
+constexpr u32 OWNER_BINS = 65536, OWNER_THR_AT = 1, OWNER_TAB_AT = 64, OWNER_PARAM_WORDS = OWNER_TAB_AT + OWNER_BINS / 8;
+struct OwnerSpec { u32 world; const u64* thr; };      // thr: the block above (null: hash the value)
 __device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os);
 __device__ inline u32 window_owner(const u64* __restrict__ w, u32 k, OwnerSpec os) {
     if (os.world <= 1) return 0;
@@ -200,8 +207,15 @@ __device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os) {
     (void)k;
     if (os.world <= 1) return 0;
     if (!os.thr) return (u32)__umul64hi(fmix64(m), (u64)os.world);
+    const u64 mul = os.thr[0];
+    if (mul) {
+        const u64 bin = __umul64hi(m, mul);
+        const u32 o = ((const u8*)(os.thr + OWNER_TAB_AT))[bin < OWNER_BINS ? bin : OWNER_BINS - 1];
+        return o < os.world ? o : os.world - 1;
+    }
+    const u64* const thr = os.thr + OWNER_THR_AT;
     u32 lo = 0, hi = os.world - 1;                  // number of thresholds <= m
-    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (os.thr[mid] <= m) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (thr[mid] <= m) lo = mid + 1; else hi = mid; }
     return lo;
 }
 // thr[r - 1] = bound * (1 - (1 - r / world)^(1 / k)), r = 1 .. world - 1: the values at which the distribution function of the window minimum,
@@ -209,6 +223,8 @@ __device__ inline u32 owner_of_min(u64 m, u32 k, OwnerSpec os) {
 // hardware: identical thresholds without any host floating point), the windows are then placed by integer comparisons.
 __global__ void owner_thresholds_kernel(double bound, u32 k, u32 world, u64* __restrict__ thr) {
     const u32 r = threadIdx.x + 1;
+    if (threadIdx.x == 0) thr[0] = 0;               // no measured table (yet)
+    thr += OWNER_THR_AT;
     if (r >= world) return;
     const double x = -expm1(log1p(-(double)r / (double)world) / (double)k);
     double v = x * bound;
@@ -298,6 +314,54 @@ __device__ inline bool window_starts_at(const u32* __restrict__ mread, const u64
 // of all the span's windows comes from LDS: the span's hashes are staged once and reduced by doubling (min over 2, 4, ... p <= k values; a
 // window of k is two overlapping stretches of p) — read from HBM window by window it was 35 loads each, 1.4 ms per 6.6 M windows.
 constexpr u32 OWNL_LDS_MAX_K = 1024;          // longer k: the plain loop (2 x (OWNL_SPAN + k) values have to fit the default 64 KB of dynamic LDS)
+// sh: two buffers of OWNL_SPAN + k - 1 values.  Returns M with M[t] = min of the p values from t on (p = largest power of two <= k), so that the
+// smallest hash of the window starting at span position li is min(M[li], M[li + k - p]).  All 256 threads call it.
+__device__ inline const u64* span_minima(const u64* __restrict__ mh, u64 b0, u64 i1, u32 k, u64* sh, u32& p) {
+    const u32 nv = OWNL_SPAN + k - 1;
+    u64* a = sh; u64* b = sh + nv;
+    for (u32 t = threadIdx.x; t < nv; t += 256) a[t] = b0 + t < i1 ? mh[b0 + t] : ~0ull;
+    __syncthreads();
+    for (p = 1; 2 * p <= k; p *= 2) {
+        for (u32 t = threadIdx.x; t < nv; t += 256) { const u64 x = a[t], y = t + p < nv ? a[t + p] : ~0ull; b[t] = x < y ? x : y; }
+        __syncthreads();
+        u64* const sw = a; a = b; b = sw;
+    }
+    return a;
+}
+// window minima of a batch counted per bin of the value range (hist[OWNER_BINS], added to): what the measured owner table is made from
+__global__ __launch_bounds__(256) void owner_bins_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1, u32 k, u64 mul,
+                                                         unsigned long long* __restrict__ hist) {
+    extern __shared__ u64 sh_min[];
+    const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
+    const bool staged = k <= OWNL_LDS_MAX_K;
+    const u64* cur = sh_min; u32 p = 1;
+    if (staged) cur = span_minima(mh, b0, i1, k, sh_min, p);
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int u = 0; u < OWNL_SPAN / 256; ++u) {
+        const u32 li = u * 256 + threadIdx.x;
+        const u64 i = b0 + li;
+        u32 bin = 0xFFFFFFFFu;
+        if (window_starts_at(mread, roff, i, i1, k)) {
+            u64 m;
+            if (staged) { const u64 x = cur[li], y = cur[li + k - p]; m = x < y ? x : y; }
+            else { m = mh[i]; for (u32 j = 1; j < k; ++j) { const u64 x = mh[i + j]; m = x < m ? x : m; } }
+            const u64 q = __umul64hi(m, mul);
+            bin = q < OWNER_BINS ? (u32)q : OWNER_BINS - 1;
+        }
+        // one atomic per distinct bin of the wave (the heavy bins are hit by several lanes of every wave)
+        for (u64 todo = __ballot(bin != 0xFFFFFFFFu); todo;) {
+            const u32 bb = (u32)__shfl((int)bin, __ffsll((unsigned long long)todo) - 1, 64);
+            const u64 mm = __ballot(bin == bb);
+            if (bin == bb && (mm & ((1ull << lane) - 1)) == 0) atomicAdd(&hist[bb], (unsigned long long)__popcll(mm));
+            todo &= ~mm;
+        }
+    }
+}
+void launch_owner_bins(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u64 mul, u64* hist, hipStream_t s) {
+    const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k - 1) * sizeof(u64) : 0;
+    if (i1 > i0) hipLaunchKernelGGL(owner_bins_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), lds, s, mh, mread, roff, i0, i1, k, mul, (unsigned long long*)hist);
+}
 __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
                                                                u32 k, u32 world, const u64* thr, u32* __restrict__ blk_cnt, u8* __restrict__ owner_of) {
     extern __shared__ u64 sh_min[];               // two buffers of OWNL_SPAN + k - 1 values (k <= OWNL_LDS_MAX_K)
@@ -305,19 +369,8 @@ __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __rest
     if (threadIdx.x < world) hist[threadIdx.x] = 0;
     const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
     const bool staged = k <= OWNL_LDS_MAX_K;
-    const u32 nv = OWNL_SPAN + k - 1;
     const u64* cur = sh_min; u32 p = 1;
-    if (staged) {
-        u64* a = sh_min; u64* b = sh_min + nv;
-        for (u32 t = threadIdx.x; t < nv; t += 256) a[t] = b0 + t < i1 ? mh[b0 + t] : ~0ull;
-        __syncthreads();
-        for (; 2 * p <= k; p *= 2) {
-            for (u32 t = threadIdx.x; t < nv; t += 256) { const u64 x = a[t], y = t + p < nv ? a[t + p] : ~0ull; b[t] = x < y ? x : y; }
-            __syncthreads();
-            u64* const sw = a; a = b; b = sw;
-        }
-        cur = a;
-    } else __syncthreads();
+    if (staged) cur = span_minima(mh, b0, i1, k, sh_min, p); else __syncthreads();
     const OwnerSpec os{world, thr};
 #pragma unroll
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
