@@ -650,6 +650,8 @@ struct FinArgs {
     BatchTab bt;
     u64* solid_list; u64* solid_count;       // compact list of solid slots (fin_mark -> fin_emit), any order
     u64* solid_dense;                        // dense ordered index of each listed slot's first sighting (-> its row, fin_order_kernel)
+    const u64* n_solid_dev;                  // non-null: fin_order / fin_emit were launched for an ESTIMATED number of rows (their grid and the capacity of the
+                                             // outputs) before the host knew the count: they take it from here and do nothing when it exceeds the estimate
     const u64* order;                        // non-null: slot of the node in row q (fin_emit then writes its rows in order: whole lines instead of
                                              // eleven scattered 2..8-byte stores per node)
     u64* o_row;                              // non-null: write node q at position q and its global row here (partitioned table)
@@ -764,6 +766,7 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
 // row of every listed solid slot (rank of its first sighting among the solid ones) -> order[row] = slot
 __global__ __launch_bounds__(256) void fin_order_kernel(FinArgs F, u64 n_solid, u64* __restrict__ order) {
     const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (F.n_solid_dev) { const u64 n = *F.n_solid_dev; if (n > n_solid) return; n_solid = n; }      // (n_solid: the estimate the launch was sized for)
     if (q >= n_solid) return;
     const u64 D = F.solid_dense[q];
     order[F.pre_solid[D >> 6] + __popcll(F.bm_solid[D >> 6] & ((1ull << (D & 63)) - 1))] = F.solid_list[q];
@@ -969,6 +972,7 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
     __shared__ u64 sh_row[256];
     const u64 q0 = (u64)blockIdx.x * 256, q = q0 + threadIdx.x;
     const u32 k = F.k;
+    if (F.n_solid_dev) { const u64 n = *F.n_solid_dev; if (n > n_solid || q0 >= n) return; n_solid = n; }      // (uniform over the workgroup)
     if (q < n_solid) {
         const u64 s = F.order ? F.order[q] : F.solid_list[q];
         const Slot e = F.tab[s];
