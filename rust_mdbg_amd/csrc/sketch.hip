@@ -71,10 +71,10 @@ static_assert(sizeof(TileRec) == 48, "three 16-byte words");
 // bread[] and the records in ONE launch: thread t runs the searches for entries t and t + 2 side by side (two dependent chains of ~20
 // loads each in flight together; two kernels in a row were 10 + 6 us and a launch)
 // init: scalars the sketch starts from (three zeroed, one set), folded in here: one launch less in front of the tile kernel
-struct SketchInit { u64* zero[3]; u64* set_p; u64 set_v; };
+struct SketchInit { u64* zero[4]; u64* set_p; u64 set_v; };
 __global__ void tile_rec_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bases, u32 n_tiles, u32* __restrict__ bread, TileRec* __restrict__ recs, SketchInit init) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) { for (int i = 0; i < 3; ++i) if (init.zero[i]) *init.zero[i] = 0; if (init.set_p) *init.set_p = init.set_v; }
+    if (t == 0) { for (int i = 0; i < 4; ++i) if (init.zero[i]) *init.zero[i] = 0; if (init.set_p) *init.set_p = init.set_v; }
     if (t >= n_tiles + 2) return;
     auto first_pos = [&](u32 e) -> u64 {
         int64_t p = (int64_t)e * TILE_STRIDE - HALO_BASES;

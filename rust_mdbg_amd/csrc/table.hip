@@ -246,9 +246,12 @@ void launch_owner_thresholds(double bound, u32 k, u32 world, u64* thr, hipStream
 constexpr int OWN_SPAN = OWN_SPAN_V;
 __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
                                                                    const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
-                                                                   u32* __restrict__ cap_err) {
+                                                                   u32* __restrict__ cap_err, const u64* __restrict__ i1_dev) {
     extern __shared__ u64 sh_keys[];           // [OWN_SPAN + k] keys, then u16 list[OWN_SPAN], then the counter
     if (cap_err[1]) return;
+    // i1_dev: launched behind the sketch of the same batch before the host knew how many minimizers it has (i1 = an upper bound the grid was
+    // sized for): the count comes from the device, workgroups behind it have nothing to do
+    if (i1_dev) { i1 = *i1_dev; if (i0 + (u64)blockIdx.x * OWN_SPAN >= i1) return; }
     const u32 k = T.ks.k;
     u16* const list = (u16*)(sh_keys + OWN_SPAN + k);
     u32* const n_own = (u32*)(list + OWN_SPAN);
@@ -580,8 +583,10 @@ void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch
 // the insert speculatively and needs one round trip per batch instead of two.  Same rule as slots_for() in api.inc.
 // The number of keys in the table is summed from its shards here (one launch less in front of every insertion).
+// carry / over_max (null: not used): the insertion was launched behind the batch's own sketch, before the host looked at it — when the sketch has to
+// be repeated (a slab or the store was too small, or the 2^32 limit) the insertion must not happen either.
 __global__ __launch_bounds__(256) void reserve_check_kernel(const u64* __restrict__ distinct_shards, u64* __restrict__ n_distinct, const u64* __restrict__ batch_windows, u64 cap,
-                                                            u32* __restrict__ too_small) {
+                                                            u32* __restrict__ too_small, const u64* __restrict__ carry, u64 store_cap, const u32* __restrict__ over_max) {
     __shared__ u64 ws[4];
     u64 v = 0;
     for (int i = threadIdx.x; i < CTR_SHARDS; i += 256) v += distinct_shards[i];
@@ -592,7 +597,9 @@ __global__ __launch_bounds__(256) void reserve_check_kernel(const u64* __restric
         const u64 nd = ws[0] + ws[1] + ws[2] + ws[3];
         *n_distinct = nd;
         const u64 n = nd + *batch_windows;
-        *too_small = n + n / 2 + 1024 > cap ? 1u : 0u;
+        bool skip = n + n / 2 + 1024 > cap;
+        if (carry) skip = skip || *carry > store_cap || *carry >= 0xFFFFFFF0ull || (over_max && *over_max);
+        *too_small = skip ? 1u : 0u;
     }
 }
 
@@ -1208,12 +1215,12 @@ void launch_clear_table(Slot* tab, u64 cap, u64* mx, u64 n_mx, hipStream_t s) {
     hipLaunchKernelGGL(clear_table_kernel, dim3(2048), dim3(256), 0, s, tab, cap, mx, n_mx);
 }
 void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 slot0,
-                           u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s) {
+                           u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s, const u64* i1_dev = nullptr) {
     if (i1 <= i0) return;
     (void)n_windows;
     const u64 n = i1 - i0;
     hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((n + OWN_SPAN - 1) / OWN_SPAN)), dim3(256),
-                       (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err);
+                       (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err, i1_dev);
 }
 // Several small regions zeroed (and one scalar set) by ONE launch: the steps between the big kernels would otherwise be chains of
 // 5-microsecond fill kernels (ten of them in front of the sketch, five in front of finalize).
@@ -1230,8 +1237,9 @@ void launch_zero_regions(const ZeroList& z, hipStream_t s) {
     const unsigned blocks = (unsigned)std::min<u64>(1024, (mx + 255) / 256);
     hipLaunchKernelGGL(zero_regions_kernel, dim3(blocks), dim3(256), 0, s, z);
 }
-void launch_reserve_check(const u64* distinct_shards, u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s) {
-    hipLaunchKernelGGL(reserve_check_kernel, dim3(1), dim3(256), 0, s, distinct_shards, n_distinct, batch_windows, cap, too_small);
+void launch_reserve_check(const u64* distinct_shards, u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s,
+                          const u64* carry = nullptr, u64 store_cap = 0, const u32* over_max = nullptr) {
+    hipLaunchKernelGGL(reserve_check_kernel, dim3(1), dim3(256), 0, s, distinct_shards, n_distinct, batch_windows, cap, too_small, carry, store_cap, over_max);
 }
 void launch_insert_records(const TableArgs& T, u64 r0, u64 r1, u64* n_windows, hipStream_t s) {
     if (r1 <= r0) return;
