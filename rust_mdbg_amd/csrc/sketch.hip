@@ -1083,7 +1083,10 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
     for (u32 j0 = 0; j0 < slots; j0 += 64) {
         const u32 j = j0 + lane;
         Rec r{}; r.read = REC_REJECTED;
-        if (j < slots) r = j0 == 0 ? pre[0] : j0 == 64 ? pre[1] : s[j];
+        if (j < slots) r = pre[0];
+        // two rounds ahead stay in flight (dense settings: thousands of records per tile, one dependent round trip per 64 of them otherwise)
+        pre[0] = pre[1];
+        if (j + 128 < slots && j + 128 < g.slab_cap) pre[1] = s[j + 128];
         const bool valid = r.read != REC_REJECTED;
         const u64 bal = __ballot(valid);
         const u64 lower = bal & ((1ull << lane) - 1ull);
