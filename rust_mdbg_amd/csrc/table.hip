@@ -1215,10 +1215,10 @@ void launch_clear_table(Slot* tab, u64 cap, u64* mx, u64 n_mx, hipStream_t s) {
     hipLaunchKernelGGL(clear_table_kernel, dim3(2048), dim3(256), 0, s, tab, cap, mx, n_mx);
 }
 void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 slot0,
-                           u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s, const u64* i1_dev = nullptr) {
+                           u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s, const u64* i1_dev = nullptr, u64 n_starts = 0) {
     if (i1 <= i0) return;
     (void)n_windows;
-    const u64 n = i1 - i0;
+    const u64 n = n_starts ? n_starts : i1 - i0;          // n_starts: only the window starts [i0, i0 + n_starts) (a slice; i1 stays the end of the batch)
     hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((n + OWN_SPAN - 1) / OWN_SPAN)), dim3(256),
                        (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err, i1_dev);
 }
@@ -1236,6 +1236,29 @@ void launch_zero_regions(const ZeroList& z, hipStream_t s) {
     for (int r = 0; r < 6; ++r) mx = z.n[r] > mx ? z.n[r] : mx;
     const unsigned blocks = (unsigned)std::min<u64>(1024, (mx + 255) / 256);
     hipLaunchKernelGGL(zero_regions_kernel, dim3(blocks), dim3(256), 0, s, z);
+}
+// A batch inserted in SLICES (dense settings: hundreds of millions of windows of which few are new keys — sizing the table for all of them would make it
+// tens of GB): before slice `id` the table must have room for `bound` more keys (one per window start of the slice at most).  The first slice that does
+// not fit sets *too_small (which makes it and every later insert kernel of the round return at once) and leaves its id; the host grows the table and
+// resumes there.
+__global__ __launch_bounds__(256) void slice_check_kernel(const u64* __restrict__ distinct_shards, u64* __restrict__ n_distinct, u64 bound, u64 cap, u32* __restrict__ too_small,
+                                                          u64* __restrict__ fail_at, u64 id) {
+    __shared__ u64 ws[4];
+    if (*too_small) return;
+    u64 v = 0;
+    for (int i = threadIdx.x; i < CTR_SHARDS; i += 256) v += distinct_shards[i];
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 nd = ws[0] + ws[1] + ws[2] + ws[3];
+        *n_distinct = nd;
+        const u64 n = nd + bound;
+        if (n + n / 2 + 1024 > cap) { *fail_at = id; *too_small = 1u; }
+    }
+}
+void launch_slice_check(const u64* distinct_shards, u64* n_distinct, u64 bound, u64 cap, u32* too_small, u64* fail_at, u64 id, hipStream_t s) {
+    hipLaunchKernelGGL(slice_check_kernel, dim3(1), dim3(256), 0, s, distinct_shards, n_distinct, bound, cap, too_small, fail_at, id);
 }
 void launch_reserve_check(const u64* distinct_shards, u64* n_distinct, const u64* batch_windows, u64 cap, u32* too_small, hipStream_t s,
                           const u64* carry = nullptr, u64 store_cap = 0, const u32* over_max = nullptr) {

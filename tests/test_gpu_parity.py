@@ -252,6 +252,25 @@ def test_batch_split_and_order_invariance():
     assert_nodes_equal(grown, exp)
 
 
+def test_dense_rounds_are_inserted_in_slices(monkeypatch):
+    """rounds with very many window starts (dense settings) go into the table slice by slice, each checked on the device against the keys the table
+    holds by then; the table grows when a slice does not fit and the round resumes there (csrc/api.inc, insert_resident_impl).  MDBG_INSERT_SLICE
+    shrinks the slice so that a small input takes that path: several slices, several growths, one and several batches — same table as the oracle"""
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(11, 120000, 300, mean_len=9000, sd_len=2000, min_len=1000, max_len=20000, err_ppm=1500)
+    k, l, d, A = 10, 12, 0.05, 2
+    exp = oracle_graph(reads, k, l, d, A)
+    plain, st0 = run_gpu(reads, k, l, d, A)
+    assert_nodes_equal(plain, exp)
+    monkeypatch.setenv("MDBG_INSERT_SLICE", "4096")
+    sliced, st1 = run_gpu(reads, k, l, d, A)
+    assert_nodes_equal(sliced, exp)
+    assert st1["n_windows"] == st0["n_windows"] and st1["n_distinct"] == st0["n_distinct"]
+    assert st1["table_capacity"] < st0["table_capacity"]                 # sized for the keys met so far, not for every window of the round
+    batched, _ = run_gpu(reads, k, l, d, A, batches=[(0, 100), (100, 101), (101, 300)])
+    assert_nodes_equal(batched, exp)
+
+
 def test_strict_k_and_palindromes():
     rnd = random.Random(21)
     s = bytes(rnd.choice(b"ACGT") for _ in range(6000))
