@@ -470,7 +470,12 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
     const int64_t raw0 = (int64_t)gt * TILE_STRIDE - HALO_BASES;      // first staged raw position (negative for tile 0)
     const bool interior = raw0 >= 0 && raw0 + RW * 32 <= nb;
     const TileRec* const rec = a.recs + gt;
-    const int64_t first_base = rec->first_base;       // positions in front of it belong to no read
+    // (the record is read with vector loads — the compiler cannot prove it read-only —, so what is the same in every lane is moved to scalar
+    // registers by hand: the conditions below then branch on SCC instead of travelling through the phases as lane masks)
+    auto uniform64 = [](int64_t v) -> int64_t {
+        return (int64_t)((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)v >> 32)) << 32 | (u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)v));
+    };
+    const int64_t first_base = uniform64(rec->first_base);       // positions in front of it belong to no read
 
     // ---- phase 1: load (issued first: everything below hides under its latency), read starts, planes -------------------
     u32 x0[WPT], x1[WPT], pv0 = 0, pv1 = 0;          // my raw words (MSB first); pv*: bit 0 = the base in front of them
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         }
         if (tid && pi0 - 1 >= 0 && pi0 - 1 < n_pairs) { const uint2 q = a.planes[pi0 - 1]; pv0 = q.x >> 31; pv1 = q.y >> 31; }
     }
-    const u32 rl = rec->rl, rh_ = rec->rh;
+    const u32 rl = (u32)__builtin_amdgcn_readfirstlane((int)rec->rl), rh_ = (u32)__builtin_amdgcn_readfirstlane((int)rec->rh);
     static_assert((2 * (DPAD + RW + 4)) % 4 == 0, "the dense stream is a whole number of 16-byte words");
     for (int i = tid; i < 2 * (DPAD + RW + 4) / 4; i += TT) ((uint4*)S.dense)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (SCHEME == 0) { if (tid < (2 << (2 * BS_GS))) S.t3[tid] = a.t4[tid]; }
@@ -565,6 +570,20 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
     u32 kw[WPT], n_kept[WPT], mine = 0;
     {
         const int64_t lo = first_base - raw0, hi = nb - raw0;        // existing positions, tile-relative
+        if (interior && lo <= 0 && hpc) {
+            // the usual tile (every staged position exists, homopolymer compression on) on a path of its own: decided once, in scalar registers —
+            // folded into the general loop below the compiler carried both conditions through every word as lane masks
+            const uint4 st = *(const uint4*)(S.dense + WPT * tid);          // read-start bits of my four words
+            *(uint4*)(S.dense + WPT * tid) = make_uint4(0u, 0u, 0u, 0u);    // consumed: back to an empty dense stream
+            const u32 sb[WPT] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const u32 d0 = bs_alignbit(i ? x0[i - 1] : pv0, x0[i], 1), d1 = bs_alignbit(i ? x1[i - 1] : pv1, x1[i], 1);
+                u32 k = (x0[i] ^ d0) | (x1[i] ^ d1) | sb[i];
+                if (i == 0) k |= tid == 0 ? 0x80000000u : 0u;     // nothing staged in front of the tile's first position
+                kw[i] = k; n_kept[i] = bs_popc(k); mine += n_kept[i];
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {                      // keep masks first: they look at the neighbouring raw word
             const int w = WPT * tid + i;
@@ -577,6 +596,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
             }
             S.dense[w] = 0;                                  // the read-start bitmap has been consumed: back to an empty dense stream
             kw[i] = k; n_kept[i] = bs_popc(k); mine += n_kept[i];
+        }
         }
         if (hpc) {                                           // (wave-uniform: no exec juggling per word)
 #pragma unroll
