@@ -284,10 +284,15 @@ def main():
     fence()
     if routed and cdist is None and not replicate:
         runner.times = {}
+    # the tile kernel's HIP-event time of EVERY timed step (the context's timers restart with each reset): host-side reads of a struct, no device sync
+    tile_acc = {"ms_sketch_tile": 0.0, "n_sketch_tile_launches": 0, "n_sketch_tile_bases": 0}
     t0 = time.perf_counter()
     n_nodes = 0
     for _ in range(args.steps):
         n_nodes = step()
+        sti = api_stats_of(cdist) if cdist is not None else m.stats()
+        for f in tile_acc:
+            tile_acc[f] += sti[f]
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -346,7 +351,9 @@ def main():
                     "algorithmic_bytes_per_launch": alg / stt["n_sketch_tile_launches"], "launches_per_step": stt["n_sketch_tile_launches"],
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_base": per_base,
                     "kernel_gbases_per_s": stt["n_sketch_tile_bases"] / (stt["ms_sketch_tile"] * 1e-3) / 1e9}
-        roof = roofline(st, 0.25 if packed else 1.0, args.input)
+        roof = roofline(dict(st, **tile_acc), 0.25 if packed else 1.0, args.input)          # the kernel's average launch duration over all timed steps
+        if roof:
+            roof["launches_per_step"] = tile_acc["n_sketch_tile_launches"] / max(1, args.steps); roof["launches_timed"] = tile_acc["n_sketch_tile_launches"]
         if roof:
             roof["traffic"], roof["traffic_source"] = pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args)
             sq = sq_counters(args)
