@@ -116,7 +116,7 @@ def pmc_traffic(bases_per_launch, args, fmt=None):
         try:
             j = json.load(open(p))
             ref = json.load(open(p.replace("_pmc_traffic.json", "_bench.json")))
-            k = j["kernels"]["sketch_bs_kernel<%d>" % args.l]
+            k = next(v for n, v in j["kernels"].items() if n.startswith("sketch_bs_kernel<%d>" % args.l) or n.startswith("sketch_bs_kernel<%d," % args.l))
             c = ref["config"]
             same = (c["k"], c["l"], c["density"], c["minabund"], c.get("input_format")) == (args.k, args.l, args.density, args.minabund, args.input) and \
                 abs(c["bases_per_gpu"] / ref["roofline"]["launches_per_step"] - bases_per_launch) < 1e-6 * bases_per_launch
