@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genome-mb", type=float, default=None, help="genome size per GPU in Mb (default: 140 at N=1, 375 at N>1)")
     ap.add_argument("--coverage", type=float, default=None, help="default: 50 at N=1, 52 at N>1")
     ap.add_argument("-k", type=int, default=35)
