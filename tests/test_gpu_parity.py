@@ -271,6 +271,35 @@ def test_dense_rounds_are_inserted_in_slices(monkeypatch):
     assert_nodes_equal(batched, exp)
 
 
+def test_second_batch_overflows_its_slabs_behind_a_speculative_insertion():
+    """from the second batch on the window count, capacity check and insertion are launched BEHIND the batch's sketch, before the host has looked at
+    it (csrc/api.inc, sketch_device_impl `fused`).  A batch whose tiles hold far more minimizers than the density predicts makes the sketch run again
+    with larger slabs: the speculative insertion must have done nothing, the repeated round must insert exactly once.  Graph == oracle."""
+    from rust_mdbg_amd import synth
+    plain = synth.synth_reads(21, 100000, 120, mean_len=9000, sd_len=2000, min_len=1000, max_len=20000, err_ppm=1000)
+    k, l, d, A = 6, 12, 0.004, 2
+    R = _mdbg()
+    b0, o0 = O.concat_reads(plain)
+    sk = O.sketch(b0, o0, l, d)
+    # an l-mer of the data whose hash is below the threshold, repeated: every 12th position of such a read is a minimizer (25 x the density)
+    r0 = next(r for r in range(len(plain)) if sk["off"][r + 1] > sk["off"][r])
+    p = int(sk["pos"][sk["off"][r0]])
+    unit = bytes(plain[r0][p:p + 400])
+    hp = bytearray()
+    for c in unit:                       # the l-mer as the sketch saw it: homopolymer-compressed
+        if not hp or hp[-1] != c:
+            hp.append(c)
+    unit = bytes(hp[:l])
+    assert len(unit) == l and unit[0] != unit[-1]
+    dense = [unit * 6000, unit * 9000, plain[3] + unit * 5000 + plain[4]]
+    reads = plain + dense
+    exp = oracle_graph(reads, k, l, d, A)
+    got, st = run_gpu(reads, k, l, d, A, batches=[(0, len(plain)), (len(plain), len(reads))])
+    assert_nodes_equal(got, exp)
+    three, _ = run_gpu(reads, k, l, d, A, batches=[(0, 60), (60, len(plain) + 1), (len(plain) + 1, len(reads))])
+    assert_nodes_equal(three, exp)
+
+
 def test_strict_k_and_palindromes():
     rnd = random.Random(21)
     s = bytes(rnd.choice(b"ACGT") for _ in range(6000))
