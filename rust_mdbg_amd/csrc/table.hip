@@ -469,6 +469,7 @@ __global__ void seg_pick_kernel(const u64* __restrict__ pre, const u32* __restri
     const u64 j = b < B.n ? B.start[b] : n;
     out[b] = j < n ? pre[j] : (n ? pre[n - 1] + add[n - 1] : 0);
 }
+__device__ inline bool listed_check(u64 j) { return (((u32)j * 0x9E3779B1u) >> 28) == 0; }      // one list entry in 16
 // inserts exactly the listed windows of the batch whose minimizers start at m0 (keys are read from the resident store)
 __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
                                                                     u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
@@ -484,7 +485,9 @@ __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T,
     }
     if (ok) {                                      // a wrong list is caught by the count check
         rs = roff[slot]; const u64 re = roff[slot + 1];
-        ok = i >= rs && re - rs > k && i + k <= re && window_owner(mh + i, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank;
+        // (ownership is re-derived for one entry in 16: it costs the window's k values once more, and a sender that disagrees about the owner function
+        // — the one realistic fault: parameters or the measured table differing between ranks — is wrong for millions of entries, not for one)
+        ok = i >= rs && re - rs > k && i + k <= re && (!listed_check(j) || window_owner(mh + i, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank);
     }
     wave_count_add(ok, T.own_inserted);
     if (!ok) return;
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(256) void insert_listed_span_kernel(TableArgs T, co
         }
         if (ok) {                                  // a wrong list is caught by the count check
             rs = roff[slot]; const u64 re = roff[slot + 1];
-            ok = i >= rs && re - rs > k && i + k <= re && window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank;
+            ok = i >= rs && re - rs > k && i + k <= re && (!listed_check(j) || window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank);
         }
         wave_count_add(ok, T.own_inserted);
         if (!ok) continue;
@@ -574,7 +577,12 @@ void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u
                           u32 n_reads, u64 first_ordinal, u32* cap_err, hipStream_t s) {
     if (!n) return;
     const size_t lds = ((size_t)OWNL_SPAN + T.ks.k) * sizeof(u64);
-    if (seg && lds <= 64 * 1024)
+    // few listed windows per span (a rank's share of a sketch at 4+ ranks): staging every span of the sketch would mostly fetch hashes nobody needs, and
+    // a workgroup would work off a few dozen entries; the per-entry kernel reads each window's values where they lie
+    u64 per_span_min = 150;
+    { const char* v = getenv("MDBG_LISTED_SPAN_MIN"); if (v) per_span_min = strtoull(v, nullptr, 10); }
+    const bool sparse = n < (u64)owner_list_spans(m1 - m0) * per_span_min;
+    if (seg && lds <= 64 * 1024 && !sparse)
         hipLaunchKernelGGL(insert_listed_span_kernel, dim3(owner_list_spans(m1 - m0)), dim3(256), lds, s, T, mh, mread, roff, m0, m1, list, seg, n, slot0, n_reads, first_ordinal, cap_err);
     else       // very long k: the span does not fit the default LDS window, every window reads its values from HBM
         hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err);
@@ -1044,18 +1052,35 @@ __device__ inline u32 batch_of_ordinal(const FinArgs& F, u64 ord) {
     while (lo < hi) { const u32 mid = lo + ((hi - lo + 1) >> 1); if (F.bt.first_ordinal[mid] <= ro) lo = mid; else hi = mid - 1; }
     return lo;
 }
+// (Per-peer counts and slots go through LDS: one global atomic per peer and workgroup.  One per node on `world` addresses was 6 ms per finalize at 8
+// ranks — same-address atomics serialise.)
 __global__ __launch_bounds__(256) void pos_query_kernel(FinArgs F, u64 n_solid, PosQueryArgs Q) {
+    __shared__ u32 cnt[OWNL_MAX_WORLD];
+    __shared__ u64 base[OWNL_MAX_WORLD];
+    if (threadIdx.x < OWNL_MAX_WORLD) cnt[threadIdx.x] = 0;
+    __syncthreads();
     const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (q >= n_solid) return;
-    const u64 s = F.solid_list[q];
-    const Slot e = F.tab[s];
-    const SlotView v = slot_view(e, s, F.mx, F.casc, F.A, rep_ordinal(F, e.word), F.ath_override);
-    const u32 src = Q.batch_src[batch_of_ordinal(F, v.ath)];
-    if (src == Q.me || src >= Q.world) return;
-    if (Q.pass == 0) { atomicAdd(&Q.counts[src], 1ull); return; }
-    const u64 at = Q.offs[src] + atomicAdd(&Q.fill[src], 1ull);
-    u64 i, D; decode_ordinal(F, v.ath, i, D);
-    Q.q_ord[at] = v.ath; Q.q_idx[at] = i;
+    u32 src = 0xFFFFFFFFu, local = 0; u64 ath = 0;
+    if (q < n_solid) {
+        const u64 s = F.solid_list[q];
+        const Slot e = F.tab[s];
+        const SlotView v = slot_view(e, s, F.mx, F.casc, F.A, rep_ordinal(F, e.word), F.ath_override);
+        ath = v.ath;
+        src = Q.batch_src[batch_of_ordinal(F, ath)];
+        if (src == Q.me || src >= Q.world || src >= OWNL_MAX_WORLD) src = 0xFFFFFFFFu;
+        else local = atomicAdd(&cnt[src], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < Q.world && threadIdx.x < OWNL_MAX_WORLD && cnt[threadIdx.x]) {
+        if (Q.pass == 0) atomicAdd(&Q.counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+        else base[threadIdx.x] = atomicAdd(&Q.fill[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+    }
+    if (Q.pass == 0) return;
+    __syncthreads();
+    if (src == 0xFFFFFFFFu) return;
+    const u64 at = Q.offs[src] + base[src] + local;
+    u64 i, D; decode_ordinal(F, ath, i, D);
+    Q.q_ord[at] = ath; Q.q_idx[at] = i;
 }
 // answers: {p[0], p[1], p[k-2], p[k-1]} of the window with the given ordinal in THIS rank's store; *bad counts ordinals that are not
 // windows of a batch this rank sketched (a protocol error)

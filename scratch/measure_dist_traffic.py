@@ -83,7 +83,7 @@ def body(rank):
             assert gen.pack_device(db, nb, words.data_ptr(), exc[0].data_ptr(), exc[1].data_ptr(), 64) == 0
             pb = api.PackedBatch(words.data_ptr(), do, n_reads, 0, 0, 0)
             out = {}
-            for whole in (0, 1):
+            for whole in ((0,) if os.environ.get("MODES") == "segments" else (1,) if os.environ.get("MODES") == "whole" else (0, 1)):
                 assert L.mdbg_dist_set_exchange(h, whole) == 0 and L.mdbg_dist_set_pipeline(h, chunks) == 0
                 ts = []
                 for step in range(3):
@@ -106,7 +106,7 @@ th = [threading.Thread(target=body, args=(r,)) for r in range(W)]
 [t.start() for t in th]; [t.join() for t in th]
 if errs: raise errs[0]
 summ = {"world": W, "config": cfg, "chunks": chunks, "k": k, "l": l, "density": d, "reads_per_rank": n_reads}
-for mode in ("segments", "whole"):
+for mode in [m_ for m_ in ("segments", "whole") if m_ in res[0]]:
     bi = [res[r][mode]["bytes_in_per_step"] for r in range(W)]
     summ[mode] = dict(bytes_in_per_rank_per_step_max=max(bi), bytes_in_per_rank_per_step_mean=float(np.mean(bi)), nodes_global=res[0][mode]["nodes_global"],
                       nodes_local=[res[r][mode]["nodes_local"] for r in range(W)], ms_per_step_all_ranks_on_one_gpu=res[0][mode]["ms_per_step_all_ranks_on_one_gpu"],
