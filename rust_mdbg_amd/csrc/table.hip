@@ -471,16 +471,27 @@ __global__ void seg_pick_kernel(const u64* __restrict__ pre, const u32* __restri
 }
 __device__ inline bool listed_check(u64 j) { return (((u32)j * 0x9E3779B1u) >> 28) == 0; }      // one list entry in 16
 // inserts exactly the listed windows of the batch whose minimizers start at m0 (keys are read from the resident store)
+// multi (non-null): the lists of SEVERAL batches in one launch — entry j belongs to batch b with multi[b].start <= j < multi[b + 1].start (n_multi batches
+// and a closing entry); the per-batch arguments then come from the table.  (At 8 ranks and two chunks per step a rank inserts from 16 listed batches:
+// 16 launches of ~0.4 M windows each.)
+struct ListedBatch { u64 start, m0, m1, first_ordinal; const u32* list; u32 slot0, n_reads; };
 __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
                                                                     u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
-                                                                    u32* __restrict__ cap_err) {
+                                                                    u32* __restrict__ cap_err, const ListedBatch* __restrict__ multi, u32 n_multi) {
     if (cap_err[1]) return;
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 k = T.ks.k;
     bool ok = j < n;
     u64 i = 0, rs = 0; u32 slot = 0;
+    u64 jl = j;
+    if (ok && multi) {
+        u32 lo = 0, hi = n_multi - 1;
+        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (multi[mid].start <= j) lo = mid; else hi = mid - 1; }
+        const ListedBatch b = multi[lo];
+        m0 = b.m0; m1 = b.m1; list = b.list; slot0 = b.slot0; n_reads = b.n_reads; first_ordinal = b.first_ordinal; jl = j - b.start;
+    }
     if (ok) {
-        const uint2 e = ((const uint2*)list)[j];
+        const uint2 e = ((const uint2*)list)[jl];
         i = m0 + e.x; slot = slot0 + e.y; ok = e.y < n_reads && i + k <= m1;
     }
     if (ok) {                                      // a wrong list is caught by the count check
@@ -585,7 +596,19 @@ void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u
     if (seg && lds <= 64 * 1024 && !sparse)
         hipLaunchKernelGGL(insert_listed_span_kernel, dim3(owner_list_spans(m1 - m0)), dim3(256), lds, s, T, mh, mread, roff, m0, m1, list, seg, n, slot0, n_reads, first_ordinal, cap_err);
     else       // very long k: the span does not fit the default LDS window, every window reads its values from HBM
-        hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err);
+        hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err,
+                           (const ListedBatch*)nullptr, 0u);
+}
+// true: launch_insert_listed would take the per-entry kernel for this batch (then several such batches can share one launch, launch_insert_listed_multi)
+bool listed_is_sparse(const TableArgs& T, u64 m0, u64 m1, u64 n) {
+    u64 per_span_min = 150;
+    { const char* v = getenv("MDBG_LISTED_SPAN_MIN"); if (v) per_span_min = strtoull(v, nullptr, 10); }
+    return n < (u64)owner_list_spans(m1 - m0) * per_span_min || ((size_t)OWNL_SPAN + T.ks.k) * sizeof(u64) > 64 * 1024;
+}
+void launch_insert_listed_multi(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, const ListedBatch* d_batches, u32 n_batches, u64 total, u32* cap_err, hipStream_t s) {
+    if (!total) return;
+    hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, 0ull, 0ull, (const u32*)nullptr, total, 0u, 0u, 0ull, cap_err,
+                       d_batches, n_batches);
 }
 
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch
