@@ -84,7 +84,6 @@ struct TableArgs {
     const u64* own_thr;           // see OwnerSpec
     u32* probe_err;               // set when a probe sequence visited every slot: the table was sized from a wrong window count
     u64* own_inserted;            // sharded counter: owned windows actually inserted (checked against the senders' counts)
-    u32 exp;                      // diagnostic (MDBG_INSERT_EXP): parts of insert_windows_kernel switched off to time the rest (results are wrong)
 };
 
 // Home slot of a key hash: range reduction by multiplication, so the capacity need not be a power of two.  It is fed
@@ -288,13 +287,12 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
         const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
         const u64* w = sh_keys + li;
         const bool rev = window_reversed(w, k);
-        const u64 h = (T.exp & 8u) ? fmix64(w[0] + 3 * w[k - 1] + 5 * w[k / 2]) : key_hash_window(w, k, rev);
-        if (T.exp & 16u) { if (h == 12345u) *cap_err = 1; continue; }
+        const u64 h = key_hash_window(w, k, rev);
         bool claimed;
-        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return (T.exp & 1u) ? true : same_key_window(T.ks, word, w, rev); }, claimed);
+        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
         if (claimed || s == ~0ull) continue;
-        if (!(T.exp & 4u)) atomicAdd(&T.tab[s].count, 1u);
-        if (!(T.exp & 2u)) push_ordinal(T, s, ord);
+        atomicAdd(&T.tab[s].count, 1u);
+        push_ordinal(T, s, ord);
     }
 }
 
