@@ -21,8 +21,9 @@ def _digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def _run_ranks(W, k, l, d, A, feed, chunks, whole):
-    """feed(rank, gen) -> (d_bases, d_offsets, n_reads, n_bases, first_ordinal) in DEVICE memory (kept alive by the caller); -> list of partitions"""
+def _run_ranks(W, k, l, d, A, feed, chunks, whole, rounds=1, scheme=0, syncmer_s=0):
+    """feed(rank, gen[, round]) -> (d_bases, d_offsets, n_reads, n_bases, first_ordinal) in DEVICE memory (kept alive by the caller; n_reads = 0: the rank
+    has nothing for the round); -> list of partitions"""
     from rust_mdbg_amd import api, dist_c
     import rust_mdbg_amd as R
     L = api.load_library()
@@ -40,15 +41,16 @@ def _run_ranks(W, k, l, d, A, feed, chunks, whole):
     def body(rank):
         try:
             cm, keep = world.comm(rank)
-            P = api.Params(k=k, l=l, density=d, min_abundance=A, reads_already_hpc=0, device=0, flags=0, table_capacity_hint=0)
+            P = api.Params(k=k, l=l, density=d, min_abundance=A, reads_already_hpc=0, device=0, flags=0, table_capacity_hint=0, scheme=scheme, syncmer_s=syncmer_s)
             err = C.c_int()
             h = L.mdbg_dist_create(C.byref(P), C.byref(cm), C.byref(err))
             assert h, err.value
             assert L.mdbg_dist_set_pipeline(h, chunks) == 0 and L.mdbg_dist_set_exchange(h, 1 if whole else 0) == 0
             with R.Mdbg(k, l, d, A, device=0) as gen:
-                db, do, n_reads, nb, first = feed(rank, gen)
-                e = L.mdbg_dist_ingest_batch_device(h, db, do, n_reads, nb, first)
-                assert e == 0, e
+                for rd in range(rounds):
+                    db, do, n_reads, nb, first = feed(rank, gen) if rounds == 1 else feed(rank, gen, rd)
+                    e = L.mdbg_dist_ingest_batch_device(h, db, do, n_reads, nb, first)
+                    assert e == 0, e
                 nd, row, ng = api.Nodes(), C.c_void_p(), C.c_uint64()
                 e = L.mdbg_dist_finalize(h, C.byref(nd), C.byref(row), C.byref(ng))
                 assert e == 0, e
@@ -138,3 +140,32 @@ def test_wrapped_abundances_across_ranks(whole, chunks):
     assert ref["n_nodes"] >= 3 and ref["n_wrapped"] >= ref["n_nodes"] - 2 and int(np.max(ref["src_read"])) > 200
     _assert_partitions_equal(parts, ref)
     assert sum(p["n_wrapped"] for p in parts) == ref["n_wrapped"]
+
+
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_syncmer_scheme_and_uneven_rounds_across_three_ranks(chunks):
+    """the syncmer scheme through the multi-GPU layer (its hash bound is density * 4^l: the owner thresholds and the measured table are built from that), three
+    rounds per rank of which one rank sits out the second (n_reads = 0) and another the third"""
+    import rust_mdbg_amd as R
+    W, k, l, s_, d, per = 3, 10, 12, 4, 0.05, 1500
+    genome = 6_000_000
+
+    def first_of(rank, rd):
+        return (rd * W + rank) * per
+
+    def feed(rank, gen, rd):
+        if (rank, rd) in ((1, 1), (2, 2)):
+            return None, None, 0, 0, first_of(rank, rd)
+        db, do, nb = gen.synth_reads_device(seed=5, genome_len=genome, n_reads=per, mean_len=9000, sd_len=1500, min_len=2000, max_len=16000, err_ppm=2000, first_read=first_of(rank, rd))
+        return db, do, per, nb, first_of(rank, rd)
+    parts = _run_ranks(W, k, l, d, 2, feed, chunks=chunks, whole=False, rounds=3, scheme=1, syncmer_s=s_)
+    with R.Mdbg(k, l, d, 2, device=0, syncmer_s=s_) as one, R.Mdbg(k, l, d, 2, device=0) as gen:
+        for rd in range(3):
+            for r in range(W):
+                if (r, rd) in ((1, 1), (2, 2)):
+                    continue
+                db, do, nb = gen.synth_reads_device(seed=5, genome_len=genome, n_reads=per, mean_len=9000, sd_len=1500, min_len=2000, max_len=16000, err_ppm=2000, first_read=first_of(r, rd))
+                one.ingest_device(db, do, per, nb, first_of(r, rd))
+        ref = one.finalize()
+    assert ref["n_nodes"] > 1000
+    _assert_partitions_equal(parts, ref)
