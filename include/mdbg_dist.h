@@ -17,6 +17,9 @@
  *
  * Every call below is COLLECTIVE: all ranks call it the same number of times, in the same order (a rank that has run out of reads
  * passes n_reads = 0).  Error codes and conventions are those of mdbg_hip.h.
+ * The first round compares library version (MDBG_ABI_VERSION), exchange mode, chunks per call and the sketch parameters over the ranks: a
+ * rank that differs makes every rank's call return MDBG_E_PARAM.  The same round measures where the windows' smallest hashes fall and deals the
+ * value range out to the ranks evenly (mdbg_dist_set_exchange); that assignment holds for the lifetime of the mdbg_dist.
  */
 #ifndef MDBG_DIST_H
 #define MDBG_DIST_H

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MDBG_ABI_VERSION 2
+#define MDBG_ABI_VERSION 3      /* 3: the owner of a k-min-mer is a function of its smallest hash (ranks of a multi-GPU job must run the same version) */
 
 enum {
     MDBG_OK = 0,

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert sorted(api.EXPORTS) == syms
-    assert L.mdbg_abi_version() == 2
+    assert L.mdbg_abi_version() == 3
     assert L.mdbg_strerror(0) == b"ok" and b"ACGTN" in L.mdbg_strerror(-2)
 
 

@@ -169,3 +169,44 @@ def test_syncmer_scheme_and_uneven_rounds_across_three_ranks(chunks):
         ref = one.finalize()
     assert ref["n_nodes"] > 1000
     _assert_partitions_equal(parts, ref)
+
+
+def test_ranks_that_disagree_about_the_exchange_are_told_so():
+    """every rank must run the same library version, exchange mode, chunk count and sketch parameters; the first round compares them and fails on every rank
+    (MDBG_E_PARAM) instead of hanging in a mismatched exchange"""
+    from rust_mdbg_amd import api, dist_c
+    import rust_mdbg_amd as R
+    L = api.load_library()
+    L.mdbg_dist_create.restype = C.c_void_p
+    L.mdbg_dist_create.argtypes = [C.POINTER(api.Params), C.POINTER(dist_c.Comm), C.POINTER(C.c_int)]
+    L.mdbg_dist_ingest_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.mdbg_dist_set_exchange.argtypes = [C.c_void_p, C.c_uint32]
+    L.mdbg_dist_destroy.argtypes = [C.c_void_p]
+    W = 2
+    world = ThreadWorld(W)
+    rc = [None] * W
+    errs = []
+
+    def body(rank):
+        try:
+            cm, keep = world.comm(rank)
+            P = api.Params(k=9, l=12, density=0.004, min_abundance=2, reads_already_hpc=0, device=0, flags=0, table_capacity_hint=0)
+            err = C.c_int()
+            h = L.mdbg_dist_create(C.byref(P), C.byref(cm), C.byref(err))
+            assert h, err.value
+            assert L.mdbg_dist_set_exchange(h, rank) == 0            # rank 0: segments, rank 1: whole sketches
+            with R.Mdbg(9, 12, 0.004, 2, device=0) as gen:
+                db, do, nb = gen.synth_reads_device(seed=2, genome_len=150000, n_reads=100, mean_len=9000, sd_len=1500, min_len=2000, max_len=16000, first_read=rank * 100)
+                rc[rank] = L.mdbg_dist_ingest_batch_device(h, db, do, 100, nb, rank * 100)
+            world.bar.wait()
+            L.mdbg_dist_destroy(h)
+        except BaseException as ex:          # noqa: BLE001
+            errs.append(ex)
+            world.bar.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    assert rc == [-1, -1], rc          # MDBG_E_PARAM on both
