@@ -693,6 +693,8 @@ struct FinArgs {
     u64* o_row;                              // non-null: write node q at position q and its global row here (partitioned table)
     const u64* ath_override;                 // [Slot.pad - 1]: sighting whose metadata a node that wrapped its u16 abundance keeps (null: none)
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
+    u8* by_first; u8* by_solid;              // the same as one BYTE per index (zeroed): fin_mark sets bytes with plain stores — 3.9 M device-scope atomics on the
+                                             // bitmaps were most of its time —, bytes_to_bits_kernel packs them into the bitmaps
     const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
     u64* sh_solid; u64* sh_wrapped; u64* sh_distinct;   // sharded counters (CTR_SHARDS u64 each)
     // outputs (device), node order = rank of first sighting among solid nodes
@@ -772,8 +774,8 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
                 D = dense_of_index(F, (u32)e[u].word);
                 if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < D) D = D1; }
             }
-            atomicOr((unsigned long long*)&F.bm_first[D >> 6], 1ull << (D & 63));
-            if (solid[u]) atomicOr((unsigned long long*)&F.bm_solid[D >> 6], 1ull << (D & 63));
+            F.by_first[D] = 1;                       // (distinct keys have distinct first sightings: nobody else writes this byte)
+            if (solid[u]) F.by_solid[D] = 1;
         }
         dense[u] = D;
         m[u] = __ballot(solid[u]);
@@ -798,6 +800,26 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
             const u64 j = bbase + wcnt[16 * u + wv] + __popcll(m[u] & ((1ull << lane) - 1));
             F.solid_list[j] = s0 + 1024ull * u; F.solid_dense[j] = dense[u];
         }
+}
+// bitmap word w <- bit i = (byte 64 w + i != 0), for both maps; one thread per word (four 16-byte loads per map)
+__global__ __launch_bounds__(256) void bytes_to_bits_kernel(const u8* __restrict__ by0, const u8* __restrict__ by1, u64 n_words, u64* __restrict__ bm0, u64* __restrict__ bm1) {
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    auto pack = [](const u8* p) -> u64 {
+        u64 out = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = ((const uint4*)p)[q];
+            const u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out |= (u64)((((x[j] & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (16 * q + 4 * j);      // bytes hold 0 or 1: four of them -> four bits, byte 0 lowest
+        }
+        return out;
+    };
+    bm0[w] = pack(by0 + 64 * w); bm1[w] = pack(by1 + 64 * w);
+}
+void launch_bytes_to_bits(const u8* by0, const u8* by1, u64 n_words, u64* bm0, u64* bm1, hipStream_t s) {
+    if (n_words) hipLaunchKernelGGL(bytes_to_bits_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, by0, by1, n_words, bm0, bm1);
 }
 // row of every listed solid slot (rank of its first sighting among the solid ones) -> order[row] = slot
 __global__ __launch_bounds__(256) void fin_order_kernel(FinArgs F, u64 n_solid, u64* __restrict__ order) {
