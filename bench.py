@@ -10,7 +10,9 @@ table is partitioned by key range; the ranks exchange the hashes of their sketch
 (include/mdbg_dist.h; default) or route the k-min-mer occurrences to their owner with one RCCL all-to-all per step (--dist-mode route;
 rust_mdbg_amd/dist.py).  `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, one rank per GPU) and exits
 non-zero when fewer than N GPUs are visible; under an external launcher WORLD_SIZE must equal --gpus; `n_gpus` in the line is the
-number of ranks that took part in an all-reduce.
+number of ranks that took part in an all-reduce.  At N>1 the line also carries `no_exchange_anchor`: the same ranks, each pushing its own shard through one local
+context right after the timed region (no exchange, table not partitioned) — N=1 of this script is another workload (configs[2]), so the weak-scaling efficiency of
+the multi-GPU path for ITS workload is value / no_exchange_anchor.value.
 The reads sit in HBM in the north star's layout, packed 2 bits per base (--input ascii: one byte per base).
 
 Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_bs_kernel) as fed in the timed region and
@@ -319,6 +321,34 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tsum)
         exchange = {"mode": args.dist_exchange, "chunks_per_step": n_chunks, "bytes_in_busiest_rank_per_step": int(tmax[0].item()), "bytes_in_mean_per_step": float(tsum[0].item()) / world,
                     "nodes_busiest_rank_over_mean": (float(tmax[1].item()) * world / float(tsum[1].item())) if int(tsum[1].item()) else None}
+    anchor = None
+    if cdist is not None:    # outside the timed region: what the same ranks do WITHOUT the exchange — every rank pushes its own shard through one local context
+        # (table not partitioned).  N x this rate is the ceiling of the weak-scaling curve on this node for THIS workload; the N=1 line of `bench.py` is another
+        # workload (configs[2]), so value / anchor.value is the efficiency the exchange and the partitioning leave.
+        t_loc = -1.0
+        try:
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize(); m.sync()
+                t1 = time.perf_counter()
+                m.reset(0)
+                if packed:
+                    m.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
+                else:
+                    m.ingest_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
+                m.finalize_device()
+                m.sync()
+                ts.append(time.perf_counter() - t1)
+            t_loc = min(ts[1:])          # the first pass sizes the store and the table
+            m.reset(0)
+        except Exception as ex:          # (the line above it is the result; a failure here must not lose it — but every rank still joins the all-reduce)
+            print("bench.py: local anchor pass failed on rank %d: %r" % (rank, ex), file=sys.stderr)
+        ta = torch.tensor([t_loc, -t_loc], device="cuda", dtype=torch.float64)
+        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        t_max, t_min = float(ta[0].item()), -float(ta[1].item())
+        if t_min > 0:
+            anchor = {"what": "the same %d rank(s), each pushing its own shard through one local context: no exchange, table not partitioned (after the timed region; "
+                              "slowest rank)" % world, "value": total_bases / t_max / 1e9, "unit": "Gbases/s", "ms_per_step": t_max * 1e3}
     st = m.stats()          # stats of the last step only (reset clears the timers)
     if cdist is not None:
         m_stats = api_stats_of(cdist)
@@ -382,7 +412,7 @@ def main():
             e = m.graph_edges_device(0.01)
             edges = {"ms": (time.perf_counter() - t1) * 1e3, "n_edges": int(e.n), "presimp_removed": int(e.presimp_removed)}
         cpu = None
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:          # rank 0 at N=1 only: at N>1 the other ranks would wait for it
             cpu = cpu_baseline(m, d_bases, d_off, reads_per_gpu, n_bases, args)
         graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
         want = expected_graph(args, world, reads_per_gpu, n_bases)
@@ -403,7 +433,7 @@ def main():
                          "checked_against_recorded_counts": want is not None,
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent},
-               "exchange": exchange, "edges_after_timed_region": edges}
+               "exchange": exchange, "no_exchange_anchor": anchor, "edges_after_timed_region": edges}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     if cdist is not None:
