@@ -24,6 +24,12 @@ def test_library_exports_every_declared_symbol():
     assert L.mdbg_strerror(0) == b"ok" and b"ACGTN" in L.mdbg_strerror(-2)
 
 
+def test_build_hook_checks_agree_with_the_tree():
+    """the checks __graft_entry__.build() runs behind the compile step (it once kept an ABI version of its own)"""
+    import __graft_entry__ as G
+    G.check_built()
+
+
 def test_emit_library_exports_every_declared_symbol():
     from rust_mdbg_amd import emit
     h = open(os.path.join(ROOT, "include", "mdbg_emit.h")).read()
