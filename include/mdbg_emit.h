@@ -47,7 +47,10 @@ int mdbg_seqfile_close(mdbg_seqfile* f);
 /* ---- host ingest: FASTA / FASTQ, optionally gzip-compressed, into the batch layout of
  * mdbg_ingest_batch.  Mirrors get_reader + the seq_io readers of the reference (src/main.rs:163-178,461-467,830-839):
  * the format is decided by the FILE NAME (".fa"/".fasta" suffix or ".fa."/".fasta." inside -> FASTA, anything else ->
- * FASTQ), ".gz" is read through zlib, ".lz4" through a built-in LZ4 frame decoder (the image has no liblz4).  Like seq_io's RefRecord::seq(), a multi-line
+ * FASTQ); a regular file that starts with the gzip magic is mapped and inflated by the library's own decoder (csrc/gz_inflate.h: concatenated
+ * members like the reference's MultiGzDecoder, CRC-32 and length of every member checked, ~3x zlib's rate; a damaged or truncated stream makes
+ * mdbg_reader_next return MDBG_E_IO), other input goes through zlib's gzread (which passes plain text through), ".lz4" through a built-in LZ4
+ * frame decoder (the image has no liblz4).  Like seq_io's RefRecord::seq(), a multi-line
  * FASTA record keeps its interior line terminators unless strip_newlines is set (the reference strips them only with
  * --reference, src/main.rs:737; otherwise such a read trips the ACGTN check, as it does in the reference). */
 typedef struct mdbg_reader mdbg_reader;
@@ -61,8 +64,9 @@ int mdbg_reader_is_fasta(const mdbg_reader* r);
  * one thread and only run the per-read work in parallel): the file is mapped, every batch is a window of about max_bases file bytes
  * (2 * max_bases for FASTQ) cut at record starts and parsed piecewise by the same record code, so batches hold the same records in the
  * same order with the same bytes as mdbg_reader_open's, only cut at other places (never more than max_bases bases unless a window's last
- * record is longer).  FASTQ is taken as four-line records (as the streaming reader does).  .gz / .lz4 input and threads <= 1 fall back to
- * the streaming reader.  When the file is read in parallel, mdbg_reader_next alternates two buffers: a batch stays valid until the call
+ * record is longer).  FASTQ is taken as four-line records (as the streaming reader does).  .lz4 input and threads <= 1 fall back to
+ * the streaming reader.  gzip input keeps the streaming parser but is inflated AHEAD of it on a thread of its own, and a BGZF file (bgzip:
+ * independent blocks of at most 64 KiB) by threads - 1 threads at once.  When the file is read in parallel, mdbg_reader_next alternates two buffers: a batch stays valid until the call
  * AFTER the next one, so that another thread can pack / copy batch i while batch i+1 is being parsed. */
 mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err);
 int mdbg_reader_is_parallel(const mdbg_reader* r);      /* 1: the file is mapped and parsed by several threads (two alternating batch buffers) */

@@ -22,6 +22,7 @@
 #include <zlib.h>
 
 #include "../../include/mdbg_emit.h"
+#include "gz_inflate.h"
 
 namespace {
 
@@ -422,6 +423,8 @@ struct Lz4In {
 // ---- host ingest -------------------------------------------------------------------------------------
 struct mdbg_reader {
     gzFile f = nullptr; Lz4In* lz = nullptr; bool fasta = false, strip = false, eof = false, io_error = false;
+    gz::GzAhead* gzin = nullptr; const u8* gz_map = nullptr; size_t gz_size = 0;   // a gzip file, mapped and inflated by gz_inflate.h (f stays null)
+    bool gz_ahead = false;                                    // inflate on a thread of its own, ahead of the parser (mdbg_reader_open_mt)
     std::vector<u8> buf; size_t pos = 0, len = 0;            // input window
     const u8* mem = nullptr;                                  // memory mode (a piece of a mapped file): the window is [mem, mem + len), never refilled
     const u8* data() const { return mem ? mem : buf.data(); }
@@ -441,7 +444,7 @@ struct mdbg_reader {
         if (pos > 0) { memmove(buf.data(), buf.data() + pos, len - pos); len -= pos; pos = 0; }
         if (buf.size() - len < (1u << 20)) buf.resize(buf.size() * 2);
         const size_t want = std::min<size_t>(buf.size() - len, 1u << 30);
-        const int n = lz ? lz->read(buf.data() + len, want) : gzread(f, buf.data() + len, (unsigned)want);
+        const int n = gzin ? (gz_ahead ? gzin->read(buf.data() + len, want) : gzin->core.read(buf.data() + len, want)) : lz ? lz->read(buf.data() + len, want) : gzread(f, buf.data() + len, (unsigned)want);
         if (n < 0) io_error = true;
         if (n <= 0) { eof = true; return false; }
         len += (size_t)n;
@@ -504,10 +507,27 @@ mdbg_reader* mdbg_reader_open(const char* path, int strip_newlines, int* err) {
         if (!fp) { delete r; return nullptr; }
         r->lz = new Lz4In(); r->lz->f = fp;
     } else {
-        gzFile f = gzopen(path, "rb");                       // ".gz" and plain files alike (transparent for uncompressed input)
-        if (!f) { delete r; return nullptr; }
-        gzbuffer(f, 1u << 20);
-        r->f = f;
+        // a regular file that starts with the gzip magic is mapped and inflated by gz_inflate.h; everything else (plain text, pipes) goes through zlib's
+        // gzread, which passes uncompressed input through
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) { delete r; return nullptr; }
+        struct stat st;
+        u8 magic[3] = {0, 0, 0};
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 18 && pread(fd, magic, 3, 0) == 3 && magic[0] == 0x1f && magic[1] == 0x8b && magic[2] == 8) {
+            void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (mp != MAP_FAILED) {
+                (void)madvise(mp, (size_t)st.st_size, MADV_SEQUENTIAL);
+                r->gz_map = (const u8*)mp; r->gz_size = (size_t)st.st_size;
+                r->gzin = new gz::GzAhead(); r->gzin->core.open(r->gz_map, r->gz_size, 1);
+            }
+        }
+        close(fd);
+        if (!r->gzin) {
+            gzFile f = gzopen(path, "rb");
+            if (!f) { delete r; return nullptr; }
+            gzbuffer(f, 1u << 20);
+            r->f = f;
+        }
     }
     r->strip = strip_newlines != 0;
     r->fasta = p.find(".fasta.") != std::string::npos || p.find(".fa.") != std::string::npos || ends(".fa") || ends(".fasta");   // main.rs:463
@@ -610,6 +630,8 @@ int mdbg_reader_is_parallel(const mdbg_reader* r) { return r && r->map ? 1 : 0; 
 mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err) {
     mdbg_reader* r = mdbg_reader_open(path, strip_newlines, err);
     if (!r || threads <= 1 || r->lz) return r;
+    // gzip: the inflate runs ahead of the parser on its own thread; BGZF blocks are inflated by the remaining threads (an ordinary gzip file is one stream)
+    if (r->gzin) { r->gz_ahead = true; r->gzin->core.threads = std::max(1, threads - 1); return r; }
     // plain file?  (gzip magic 1f 8b; ".lz4" was taken by name above)  Map it and let `threads` threads parse it.
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return r;
@@ -634,20 +656,21 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
         return e;
     }
     r->bases.clear(); r->offs.assign(1, 0);
-    std::vector<u8> rec;
-    for (;;) {
-        if (r->have_pending) { rec.swap(r->pending); r->have_pending = false; }
-        else if (!r->record(rec)) break;
-        if (r->offs.size() > 1 && r->bases.size() + rec.size() > max_bases) { r->pending.swap(rec); r->have_pending = true; break; }
-        r->bases.insert(r->bases.end(), rec.begin(), rec.end());
+    if (r->have_pending) { r->bases.insert(r->bases.end(), r->pending.begin(), r->pending.end()); r->offs.push_back(r->bases.size()); r->have_pending = false; }
+    while (r->bases.size() < max_bases || r->offs.size() == 1) {
+        const size_t before = r->bases.size();
+        if (!r->record_append(r->bases)) break;                 // (parsed straight into the batch: one copy less per base than through a record buffer)
+        if (r->offs.size() > 1 && r->bases.size() > max_bases) {  // does not fit any more: it opens the next batch
+            r->pending.assign(r->bases.begin() + (long)before, r->bases.end()); r->bases.resize(before); r->have_pending = true;
+            break;
+        }
         r->offs.push_back(r->bases.size());
-        if (r->bases.size() >= max_bases) break;
     }
     *bases = r->bases.data(); *offsets = r->offs.data(); *n_reads = r->offs.size() - 1;
     return r->io_error ? MDBG_E_IO : MDBG_OK;                // a malformed / truncated compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->map) munmap((void*)r->map, r->map_size); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
+void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); if (r->map) munmap((void*)r->map, r->map_size); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
 
 }  // extern "C"
 

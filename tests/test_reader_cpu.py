@@ -256,3 +256,115 @@ def test_packed_reader_buffers_alternate(tmp_path):
             for cur in it:
                 assert all(np.array_equal(prev[f], snap[f]) for f in ("words", "offsets", "exc_pos", "exc_val"))
                 prev, snap = cur, {f: (np.array(v, copy=True) if hasattr(v, "shape") else v) for f, v in cur.items()}
+
+
+# ---- gzip input: the reader's own inflate (csrc/gz_inflate.h) against what the compressors of zlib can produce --------------------
+# A FASTA record on one line may hold any bytes but LF (and a '>' in front), so the decoder is fed more than DNA: incompressible bytes
+# (stored blocks), zero runs (distance 1), periodic data (distances 2..7), prose, and mixtures, at several levels and strategies.
+def _payloads():
+    rng = np.random.default_rng(11)
+    clean = lambda b: bytes(b).replace(b"\n", b"N").replace(b"\r", b"R")
+    text = clean(open(os.path.join(os.path.dirname(GOLDEN), "..", "DESIGN.md"), "rb").read())
+    dna = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=700_000).tobytes()
+    rnd = clean(rng.integers(0, 256, 400_000, dtype=np.uint8).tobytes())
+    recs = [dna[:300_000], text, rnd, bytes(300_000), b"abcdefg" * 30_000 + b"xy" * 40_000 + b"12345" * 20_000, b"", b"A", dna[300_000:], text[:1000] * 50,
+            b"".join(bytes([int(v)]) * int(n) for v, n in zip(rng.integers(32, 127, 3000), rng.integers(1, 600, 3000)))]
+    raw = b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(recs))
+    want = [r[1:] if r[:1] == b">" else r for r in recs]          # (none starts with '>')
+    return raw, want
+
+
+def _bgzf(data, blk=65280):
+    import struct
+    import zlib
+    out = bytearray()
+    for i in list(range(0, len(data), blk)) + [None]:                # the empty block at the end is BGZF's end marker
+        chunk = b"" if i is None else data[i:i + blk]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) + body
+        out += struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def _member(data, level=6):
+    """a gzip member with every optional header field (extra, name, comment, header CRC)"""
+    import struct
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = c.compress(data) + c.flush()
+    hdr = bytearray(b"\x1f\x8b\x08" + bytes([2 | 4 | 8 | 16]) + b"\0\0\0\0\0\xff")
+    extra = b"XY\x03\x00abc"
+    hdr += struct.pack("<H", len(extra)) + extra + b"reads.fa\0" + b"a comment\0"
+    hdr += struct.pack("<H", zlib.crc32(bytes(hdr)) & 0xFFFF)
+    return bytes(hdr) + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+def test_gzip_decoder_over_levels_strategies_and_members(tmp_path):
+    import zlib
+    raw, want = _payloads()
+    files = {}
+    for lvl in (0, 1, 6, 9):
+        files["l%d" % lvl] = gzip.compress(raw, lvl)
+    for name, strat in (("fixed", zlib.Z_FIXED), ("huffman", zlib.Z_HUFFMAN_ONLY), ("rle", zlib.Z_RLE), ("filtered", zlib.Z_FILTERED)):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strat)
+        files[name] = c.compress(raw) + c.flush()
+    c = zlib.compressobj(6, zlib.DEFLATED, 25, 1)                     # 512-byte window, smallest hash table, a sync flush (empty stored block) every 50 kB
+    files["sync"] = b"".join(c.compress(raw[i:i + 50_000]) + c.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(raw), 50_000)) + c.flush()
+    cut = [0, 100, 300_107, 300_108, 1_000_000, len(raw)]             # members cut anywhere (also in the middle of a header line), an empty one between
+    files["members"] = b"".join(_member(raw[a:b]) + _member(b"") for a, b in zip(cut, cut[1:]))
+    files["members_padded"] = files["members"] + bytes(1000)
+    files["members_garbage"] = files["members"] + b"not a gzip member"
+    files["bgzf"] = _bgzf(raw)
+    files["bgzf_small_blocks"] = _bgzf(raw, 777)
+    files["bgzf_then_member_then_bgzf"] = _bgzf(raw[:500_000]) + _member(raw[500_000:900_000]) + _bgzf(raw[900_000:])
+    for name, data in files.items():
+        p = tmp_path / ("%s.fa.gz" % name)
+        p.write_bytes(data)
+        for threads in (1, 3):
+            got, fasta = collect(str(p), threads=threads)
+            assert fasta and got == want, (name, threads)
+        small = []                                                   # the same through many small batches (window slides, chunk ends everywhere)
+        with E.Reader(str(p), threads=2) as r:
+            for b, o in r.batches(10_000):
+                small += [b[int(o[i]):int(o[i + 1])].tobytes() for i in range(len(o) - 1)]
+        assert small == want, name
+
+
+def test_gzip_decoder_rejects_damaged_streams(tmp_path):
+    import struct
+    import zlib
+    raw, _ = _payloads()
+    good = gzip.compress(raw, 6)
+
+    def fails(data, threads=1):
+        p = tmp_path / "bad.fa.gz"
+        p.write_bytes(data)
+        with E.Reader(str(p), threads=threads) as r:
+            with pytest.raises(RuntimeError):
+                for _ in r.batches(1 << 20):
+                    pass
+
+    fails(good[:len(good) // 2])                                     # truncated in the deflate data
+    fails(good[:-5])                                                 # truncated in the trailer
+    fails(good[:-8] + struct.pack("<II", (zlib.crc32(raw) ^ 1) & 0xFFFFFFFF, len(raw)))      # CRC
+    fails(good[:-4] + struct.pack("<I", len(raw) + 1))              # length
+    flipped = bytearray(good); flipped[len(good) // 3] ^= 0x10
+    fails(bytes(flipped))                                            # a bit in the middle: caught by the decoder or, at the latest, by the CRC
+    fails(good + b"\x1f\x8b\x08\xe0" + bytes(20))                    # a second member with reserved flag bits
+    bg = bytearray(_bgzf(raw))
+    bg[len(bg) // 2] ^= 0x04
+    fails(bytes(bg), threads=1)
+    fails(bytes(bg), threads=3)
+    rng = np.random.default_rng(3)
+    for _ in range(60):                                              # random damage: an error or the right bytes, nothing else (and no crash)
+        d = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            d[int(rng.integers(10, len(d)))] ^= 1 << int(rng.integers(0, 8))
+        p = tmp_path / "fuzz.fa.gz"
+        p.write_bytes(bytes(d))
+        try:
+            got, _ = collect(str(p))
+        except RuntimeError:
+            continue
+        assert b"".join(got) == b"".join(_payloads()[1])
