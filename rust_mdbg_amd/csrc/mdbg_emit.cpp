@@ -425,6 +425,9 @@ struct mdbg_reader {
     gzFile f = nullptr; Lz4In* lz = nullptr; bool fasta = false, strip = false, eof = false, io_error = false;
     gz::GzAhead* gzin = nullptr; const u8* gz_map = nullptr; size_t gz_size = 0;   // a gzip file, mapped and inflated by gz_inflate.h (f stays null)
     bool gz_ahead = false;                                    // inflate on a thread of its own, ahead of the parser (mdbg_reader_open_mt)
+    // mdbg_reader_open_mt on gzip input: the inflated text is collected in a window [carry of the previous window | new text], the part of it that holds whole
+    // records is parsed by `threads` threads like a window of a mapped file (map points at gw then), the rest is carried over
+    u8* gw = nullptr; size_t gw_cap = 0, gw_len = 0; bool gw_mode = false, gw_eof = false;
     std::vector<u8> buf; size_t pos = 0, len = 0;            // input window
     const u8* mem = nullptr;                                  // memory mode (a piece of a mapped file): the window is [mem, mem + len), never refilled
     const u8* data() const { return mem ? mem : buf.data(); }
@@ -624,6 +627,66 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_o
     return MDBG_OK;
 }
 
+// gzip input read by several threads: [0, E) of the window = the whole records in it.  FASTA: everything in front of the last header line.  FASTQ: up to the
+// end of the last record whose four lines verify (next_record_start) — found from the last MB on, from the front if the tail holds none.
+namespace {
+size_t complete_prefix(const u8* m, size_t n, bool fasta) {
+    if (fasta) {
+        for (size_t p = n; p > 0;) {
+            const u8* g = (const u8*)memrchr(m, '>', p);
+            if (!g) return 0;
+            const size_t i = (size_t)(g - m);
+            if (i == 0 || m[i - 1] == '\n') return i;
+            p = i;
+        }
+        return 0;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t p = pass == 0 && n > (1u << 20) ? n - (1u << 20) : 0, last_end = 0;
+        bool any = false;
+        size_t q = next_record_start(m, n, p, false);
+        while (q < n) {
+            size_t e = q;
+            for (int l = 0; l < 4; ++l) e = line_end(m, n, e) + 1;                // behind the record's fourth line
+            last_end = std::min(e, n); any = true;
+            if (last_end >= n) break;
+            q = next_record_start(m, n, last_end, false);
+        }
+        if (any) return last_end;
+        if (p == 0) break;
+    }
+    return 0;
+}
+}  // namespace
+static bool reader_more(const mdbg_reader* r) { return r->gw_mode ? !(r->gw_eof && r->gw_len == 0) : r->map_cur < r->map_size; }
+static int reader_next_window(mdbg_reader* r, uint64_t max_bases, bool ascii_out) {
+    if (!r->gw_mode) return reader_next_parallel(r, max_bases, ascii_out);
+    size_t want = std::max<size_t>(r->fasta ? (size_t)max_bases : 2 * (size_t)max_bases, 1u << 16);
+    size_t E = 0;
+    for (;;) {
+        if (r->gw_cap < want + 64) {
+            u8* nb = (u8*)malloc(want + want / 8 + 64);
+            if (!nb) return MDBG_E_NOMEM;
+            if (r->gw_len) memcpy(nb, r->gw, r->gw_len);
+            free(r->gw); r->gw = nb; r->gw_cap = want + want / 8 + 64;
+        }
+        while (!r->gw_eof && r->gw_len < want) {
+            const int n = r->gzin->read(r->gw + r->gw_len, std::min<size_t>(want - r->gw_len, 1u << 30));
+            if (n < 0) { r->io_error = true; return MDBG_E_IO; }
+            if (n == 0) r->gw_eof = true; else r->gw_len += (size_t)n;
+        }
+        if (r->gw_len == 0) { r->offs.assign(1, 0); return MDBG_OK; }
+        E = r->gw_eof ? r->gw_len : complete_prefix(r->gw, r->gw_len, r->fasta);
+        if (E > 0) break;
+        want *= 2;                                                               // one record is larger than the window: read on
+    }
+    r->map = r->gw; r->map_size = E; r->map_cur = 0;
+    const int e = reader_next_parallel(r, (uint64_t)E, ascii_out);             // the whole of [0, E) is one batch
+    r->map = r->gw; r->map_size = 0; r->map_cur = 0;
+    memmove(r->gw, r->gw + E, r->gw_len - E); r->gw_len -= E;
+    return e;
+}
+
 int mdbg_reader_is_fasta(const mdbg_reader* r) { return r && r->fasta ? 1 : 0; }
 int mdbg_reader_is_parallel(const mdbg_reader* r) { return r && r->map ? 1 : 0; }
 
@@ -631,7 +694,14 @@ mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threa
     mdbg_reader* r = mdbg_reader_open(path, strip_newlines, err);
     if (!r || threads <= 1 || r->lz) return r;
     // gzip: the inflate runs ahead of the parser on its own thread; BGZF blocks are inflated by the remaining threads (an ordinary gzip file is one stream)
-    if (r->gzin) { r->gz_ahead = true; r->gzin->core.threads = std::max(1, threads - 1); return r; }
+    if (r->gzin) {
+        r->gz_ahead = true; r->gzin->core.threads = std::max(1, threads - 1);
+        r->gw_mode = true; r->threads = threads;
+        r->gw_cap = 1u << 20; r->gw = (u8*)malloc(r->gw_cap);
+        if (!r->gw) { mdbg_reader_close(r); if (err) *err = MDBG_E_NOMEM; return nullptr; }
+        r->map = r->gw;                                                          // (non-null: the batch calls take the parallel path)
+        return r;
+    }
     // plain file?  (gzip magic 1f 8b; ".lz4" was taken by name above)  Map it and let `threads` threads parse it.
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return r;
@@ -651,7 +721,7 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
     if (r->map) {
         int e;
         std::swap(r->big, r->big2); std::swap(r->big_cap, r->big2_cap); r->offs.swap(r->offs2);       // the batch handed out last stays intact during this call
-        do e = reader_next_parallel(r, max_bases); while (!e && r->offs.size() == 1 && r->map_cur < r->map_size);      // a window without a record (text in front of the first header) is not the end
+        do e = reader_next_window(r, max_bases, true); while (!e && r->offs.size() == 1 && reader_more(r));      // a window without a record (text in front of the first header) is not the end
         *bases = r->big; *offsets = r->offs.data(); *n_reads = r->offs.size() - 1;
         return e;
     }
@@ -670,7 +740,7 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
     return r->io_error ? MDBG_E_IO : MDBG_OK;                // a malformed / truncated compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); if (r->map) munmap((void*)r->map, r->map_size); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
+void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); if (r->map && !r->gw_mode) munmap((void*)r->map, r->map_size); free(r->gw); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
 
 }  // extern "C"
 
@@ -777,7 +847,7 @@ int mdbg_reader_next_packed(mdbg_reader* r, uint64_t max_bases, mdbg_packed_batc
     if (r->map) {
         int e;
         r->offs.swap(r->offs2);
-        do e = reader_next_parallel(r, max_bases, false); while (!e && r->offs.size() == 1 && r->map_cur < r->map_size);
+        do e = reader_next_window(r, max_bases, false); while (!e && r->offs.size() == 1 && reader_more(r));
         if (e) return e;
         if (r->offs.size() == 1) { r->pexc_pos.clear(); r->pexc_val.clear(); out->offsets = r->offs.data(); return MDBG_OK; }      // end of file (the pieces still hold the last batch)
         const u64 total = r->offs.back();

@@ -368,3 +368,29 @@ def test_gzip_decoder_rejects_damaged_streams(tmp_path):
         except RuntimeError:
             continue
         assert b"".join(got) == b"".join(_payloads()[1])
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fasta-crlf", "fasta-multiline", "fasta-multiline-strip", "fastq", "fastq-crlf", "fastq-noeol"])
+@pytest.mark.parametrize("container", ["gzip", "bgzf"])
+def test_gzip_input_parsed_in_windows_equals_streaming_reader(kind, container, tmp_path):
+    """mdbg_reader_open_mt on gzip input: the inflated text is parsed in windows by several threads (whole records per window, the rest carried over) —
+    same records as the one-thread reader of the plain file, for windows smaller than a record up to larger than the file"""
+    import random
+    rnd = random.Random(hash(kind) & 0xFFF)
+    fastq = kind.startswith("fastq")
+    data = random_records(rnd, 400, fastq, crlf="crlf" in kind, multiline="multiline" in kind)
+    if kind == "fastq-noeol":
+        data = data.rstrip(b"\n")
+    if kind == "fasta":
+        data = b"junk before the first header\n\n" + data
+    plain = tmp_path / ("r.fastq" if fastq else "r.fa")
+    plain.write_bytes(data)
+    strip = kind.endswith("strip")
+    ref, _ = collect(str(plain), strip=strip)
+    assert len(ref) == 400
+    p = tmp_path / (plain.name + ".gz")
+    p.write_bytes(gzip.compress(data, 6) if container == "gzip" else _bgzf(data, 3000))
+    for threads in (2, 3, 8):
+        for max_bases in (1 << 30, 150_000, 20_000, 3_000, 1):
+            got, is_fa = collect(str(p), max_bases=max_bases, strip=strip, threads=threads)
+            assert got == ref and is_fa == (not fastq), (threads, max_bases)
