@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -566,9 +567,10 @@ struct GzIn {
 // sequential stream, so this overlap is all the parallelism it offers; a BGZF file is also inflated by GzIn's group threads underneath).
 struct GzAhead {
     GzIn core;
-    static constexpr int SLOTS = 3; static constexpr size_t PIECE = 4u << 20;
-    struct Slot { std::vector<u8> data; size_t n = 0; int state = 0; };           // state: 0 free, 1 filled, 2 last (n bytes, then the end), 3 error
-    Slot slot[SLOTS];
+    int SLOTS = 3; size_t PIECE = 4u << 20;                                        // how far ahead: set_depth before the first read
+    struct Slot { std::unique_ptr<u8[]> data; size_t n = 0; int state = 0; };           // state: 0 free, 1 filled, 2 last (n bytes, then the end), 3 error
+    std::vector<Slot> slot;
+    void set_depth(int slots, size_t piece) { if (!started) { SLOTS = std::max(2, slots); PIECE = std::max<size_t>(piece, 1u << 16); } }
     std::mutex mu; std::condition_variable cv;
     std::thread worker; bool stop = false, started = false;
     int cur = 0; size_t cur_rd = 0; bool finished = false, failed = false;         // consumer side
@@ -578,12 +580,13 @@ struct GzAhead {
     }
     void start() {
         started = true;
+        slot.resize((size_t)SLOTS);
         worker = std::thread([this]() {
             for (int w = 0;; w = (w + 1) % SLOTS) {
-                Slot& s = slot[w];
+                Slot& s = slot[(size_t)w];
                 { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return stop || s.state == 0; }); if (stop) return; }
-                if (s.data.size() < PIECE) s.data.resize(PIECE);
-                const int r = core.read(s.data.data(), PIECE);                   // (short only at the end of the data)
+                if (!s.data) s.data.reset(new u8[PIECE]);                       // (not zero-filled: touched when written)
+                const int r = core.read(s.data.get(), PIECE);                   // (short only at the end of the data)
                 { std::lock_guard<std::mutex> g(mu); s.n = r > 0 ? (size_t)r : 0; s.state = r < 0 ? 3 : (size_t)r < PIECE ? 2 : 1; }
                 cv.notify_all();
                 if (r < 0 || (size_t)r < PIECE) return;
@@ -594,12 +597,12 @@ struct GzAhead {
         if (!started) start();
         size_t got = 0;
         while (got < want && !finished && !failed) {
-            Slot& s = slot[cur];
+            Slot& s = slot[(size_t)cur];
             int st;
             { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return s.state != 0; }); st = s.state; }
             if (st == 3) { failed = true; break; }
             const size_t take = std::min(want - got, s.n - cur_rd);
-            memcpy(dst + got, s.data.data() + cur_rd, take); cur_rd += take; got += take;
+            memcpy(dst + got, s.data.get() + cur_rd, take); cur_rd += take; got += take;
             if (cur_rd == s.n) {
                 if (st == 2) { finished = true; break; }
                 { std::lock_guard<std::mutex> g(mu); s.state = 0; }

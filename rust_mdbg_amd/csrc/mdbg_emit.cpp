@@ -697,6 +697,7 @@ mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threa
     if (r->gzin) {
         r->gz_ahead = true; r->gzin->core.threads = std::max(1, threads - 1);
         r->gw_mode = true; r->threads = threads;
+        r->gzin->set_depth(8, 16u << 20);                                        // up to 128 MB of text inflated while the previous window is parsed
         r->gw_cap = 1u << 20; r->gw = (u8*)malloc(r->gw_cap);
         if (!r->gw) { mdbg_reader_close(r); if (err) *err = MDBG_E_NOMEM; return nullptr; }
         r->map = r->gw;                                                          // (non-null: the batch calls take the parallel path)
