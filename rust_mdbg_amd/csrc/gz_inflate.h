@@ -24,6 +24,7 @@
 #include <vector>
 
 #include <immintrin.h>
+#include <zlib.h>                   // crc32_combine only
 
 namespace gz {
 typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
@@ -113,6 +114,22 @@ inline u32 e_extra(u32 e) { return e >> 24 & 31; }
 constexpr int LIT_BITS = 11, DIST_BITS = 8;
 constexpr int LIT_TAB = (1 << LIT_BITS) + 288 * 16, DIST_TAB = (1 << DIST_BITS) + 32 * 128;
 
+// does a dynamic-Huffman block that is not the stream's last one start at this bit?  (13 header bits, then a COMPLETE code for the code lengths: about one
+// position in a few hundred passes; used by the search for entry points into a stream, see SpecChunk)
+inline bool plausible_dynamic_header(const u8* in, size_t n, size_t bit) {
+    const size_t byte = bit >> 3;
+    if (byte + 16 > n) return false;
+    u64 w0, w1; memcpy(&w0, in + byte, 8); memcpy(&w1, in + byte + 8, 8);
+    const unsigned sh = (unsigned)(bit & 7);
+    const unsigned __int128 v = ((unsigned __int128)w1 << 64 | w0) >> sh;          // >= 120 bits from `bit` on
+    const u32 h = (u32)v;
+    if ((h & 7) != 4) return false;                                             // not the final block, dynamic Huffman codes
+    if ((h >> 3 & 31) > 29 || (h >> 8 & 31) > 29) return false;
+    const u32 hclen = (h >> 13 & 15) + 4;
+    u32 kraft = 0;
+    for (u32 i = 0; i < hclen; ++i) { const u32 l = (u32)(v >> (17 + 3 * i)) & 7; if (l) kraft += 128u >> l; }
+    return kraft == 128;
+}
 struct Inflater {
     // input (whole stream in memory)
     const u8* in = nullptr; size_t in_n = 0, ip = 0;
@@ -125,7 +142,11 @@ struct Inflater {
     u32 lit[LIT_TAB], dist[DIST_TAB];
     const char* err = nullptr;
 
-    void start(const u8* p, size_t n, size_t at) { in = p; in_n = n; ip = at; bb = 0; bc = 0; st = HEADER; last = false; stored_left = 0; pend_len = pend_dist = 0; pend_lit = pend_nlit = 0; err = nullptr; }
+    size_t stop_bit = ~(size_t)0; bool stopped = false;      // run / run_spec return in front of the first header of a dynamic block at or behind this bit of the stream
+    void start(const u8* p, size_t n, size_t at) { in = p; in_n = n; ip = at; bb = 0; bc = 0; st = HEADER; last = false; stored_left = 0; pend_len = pend_dist = 0; pend_lit = pend_nlit = 0; err = nullptr; stop_bit = ~(size_t)0; stopped = false; }
+    // ... at a bit position (a block header in the middle of a stream)
+    void start_bits(const u8* p, size_t n, size_t bit) { start(p, n, bit >> 3); if (ip < in_n) { bb = (u64)in[ip] >> (bit & 7); bc = 8 - (u32)(bit & 7); ++ip; } }
+    size_t bitpos() const { return ip * 8 - bc; }               // of the next unread bit (bytes the fast path holds above bc are not counted in ip)
     bool fail(const char* m) { err = m; return false; }
 
     // -- careful bit access (headers, ends of input / output): only counted bits
@@ -300,7 +321,11 @@ struct Inflater {
                 if (pend_len) { op_io = op; return true; }
             }
             if (st == END) { op_io = op; return true; }
-            if (st == HEADER) { if (!block_header()) return false; continue; }
+            if (st == HEADER) {
+                if (bitpos() >= stop_bit && plausible_dynamic_header(in, in_n, bitpos())) { stopped = true; op_io = op; return true; }      // (only where the search of the next piece can find it)
+                if (!block_header()) return false;
+                continue;
+            }
             if (st == STORED) {
                 const size_t n = std::min<size_t>(std::min<size_t>(stored_left, out_end - op), in_n - ip);
                 memcpy(out + op, in + ip, n); op += n; ip += n; stored_left -= (u32)n;
@@ -402,6 +427,71 @@ struct Inflater {
             st = last ? END : HEADER;
         }
     }
+
+    // The same stream decoded WITHOUT its history (a block found in the middle of a gzip file, see SpecChunk): 16-bit symbols, a byte or
+    // 256 + i for "byte i of the 32 KiB in front of this piece" — copies carry such markers along.  One table entry at a time.  Returns
+    // true when: the room is nearly used up (op > out_end - 512: call again with more), the final block has ended (st == END), the stop bit
+    // was reached in front of a block header (stopped), or the last 32 KiB hold no marker (*clean: the caller goes on with run() on bytes).
+    // last_marker = index behind the last marker written (in / out).
+    bool run_spec(u16* out, size_t& op_io, size_t out_end, size_t& last_marker, bool& clean) {
+        size_t op = op_io;
+        constexpr u32 LM = (1u << LIT_BITS) - 1, DM = (1u << DIST_BITS) - 1;
+        clean = false;
+        for (;;) {
+            if (st == END) { op_io = op; return true; }
+            if (op >= 32768 && op - last_marker >= 32768) { clean = true; op_io = op; return true; }
+            if (st == HEADER) {
+                if (bitpos() >= stop_bit && plausible_dynamic_header(in, in_n, bitpos())) { stopped = true; op_io = op; return true; }      // (only where the search of the next piece can find it)
+                if (!block_header()) return false;
+                continue;
+            }
+            if (op + 512 > out_end) { op_io = op; return true; }
+            if (st == STORED) {
+                const size_t n = std::min<size_t>(std::min<size_t>(stored_left, out_end - op), in_n - ip);
+                for (size_t k = 0; k < n; ++k) out[op + k] = in[ip + k];
+                op += n; ip += n; stored_left -= (u32)n;
+                if (stored_left) { if (ip >= in_n) return fail("truncated stored block"); op_io = op; return true; }
+                st = last ? END : HEADER;
+                continue;
+            }
+            normalize();
+            bool eob = false;
+            while (op + 512 <= out_end) {
+                if (op >= 32768 && op - last_marker >= 32768) break;
+                need(32);
+                u32 e = lit[bb & LM];
+                u32 used = 0;
+                if ((e & 0xF0) == (K_SUB << 4)) { used = LIT_BITS; e = lit[e_value(e) + ((bb >> LIT_BITS) & ((1u << e_extra(e)) - 1))]; }
+                used += e & 15;
+                const u32 kind = e_kind(e);
+                if (kind == K_BAD || kind == K_SUB) return fail(used > bc ? "truncated deflate stream" : "invalid literal / length code");
+                if (used > bc) return fail("truncated deflate stream");
+                take(used);
+                if (kind == K_LIT) { u32 n = e >> 4 & 3, v = e >> 8; while (n--) { out[op++] = (u16)(v & 0xFF); v >>= 8; } continue; }
+                if (kind == K_EOB) { eob = true; break; }
+                const u32 xb = e_extra(e);
+                if (!need(xb)) return fail("truncated deflate stream");
+                const u32 len = e_value(e) + take(xb);
+                need(32);
+                u32 d = dist[bb & DM];
+                used = 0;
+                if ((d & 0xF0) == (K_SUB << 4)) { used = DIST_BITS; d = dist[e_value(d) + ((bb >> DIST_BITS) & ((1u << e_extra(d)) - 1))]; }
+                used += d & 15;
+                if ((d >> 4 & 15) != K_BASE) return fail(used > bc ? "truncated deflate stream" : "invalid distance code");
+                if (used > bc) return fail("truncated deflate stream");
+                take(used);
+                const u32 db = e_extra(d);
+                if (!need(db)) return fail("truncated deflate stream");
+                const size_t dd = e_value(d) + take(db);
+                if (dd > op + 32768) return fail("distance reaches in front of the data");
+                for (u32 k = 0; k < len; ++k, ++op) {
+                    if (dd <= op) { const u16 v = out[op - dd]; out[op] = v; if (v >= 256) last_marker = op + 1; }
+                    else { out[op] = (u16)(256 + 32768 - (dd - op)); last_marker = op + 1; }
+                }
+            }
+            if (eob) st = last ? END : HEADER;
+        }
+    }
 };
 
 // ---- gzip members over a mapped file ----------------------------------------------------------------------------------------------
@@ -431,6 +521,51 @@ inline bool parse_header(const u8* p, size_t n, size_t at, Member& m) {
     m.data = q;
     return true;
 }
+
+// ---- an ordinary gzip stream on several threads ---------------------------------------------------------------------------------------
+// One deflate stream has no entry points, but it has block headers, and a dynamic block's header is recognisable: a piece of the file is
+// searched bit by bit for something that parses as one (13 header bits, then a COMPLETE code for the code lengths: one position in a few
+// hundred survives that, the table build and the decoding of the blocks behind it weed out the rest), and the stream is decoded from
+// there without its history: references into the unknown 32 KiB become markers (Inflater::run_spec) until 32 KiB without one have gone by,
+// from where the ordinary byte decoder takes over.  Pieces are accepted IN ORDER and only if the piece in front — decoded exactly — ended at
+// the very bit this one started at, so what the search guessed never decides what comes out; markers are then replaced from the 32 KiB in
+// front.  (The scheme of pugz / rapidgzip, written from the idea.)
+struct SpecChunk {
+    size_t start_bit = 0, end_bit = 0; bool found = false, hit_end = false;
+    std::vector<u16> sym; size_t nsym = 0;            // decoded without history: bytes and markers
+    std::vector<u8> bytes; size_t nbytes = 0;         // ... and from where no marker can be referred to any more: [0, 32768) repeats the end of sym
+    // the first block at or behind from_bit (searched up to limit_bit) from which the stream decodes up to the first block boundary at or behind stop_bit
+    void decode(const u8* in, size_t n, size_t from_bit, size_t limit_bit, size_t stop_bit, Inflater& f) {
+        found = false;
+        for (size_t pos = from_bit; pos < limit_bit; ++pos) {
+            if (!plausible_dynamic_header(in, n, pos)) continue;
+            if (attempt(in, n, pos, stop_bit, f)) { found = true; start_bit = pos; return; }
+        }
+    }
+    bool attempt(const u8* in, size_t n, size_t pos, size_t stop_bit, Inflater& f) {
+        f.start_bits(in, n, pos); f.stop_bit = stop_bit;
+        hit_end = false; nsym = nbytes = 0;
+        if (sym.size() < (1u << 18)) sym.resize(1u << 18);
+        size_t last_marker = 0; bool clean = false;
+        for (;;) {
+            if (!f.run_spec(sym.data(), nsym, sym.size(), last_marker, clean)) return false;
+            if (f.st == Inflater::END) { hit_end = true; end_bit = f.bitpos(); return true; }
+            if (f.stopped) { end_bit = f.bitpos(); return true; }
+            if (clean) break;
+            if (sym.size() >= (64u << 20)) return false;                        // markers all the way: not worth it (the sequential decoder takes the piece)
+            sym.resize(sym.size() * 2);
+        }
+        if (bytes.size() < (4u << 20)) bytes.resize(4u << 20);
+        for (size_t i = 0; i < 32768; ++i) bytes[i] = (u8)sym[nsym - 32768 + i];
+        nbytes = 32768;
+        for (;;) {
+            if (!f.run(bytes.data(), 0, nbytes, bytes.size() - 16)) return false;
+            if (f.st == Inflater::END && !f.pend_len && !f.pend_nlit) { hit_end = true; end_bit = f.bitpos(); return true; }
+            if (f.stopped) { end_bit = f.bitpos(); return true; }
+            bytes.resize(bytes.size() * 2);
+        }
+    }
+};
 
 // Streaming reader of a mapped gzip file: read() like gzread.  With threads > 1 and a BGZF file, groups of blocks are inflated in parallel.
 struct GzIn {
@@ -465,6 +600,8 @@ struct GzIn {
         inf->start(in, n, m.data);
         in_member = true; crc = 0; produced = 0;
         lo = wr;                                                       // a member has no history
+        cur_bit = m.data * 8;
+        spec_on = threads >= SPEC_MIN_THREADS && !m.bgzf && n - m.data >= 4 * SPEC_C;  // an ordinary stream of some size: several threads (produce_spec)
         return true;
     }
     bool end_member() {
@@ -479,17 +616,26 @@ struct GzIn {
         return true;
     }
     // more bytes into [wr, ..): false when nothing more comes (end or error)
+    // keep the history (at most 32 KiB) at the front of the window, write behind it
+    void slide() {
+        const size_t keep_from = std::max(lo, wr > HIST ? wr - HIST : 0), keep = wr - keep_from;
+        if (keep_from) memmove(win.data(), win.data() + keep_from, keep);
+        lo = 0; rd = wr = keep;
+    }
     bool produce() {
         if (rd != wr) return true;
-        // slide: keep the history, start writing behind it
-        if (wr > HIST) {
-            const size_t keep_from = std::max(lo, wr - HIST), keep = wr - keep_from;
-            memmove(win.data(), win.data() + keep_from, keep);
-            lo = 0; rd = wr = keep;
+        if (wr > HIST || (spec_on && in_member)) slide();
+        if (spec_on && in_member) {
+            const int r = produce_spec();
+            if (r < 0) return false;
+            if (r == 1) return true;
+            if (r == 2) return produce();                               // the member ended without a byte
+            spec_on = false;                                            // r == 0: the sequential decoder goes on at cur_bit, the history is in place
+            inf->start_bits(in, n, cur_bit);
         }
         if (is_bgzf && threads > 1 && !in_member) return produce_bgzf();
         for (;;) {
-            if (!in_member && !begin_member()) return false;
+            if (!in_member) { if (!begin_member()) return false; if (spec_on) return produce(); }
             size_t op = wr;
             if (!inf->run(win.data(), lo, op, HIST + CHUNK)) return fail(inf->err);
             if (op > wr) { crc = crc32(crc, win.data() + wr, op - wr); produced += op - wr; }
@@ -499,6 +645,98 @@ struct GzIn {
             if (got) return true;
             if (in_member) return fail("deflate stream made no progress");      // (chunk room is never zero here)
         }
+    }
+    // One round of an ordinary stream on `threads` threads (SpecChunk): pieces of SPEC_C compressed bytes; the first is decoded exactly into the
+    // window (behind the history), the others without history into buffers of their own; then the pieces are accepted in order, each only if
+    // the one in front ended at the bit it started at, and copied behind each other with their markers replaced.
+    // 1: bytes produced; 2: none, but the member has ended; 0: not worth a round (or the last one found nothing): sequential from cur_bit; -1: error
+    static constexpr size_t SPEC_C = 1u << 20;                        // smallest piece (compressed bytes); pieces grow with what is left, up to 8x
+    static constexpr int SPEC_MIN_THREADS = 3;                          // (a piece decoded without history costs about twice its sequential time)
+    bool spec_on = false, spec_quit = false; size_t cur_bit = 0;
+    u64 st_rounds = 0, st_pieces = 0, st_offered = 0;                   // rounds, pieces accepted / started (statistics)
+    std::vector<SpecChunk> chunks;
+    int produce_spec() {
+        const size_t cur_byte = cur_bit >> 3;
+        const int T = threads;
+        if (spec_quit || n < cur_byte + 3 * SPEC_C + 8) { spec_quit = false; return 0; }
+        // the first piece is decoded exactly and fast: it gets a share and a half
+        const size_t left = n - 8 - cur_byte;
+        const size_t C = std::min<size_t>(8 * SPEC_C, std::max<size_t>(SPEC_C, left / (2 * (size_t)T + 1)));
+        if ((int)chunks.size() < T) chunks.resize((size_t)T);
+        while ((int)pool.size() < T) pool.push_back(new Inflater());
+        auto lim = [&](int k) { return std::min(cur_byte + (k ? C / 2 + (size_t)k * C : 0), n - 8) * 8; };
+        const size_t h = wr;                                            // history in win[0, h)
+        size_t op0 = h; size_t end0 = 0; bool hit_end0 = false; const char* err0 = nullptr; u32 crc0 = 0;
+        auto first = [&]() {
+            Inflater& f = *pool[0];
+            f.start_bits(in, n, cur_bit); f.stop_bit = lim(1);
+            for (;;) {
+                if (win.size() < op0 + (1u << 20)) win.resize(std::max(win.size() * 2, op0 + (4u << 20)));
+                if (!f.run(win.data(), 0, op0, win.size() - 16)) { err0 = f.err; return; }
+                if (f.st == Inflater::END && !f.pend_len && !f.pend_nlit) { hit_end0 = true; break; }
+                if (f.stopped) break;
+            }
+            end0 = f.bitpos();
+            crc0 = crc32(0, win.data() + h, op0 - h);
+        };
+        {
+            std::vector<std::thread> th;
+            for (int k = 1; k < T; ++k) th.emplace_back([&, k]() { chunks[(size_t)k].decode(in, n, lim(k), lim(k + 1), lim(k + 1), *pool[(size_t)k]); });
+            first();
+            for (auto& x : th) x.join();
+        }
+        if (err0) { fail(err0); return -1; }
+        // which pieces follow each other, and where they go
+        struct Place { size_t off, len; const u8* window; u32 crc; };
+        std::vector<Place> place((size_t)T);
+        size_t end = end0, w = op0; bool ended = hit_end0; int accepted = 1;
+        for (int k = 1; k < T && !ended; ++k) {
+            SpecChunk& c = chunks[(size_t)k];
+            if (!c.found || c.start_bit != end) break;
+            // the 32 KiB in front of the piece: the end of the first piece (in the window already) or the marker-free end of the piece before
+            const u8* window = nullptr;
+            if (k == 1) { if (w >= 32768) window = win.data() + w - 32768; }      // (win is not resized between here and its use: see below)
+            else { const SpecChunk& p = chunks[(size_t)k - 1]; if (p.nbytes >= 65536) window = p.bytes.data() + p.nbytes - 32768; }
+            if (!window && c.nsym) break;                               // rare (a piece of markers only, or a member's first 32 KiB): the next round starts here
+            const size_t more = c.nsym + (c.nbytes > 32768 ? c.nbytes - 32768 : 0);
+            place[(size_t)k] = Place{w, more, window, 0};
+            w += more; end = c.end_bit; ended = c.hit_end; ++accepted;
+        }
+        if (win.size() < w + 64) {                                      // (k == 1's window pointer moves with the buffer)
+            const size_t w1 = accepted > 1 ? place[1].off : 0;
+            win.resize(w + w / 8 + 64);
+            if (accepted > 1 && place[1].window) place[1].window = win.data() + w1 - 32768;
+        }
+        auto settle = [&](int k) {                                      // markers replaced, bytes copied behind, CRC of the piece
+            SpecChunk& c = chunks[(size_t)k]; Place& pl = place[(size_t)k];
+            u8* o = win.data() + pl.off;
+            for (size_t i = 0; i < c.nsym; ++i) { const u16 v = c.sym[i]; o[i] = v < 256 ? (u8)v : pl.window[v - 256]; }
+            if (c.nbytes > 32768) memcpy(o + c.nsym, c.bytes.data() + 32768, c.nbytes - 32768);
+            pl.crc = crc32(0, o, pl.len);
+        };
+        if (accepted > 1) {
+            // place[1].window may lie in win right in front of piece 1's own output: it is read while only places behind it are written
+            std::vector<std::thread> th;
+            for (int k = 2; k < accepted; ++k) th.emplace_back(settle, k);
+            settle(1);
+            for (auto& x : th) x.join();
+        }
+        crc = (u32)::crc32_combine(crc, crc0, (z_off_t)(op0 - h));
+        for (int k = 1; k < accepted; ++k) crc = (u32)::crc32_combine(crc, place[(size_t)k].crc, (z_off_t)place[(size_t)k].len);
+        produced += w - h;
+        cur_bit = end;
+        rd = h; wr = w;
+        ++st_rounds; st_pieces += (u64)accepted; st_offered += (u64)T;
+        if (ended) {
+            const size_t q = (end + 7) >> 3;
+            if (q + 8 > n) { fail("truncated gzip trailer"); return -1; }
+            const u32 want_crc = in[q] | (u32)in[q + 1] << 8 | (u32)in[q + 2] << 16 | (u32)in[q + 3] << 24;
+            const u32 want_len = in[q + 4] | (u32)in[q + 5] << 8 | (u32)in[q + 6] << 16 | (u32)in[q + 7] << 24;
+            if (want_crc != crc) { fail("gzip CRC mismatch"); return -1; }
+            if (want_len != (u32)produced) { fail("gzip length mismatch"); return -1; }
+            at = q + 8; in_member = false; spec_on = false;
+        } else if (accepted == 1) spec_quit = true;                     // nothing found behind the first piece (stored data?): the rest of the member sequentially
+        return w > h ? 1 : ended ? 2 : 0;
     }
     // BGZF: the next blocks (about CHUNK bytes of text per thread), every one inflated on its own into its place
     std::vector<Inflater*> pool;

@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
             if (kind == 3) { const size_t p = rng() % d.size(), l = std::min<size_t>(d.size() - p, 1 + rng() % 64); for (size_t j = 0; j < l; ++j) d[p + j] = (uint8_t)rng(); }
             // exact-size heap copy: reads past the end are visible to a sanitizer build
             uint8_t* h = (uint8_t*)malloc(d.size() ? d.size() : 1); memcpy(h, d.data(), d.size());
-            gz::GzIn g; g.open(h, d.size(), 1 + (int)(rng() % 3));
+            gz::GzIn g; g.open(h, d.size(), 1 + (int)(rng() % 6));
             std::vector<uint8_t> out, buf(65536); bool ok = true;
             for (;;) { const int r = g.read(buf.data(), buf.size()); if (r <= 0) { ok = r == 0; break; } out.insert(out.end(), buf.begin(), buf.begin() + r); if (out.size() > (c.size() + 1000) * 1100) { ok = false; break; } }
             g.close_pool(); free(h);

@@ -394,3 +394,33 @@ def test_gzip_input_parsed_in_windows_equals_streaming_reader(kind, container, t
         for max_bases in (1 << 30, 150_000, 20_000, 3_000, 1):
             got, is_fa = collect(str(p), max_bases=max_bases, strip=strip, threads=threads)
             assert got == ref and is_fa == (not fastq), (threads, max_bases)
+
+
+def test_ordinary_gzip_stream_on_several_threads(tmp_path):
+    """a gzip file of some size (one stream, no BGZF) read with >= 3 threads: pieces of the stream are entered at block headers found by search and decoded
+    without their history (csrc/gz_inflate.h: SpecChunk) — same records as one thread; also with a second and an empty member behind, and damaged"""
+    import zlib
+    rng = np.random.default_rng(5)
+    recs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in rng.integers(5_000, 40_000, 900)]
+    raw = b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(recs))
+    c = zlib.compressobj(1, zlib.DEFLATED, 31)
+    z = c.compress(raw) + c.flush()
+    assert len(z) > 5_000_000                                          # large enough for the piecewise path (4 MiB of compressed data)
+    p = tmp_path / "big.fa.gz"
+    p.write_bytes(z)
+    one, _ = collect(str(p), threads=1)
+    assert one == recs
+    for threads in (3, 4, 9):
+        got, _ = collect(str(p), max_bases=3_000_000, threads=threads)
+        assert got == recs, threads
+    extra = [b"ACGTTTGA" * 10, b"GG"]
+    p.write_bytes(z + gzip.compress(b">x\n%s\n" % extra[0]) + gzip.compress(b"") + gzip.compress(b">y\n%s\n" % extra[1]))
+    got, _ = collect(str(p), threads=5)
+    assert got == recs + extra
+    bad = bytearray(z); bad[len(z) // 2] ^= 0x20
+    p.write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError):
+        collect(str(p), threads=4)
+    p.write_bytes(z[:len(z) * 2 // 3])
+    with pytest.raises(RuntimeError):
+        collect(str(p), threads=4)
