@@ -454,10 +454,63 @@ struct Inflater {
                 st = last ? END : HEADER;
                 continue;
             }
-            normalize();
             bool eob = false;
-            while (op + 512 <= out_end) {
+            // fast loop (as in run(), on 16-bit symbols): away from the end of the input, room for three literals and the longest match
+            if (in_n >= 32) {
+                const size_t in_fast = in_n - 32;
+                u64 b = bb; u32 c = bc; size_t i = ip;
+#define GZ_REFILL() do { u64 w_; memcpy(&w_, in + i, 8); b |= w_ << c; i += (63 - c) >> 3; c |= 56; } while (0)
+#define GZ_LOOKUP(e) do { e = lit[b & LM]; if ((e & 0xF0) == (K_SUB << 4)) { b >>= LIT_BITS; c -= LIT_BITS; e = lit[e_value(e) + (b & ((1u << e_extra(e)) - 1))]; } b >>= e & 15; c -= e & 15; } while (0)
+#define GZ_PUT(e) do { out[op] = (u16)(e >> 8 & 0xFF); out[op + 1] = (u16)(e >> 16 & 0xFF); out[op + 2] = (u16)(e >> 24); op += e >> 4 & 3; } while (0)
+                while (i <= in_fast && op + 512 <= out_end && !(op >= 32768 && op - last_marker >= 32768)) {
+                    GZ_REFILL();
+                    u32 e;
+                    GZ_LOOKUP(e);
+                    if (e & LITF) {
+                        GZ_PUT(e);
+                        GZ_LOOKUP(e);
+                        if (e & LITF) {
+                            GZ_PUT(e);
+                            GZ_LOOKUP(e);
+                            if (e & LITF) { GZ_PUT(e); continue; }
+                        }
+                        GZ_REFILL();
+                    }
+                    const u32 kind = e >> 4 & 7;
+                    if (kind != K_BASE) { if (kind == K_EOB) { eob = true; break; } bb = b; bc = c; ip = i; return fail("invalid literal / length code"); }
+                    const u32 xb = e_extra(e);
+                    const u32 len = e_value(e) + (u32)(b & ((1u << xb) - 1));
+                    b >>= xb; c -= xb;
+                    u32 d = dist[b & DM];
+                    if ((d & 0xF0) == (K_SUB << 4)) { b >>= DIST_BITS; c -= DIST_BITS; d = dist[e_value(d) + (b & ((1u << e_extra(d)) - 1))]; }
+                    b >>= d & 15; c -= d & 15;
+                    if ((d >> 4 & 15) != K_BASE) { bb = b; bc = c; ip = i; return fail("invalid distance code"); }
+                    const u32 db = e_extra(d);
+                    const size_t dd = e_value(d) + (size_t)(b & ((1u << db) - 1));
+                    b >>= db; c -= db;
+                    if (dd > op + 32768) { bb = b; bc = c; ip = i; return fail("distance reaches in front of the data"); }
+                    if (dd <= op && dd >= 4) {                          // inside the piece: four symbols at a time (up to three too many: room is there); a marker among them marks the whole match
+                        u16* dst = out + op; const u16* src = dst - dd;
+                        u64 any = 0;
+                        for (u32 k = 0; k < len; k += 4) { u64 w; memcpy(&w, src + k, 8); memcpy(dst + k, &w, 8); any |= w; }
+                        op += len;
+                        if (any & 0xFF00FF00FF00FF00ull) last_marker = op;
+                    } else {
+                        for (u32 k = 0; k < len; ++k, ++op) {
+                            if (dd <= op) { const u16 v = out[op - dd]; out[op] = v; if (v >= 256) last_marker = op + 1; }
+                            else { out[op] = (u16)(256 + 32768 - (dd - op)); last_marker = op + 1; }
+                        }
+                    }
+                }
+#undef GZ_REFILL
+#undef GZ_LOOKUP
+#undef GZ_PUT
+                bb = b; bc = c; ip = i;
+            }
+            normalize();
+            while (!eob && op + 512 <= out_end) {
                 if (op >= 32768 && op - last_marker >= 32768) break;
+                if (ip + 40 <= in_n) break;                             // (the fast loop goes on: it only left for room or for a clean window)
                 need(32);
                 u32 e = lit[bb & LM];
                 u32 used = 0;
