@@ -65,8 +65,9 @@ int mdbg_reader_is_fasta(const mdbg_reader* r);
  * (2 * max_bases for FASTQ) cut at record starts and parsed piecewise by the same record code, so batches hold the same records in the
  * same order with the same bytes as mdbg_reader_open's, only cut at other places (never more than max_bases bases unless a window's last
  * record is longer).  FASTQ is taken as four-line records (as the streaming reader does).  .lz4 input and threads <= 1 fall back to
- * the streaming reader.  gzip input is inflated AHEAD of the parser on a thread of its own (a BGZF file — bgzip: independent blocks of at most
- * 64 KiB — by threads - 1 threads at once) and the inflated text is parsed in windows like a mapped file: the part of a window that holds whole
+ * the streaming reader.  gzip input is inflated AHEAD of the parser on a thread of its own — a BGZF file (bgzip: independent blocks of at most
+ * 64 KiB) by threads - 1 threads at once, and from four threads on an ordinary gzip stream too (pieces entered at block headers found by search,
+ * decoded without their history, accepted only where the exact decoding of the piece in front ended) — and the inflated text is parsed in windows like a mapped file: the part of a window that holds whole
  * records goes to the parser threads, the rest is carried into the next window.  When the file is read in parallel, mdbg_reader_next alternates two buffers: a batch stays valid until the call
  * AFTER the next one, so that another thread can pack / copy batch i while batch i+1 is being parsed. */
 mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err);

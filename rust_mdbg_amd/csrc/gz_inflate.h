@@ -7,7 +7,8 @@
 // subtable), copies matches eight bytes at a time, and checks bounds once per iteration instead of once per byte (a careful per-byte
 // loop takes over near the ends of the input and of the output window).  The CRC-32 of every member is verified (carry-less multiply
 // where the CPU has it).  BGZF files (bgzip: every member is an independent block of at most 64 KiB that carries its compressed size
-// in an extra field) are inflated by several threads at once.
+// in an extra field) are inflated by several threads at once; so is an ORDINARY gzip stream of some size, which has no such entry
+// points: pieces of it are entered at block headers found by search and decoded without their history (SpecChunk / GzIn::produce_spec).
 //
 // The compressed file is mapped, so the decoder never runs out of input in the middle of a symbol; output is produced in chunks into
 // a window that keeps the last 32 KiB as history.  Untrusted input: every table index is masked, every distance is checked against the
