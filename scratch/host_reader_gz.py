@@ -22,7 +22,7 @@ for i in list(range(0, len(raw), 65280)) + [None]:
 open(d + "/r.bgzf.fq.gz", "wb").write(out)
 t = time.perf_counter(); zlib.decompress(open(d + "/r.fq.gz", "rb").read(), 31); tz = time.perf_counter() - t
 print("%d reads, %.1f MB of text; zlib inflate alone: %.0f MB/s" % (n, len(raw) / 1e6, len(raw) / tz / 1e6))
-for path, threads in ((d + "/r.fq.gz", 1), (d + "/r.fq.gz", 2), (d + "/r.bgzf.fq.gz", 1), (d + "/r.bgzf.fq.gz", 4), (d + "/r.bgzf.fq.gz", T)):
+for path, threads in ((d + "/r.fq.gz", 1), (d + "/r.fq.gz", 2), (d + "/r.fq.gz", 4), (d + "/r.fq.gz", 8), (d + "/r.fq.gz", T), (d + "/r.bgzf.fq.gz", 1), (d + "/r.bgzf.fq.gz", 4), (d + "/r.bgzf.fq.gz", T)):
     best = 1e9
     for rep in range(3):
         t = time.perf_counter(); nb = 0
