@@ -656,6 +656,8 @@ struct GzIn {
         lo = wr;                                                       // a member has no history
         cur_bit = m.data * 8;
         spec_on = threads >= SPEC_MIN_THREADS && !m.bgzf && n - m.data >= 4 * SPEC_C;  // an ordinary stream of some size: several threads (produce_spec)
+        st_member_rounds = 0;
+        if (spec_on && spec_skip) { --spec_skip; spec_on = false; }    // (a file of many small members: their pieces would be searched in vain)
         return true;
     }
     bool end_member() {
@@ -708,6 +710,7 @@ struct GzIn {
     static constexpr int SPEC_MIN_THREADS = 3;                          // (a piece decoded without history costs about twice its sequential time)
     bool spec_on = false, spec_quit = false; size_t cur_bit = 0;
     u64 st_rounds = 0, st_pieces = 0, st_offered = 0;                   // rounds, pieces accepted / started (statistics)
+    u32 st_member_rounds = 0, spec_skip = 0;                            // rounds of this member so far; members to read sequentially before the next try
     std::vector<SpecChunk> chunks;
     int produce_spec() {
         const size_t cur_byte = cur_bit >> 3;
@@ -781,6 +784,7 @@ struct GzIn {
         cur_bit = end;
         rd = h; wr = w;
         ++st_rounds; st_pieces += (u64)accepted; st_offered += (u64)T;
+        const u32 rounds_before = st_member_rounds++;
         if (ended) {
             const size_t q = (end + 7) >> 3;
             if (q + 8 > n) { fail("truncated gzip trailer"); return -1; }
@@ -789,6 +793,7 @@ struct GzIn {
             if (want_crc != crc) { fail("gzip CRC mismatch"); return -1; }
             if (want_len != (u32)produced) { fail("gzip length mismatch"); return -1; }
             at = q + 8; in_member = false; spec_on = false;
+            if (accepted == 1 && rounds_before == 0) spec_skip = 64;    // the whole member was inside the first piece: the next ones sequentially
         } else if (accepted == 1) spec_quit = true;                     // nothing found behind the first piece (stored data?): the rest of the member sequentially
         return w > h ? 1 : ended ? 2 : 0;
     }
