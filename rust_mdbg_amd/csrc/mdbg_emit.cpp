@@ -695,7 +695,7 @@ mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threa
     if (!r || threads <= 1 || r->lz) return r;
     // gzip: the inflate runs ahead of the parser on its own thread; BGZF blocks are inflated by the remaining threads (an ordinary gzip file is one stream)
     if (r->gzin) {
-        r->gz_ahead = true; r->gzin->core.threads = std::max(1, threads - 1);
+        r->gz_ahead = true; r->gzin->core.threads = std::min(48, std::max(1, threads - 1));      // (beyond a few dozen the serial parts of a round dominate)
         r->gw_mode = true; r->threads = threads;
         r->gzin->set_depth(8, 16u << 20);                                        // up to 128 MB of text inflated while the previous window is parsed
         r->gw_cap = 1u << 20; r->gw = (u8*)malloc(r->gw_cap);
