@@ -587,13 +587,14 @@ inline bool parse_header(const u8* p, size_t n, size_t at, Member& m) {
 // the very bit this one started at, so what the search guessed never decides what comes out; markers are then replaced from the 32 KiB in
 // front.  (The scheme of pugz / rapidgzip, written from the idea.)
 struct SpecChunk {
-    size_t start_bit = 0, end_bit = 0; bool found = false, hit_end = false;
+    size_t start_bit = 0, end_bit = 0; bool found = false, hit_end = false, gave_up = false;
+    size_t sym_cap = 32u << 20, byte_cap = 256u << 20;        // a piece that needs more is left to the sequential decoder (very compressible data): set by the caller
     std::vector<u16> sym; size_t nsym = 0;            // decoded without history: bytes and markers
     std::vector<u8> bytes; size_t nbytes = 0;         // ... and from where no marker can be referred to any more: [0, 32768) repeats the end of sym
     // the first block at or behind from_bit (searched up to limit_bit) from which the stream decodes up to the first block boundary at or behind stop_bit
     void decode(const u8* in, size_t n, size_t from_bit, size_t limit_bit, size_t stop_bit, Inflater& f) {
-        found = false;
-        for (size_t pos = from_bit; pos < limit_bit; ++pos) {
+        found = false; gave_up = false;
+        for (size_t pos = from_bit; pos < limit_bit && !gave_up; ++pos) {
             if (!plausible_dynamic_header(in, n, pos)) continue;
             if (attempt(in, n, pos, stop_bit, f)) { found = true; start_bit = pos; return; }
         }
@@ -608,7 +609,7 @@ struct SpecChunk {
             if (f.st == Inflater::END) { hit_end = true; end_bit = f.bitpos(); return true; }
             if (f.stopped) { end_bit = f.bitpos(); return true; }
             if (clean) break;
-            if (sym.size() >= (64u << 20)) return false;                        // markers all the way: not worth it (the sequential decoder takes the piece)
+            if (sym.size() >= sym_cap) { gave_up = true; return false; }        // markers all the way: not worth it (the sequential decoder takes the piece)
             sym.resize(sym.size() * 2);
         }
         if (bytes.size() < (4u << 20)) bytes.resize(4u << 20);
@@ -618,6 +619,7 @@ struct SpecChunk {
             if (!f.run(bytes.data(), 0, nbytes, bytes.size() - 16)) return false;
             if (f.st == Inflater::END && !f.pend_len && !f.pend_nlit) { hit_end = true; end_bit = f.bitpos(); return true; }
             if (f.stopped) { end_bit = f.bitpos(); return true; }
+            if (bytes.size() >= byte_cap) { gave_up = true; return false; }
             bytes.resize(bytes.size() * 2);
         }
     }
@@ -722,6 +724,7 @@ struct GzIn {
         const size_t left = n - 8 - cur_byte;
         const size_t C = std::min<size_t>(8 * SPEC_C, std::max<size_t>(SPEC_C, left / (2 * (size_t)T + 1)));
         if ((int)chunks.size() < T) chunks.resize((size_t)T);
+        for (SpecChunk& c : chunks) { c.byte_cap = 16 * C; c.sym_cap = 4 * C; }      // 16x expansion at most (FASTQ: ~4x); what is more compressible than that is read sequentially
         while ((int)pool.size() < T) pool.push_back(new Inflater());
         auto lim = [&](int k) { return std::min(cur_byte + (k ? C / 2 + (size_t)k * C : 0), n - 8) * 8; };
         const size_t h = wr;                                            // history in win[0, h)
@@ -734,6 +737,7 @@ struct GzIn {
                 if (!f.run(win.data(), 0, op0, win.size() - 16)) { err0 = f.err; return; }
                 if (f.st == Inflater::END && !f.pend_len && !f.pend_nlit) { hit_end0 = true; break; }
                 if (f.stopped) break;
+                if (op0 - h > 24 * C) f.stop_bit = 0;              // very compressible data: stop at the next block (the other pieces will not fit: sequential from there)
             }
             end0 = f.bitpos();
             crc0 = crc32(0, win.data() + h, op0 - h);
