@@ -27,6 +27,13 @@
 #include <immintrin.h>
 #include <zlib.h>                   // crc32_combine only
 
+// function clones are resolved through ifuncs, which run before ThreadSanitizer's runtime is up: none in such builds
+#if defined(__SANITIZE_THREAD__)
+#define GZ_CLONES
+#else
+#define GZ_CLONES __attribute__((target_clones("bmi2", "default")))
+#endif
+
 namespace gz {
 typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
 
@@ -311,7 +318,7 @@ struct Inflater {
 
     // Decodes until the output chunk [.., out_end) is full, the stream's final block has ended (st == END), or an error (false).
     // `lo` = first byte of valid history in `out`; `op` = write position (in / out).
-    __attribute__((target_clones("bmi2", "default")))            // (shrx / bzhi for the variable shifts and masks of the loop where the CPU has them: ~7 %)
+    GZ_CLONES                                                // (shrx / bzhi for the variable shifts and masks of the loop where the CPU has them: ~7 %)
     bool run(u8* out, size_t lo, size_t& op_io, size_t out_end) {
         size_t op = op_io;
         constexpr u32 LM = (1u << LIT_BITS) - 1, DM = (1u << DIST_BITS) - 1;
@@ -435,7 +442,7 @@ struct Inflater {
     // true when: the room is nearly used up (op > out_end - 512: call again with more), the final block has ended (st == END), the stop bit
     // was reached in front of a block header (stopped), or the last 32 KiB hold no marker (*clean: the caller goes on with run() on bytes).
     // last_marker = index behind the last marker written (in / out).
-    __attribute__((target_clones("bmi2", "default")))
+    GZ_CLONES
     bool run_spec(u16* out, size_t& op_io, size_t out_end, size_t& last_marker, bool& clean) {
         size_t op = op_io;
         constexpr u32 LM = (1u << LIT_BITS) - 1, DM = (1u << DIST_BITS) - 1;
