@@ -375,8 +375,11 @@ struct Lz4In {
             if (ml == 15) { u8 b; do { if (i >= n) return false; b = src[i++]; ml += b; } while (b == 255); }
             ml += 4;
             if (off == 0 || off > out.size()) return false;
-            size_t from = out.size() - off;
-            for (size_t j = 0; j < ml; ++j) out.push_back(out[from + j]);       // byte by byte: matches may overlap their own output
+            const size_t from = out.size() - off, to = out.size();
+            out.resize(to + ml);
+            u8* o = out.data();
+            if (off >= ml) memcpy(o + to, o + from, ml);                        // the usual case: source and destination apart
+            else for (size_t j = 0; j < ml; ++j) o[to + j] = o[from + j];       // a match that overlaps its own output repeats it: byte by byte
         }
         return true;
     }
