@@ -649,9 +649,10 @@ size_t complete_prefix(const u8* m, size_t n, bool fasta) {
         bool any = false;
         size_t q = next_record_start(m, n, p, false);
         while (q < n) {
-            size_t e = q;
-            for (int l = 0; l < 4; ++l) e = line_end(m, n, e) + 1;                // behind the record's fourth line
-            last_end = std::min(e, n); any = true;
+            size_t e = q; bool whole = true;
+            for (int l = 0; l < 4 && whole; ++l) { const size_t le = line_end(m, n, e); whole = le < n; e = le + 1; }      // behind the record's fourth line
+            if (!whole) break;                                                    // its last line has no terminator in the window yet (a "\r\n" may be cut in two): carried over
+            last_end = e; any = true;
             if (last_end >= n) break;
             q = next_record_start(m, n, last_end, false);
         }

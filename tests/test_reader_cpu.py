@@ -424,3 +424,16 @@ def test_ordinary_gzip_stream_on_several_threads(tmp_path):
     p.write_bytes(z[:len(z) * 2 // 3])
     with pytest.raises(RuntimeError):
         collect(str(p), threads=4)
+
+
+def test_gzip_window_cut_between_a_line_and_its_crlf(tmp_path):
+    """windows of inflated text end anywhere — also between the last quality character of a record and its "\\r\\n", where the record must count as incomplete
+    (a lone "\\r" in front of the next header would otherwise be read as a header line): every alignment of 101-byte records against the 64 KiB window"""
+    body = b"".join(b"@r%04d\r\n" % i + b"ACGT" * 11 + b"\r\n+\r\n" + b"I" * 44 + b"\r\n" for i in range(2000))
+    want_body = [b"ACGT" * 11] * 2000
+    for shift in range(101):                                          # 2 * shift runs through every residue modulo the record size
+        first = b"@first\r\n" + b"A" * shift + b"\r\n+\r\n" + b"#" * shift + b"\r\n"
+        p = tmp_path / "c.fastq.gz"
+        p.write_bytes(gzip.compress(first + body, 1))
+        got, _ = collect(str(p), max_bases=1, threads=3)
+        assert got == [b"A" * shift] + want_body, shift
