@@ -16,6 +16,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -650,6 +651,7 @@ struct GzIn {
         is_bgzf = parse_header(in, n, 0, m) && m.bgzf;
         inf = new Inflater();
         win.resize(HIST + CHUNK + 64);
+        if (const char* e = getenv("MDBG_GZ_PIECE")) { const long v = atol(e); if (v >= 1024) SPEC_C = (size_t)v; }      // small pieces: the piecewise path on small test files
     }
     bool fail(const char* m) { bad = true; err = m; return false; }
 
@@ -717,7 +719,7 @@ struct GzIn {
     // window (behind the history), the others without history into buffers of their own; then the pieces are accepted in order, each only if
     // the one in front ended at the bit it started at, and copied behind each other with their markers replaced.
     // 1: bytes produced; 2: none, but the member has ended; 0: not worth a round (or the last one found nothing): sequential from cur_bit; -1: error
-    static constexpr size_t SPEC_C = 1u << 20;                        // smallest piece (compressed bytes); pieces grow with what is left, up to 8x
+    size_t SPEC_C = 1u << 20;                                          // smallest piece (compressed bytes); pieces grow with what is left, up to 8x (MDBG_GZ_PIECE: test hook)
     static constexpr int SPEC_MIN_THREADS = 3;                          // (a piece decoded without history costs about twice its sequential time)
     bool spec_on = false, spec_quit = false; size_t cur_bit = 0;
     u64 st_rounds = 0, st_pieces = 0, st_offered = 0;                   // rounds, pieces accepted / started (statistics)

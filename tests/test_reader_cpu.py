@@ -437,3 +437,29 @@ def test_gzip_window_cut_between_a_line_and_its_crlf(tmp_path):
         p.write_bytes(gzip.compress(first + body, 1))
         got, _ = collect(str(p), max_bases=1, threads=3)
         assert got == [b"A" * shift] + want_body, shift
+
+
+@pytest.mark.parametrize("piece", [3000, 20000, 90000])
+def test_piecewise_gzip_path_on_small_files(piece, tmp_path, monkeypatch):
+    """MDBG_GZ_PIECE (test hook: smallest piece of the several-thread path of an ordinary gzip stream) makes small files take that path: pieces that end with
+    markers unresolved, rounds that accept only some pieces, members that end inside a piece — the payloads of the decoder test, every level and strategy"""
+    import zlib
+    monkeypatch.setenv("MDBG_GZ_PIECE", str(piece))
+    raw, want = _payloads()
+    files = {"l%d" % lvl: gzip.compress(raw, lvl) for lvl in (1, 6, 9)}
+    for name, strat in (("huffman", zlib.Z_HUFFMAN_ONLY), ("rle", zlib.Z_RLE), ("fixed", zlib.Z_FIXED)):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strat)
+        files[name] = c.compress(raw) + c.flush()
+    cut = [0, 400_000, 400_001, 1_500_000, len(raw)]
+    files["members"] = b"".join(_member(raw[a:b]) for a, b in zip(cut, cut[1:])) + _member(b"")
+    for name, data in files.items():
+        p = tmp_path / ("%s.fa.gz" % name)
+        p.write_bytes(data)
+        for threads in (4, 7):
+            got, _ = collect(str(p), max_bases=200_000, threads=threads)
+            assert got == want, (name, threads)
+    bad = bytearray(files["l6"]); bad[len(bad) // 2] ^= 2
+    p = tmp_path / "bad.fa.gz"
+    p.write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError):
+        collect(str(p), threads=5)
