@@ -166,14 +166,17 @@ struct Inflater {
     void byte_align() { normalize(); const u32 drop = bc & 7; bb >>= drop; bc -= drop; ip -= bc >> 3; bb = 0; bc = 0; }
 
     // canonical Huffman code -> lookup table (codes are read LSB first: entries are indexed by the bit-reversed code)
-    // kind_of(sym, &extra, &value) describes a symbol.  Incomplete codes leave K_BAD entries; oversubscribed ones are rejected.
+    // kind_of(sym, &extra, &value) describes a symbol.  Oversubscribed codes are rejected, and so are incomplete ones as zlib does it (inftrees.c): the code of the
+    // code lengths must be complete, the other two may be incomplete only as a single code of one bit (or empty); what may stay unused holds K_BAD entries.
     template <class F>
-    bool build(const u8* lens, int n, u32* tab, int P, int cap, F kind_of) {
+    bool build(const u8* lens, int n, u32* tab, int P, int cap, F kind_of, bool code_lengths = false) {
         u16 count[16] = {0}; u16 next[16];
         for (int i = 0; i < n; ++i) ++count[lens[i]];
         count[0] = 0;
         int left = 1;
-        for (int l = 1; l <= 15; ++l) { left <<= 1; left -= count[l]; if (left < 0) return fail("oversubscribed Huffman code"); }
+        int maxlen = 0;
+        for (int l = 1; l <= 15; ++l) { left <<= 1; left -= count[l]; if (left < 0) return fail("oversubscribed Huffman code"); if (count[l]) maxlen = l; }
+        if (left > 0 && maxlen != 0 && (code_lengths || maxlen != 1)) return fail("incomplete Huffman code");
         u32 code = 0;
         for (int l = 1; l <= 15; ++l) { code = (code + count[l - 1]) << 1; next[l] = (u16)code; }
         const u32 PM = (1u << P) - 1;
@@ -268,7 +271,7 @@ struct Inflater {
             u8 cl[19] = {0};
             for (int i = 0; i < hclen; ++i) { if (!need(3)) return fail("truncated deflate stream"); cl[order[i]] = (u8)take(3); }
             u32 cltab[128];
-            if (!build(cl, 19, cltab, 7, 128, [](int s, u32&, u32& value) { value = (u32)s; return (u32)K_LIT; })) return false;
+            if (!build(cl, 19, cltab, 7, 128, [](int s, u32&, u32& value) { value = (u32)s; return (u32)K_LIT; }, true)) return false;
             int i = 0;
             while (i < hlit + hdist) {
                 if (!need(7 + 7)) { if (!need(1)) return fail("truncated deflate stream"); }      // (the tail of the stream may hold fewer than 14 bits)
