@@ -584,7 +584,11 @@ inline bool parse_header(const u8* p, size_t n, size_t at, Member& m) {
     }
     if (flg & 8) { while (q < n && p[q]) ++q; if (q >= n) return false; ++q; }
     if (flg & 16) { while (q < n && p[q]) ++q; if (q >= n) return false; ++q; }
-    if (flg & 2) { if (q + 2 > n) return false; q += 2; }
+    if (flg & 2) {                                                     // CRC-16 of the header (zlib and flate2 check it)
+        if (q + 2 > n) return false;
+        if ((crc32(0, p + at, q - at) & 0xFFFF) != (p[q] | (u32)p[q + 1] << 8)) return false;
+        q += 2;
+    }
     m.data = q;
     return true;
 }

@@ -352,6 +352,8 @@ def test_gzip_decoder_rejects_damaged_streams(tmp_path):
     flipped = bytearray(good); flipped[len(good) // 3] ^= 0x10
     fails(bytes(flipped))                                            # a bit in the middle: caught by the decoder or, at the latest, by the CRC
     fails(good + b"\x1f\x8b\x08\xe0" + bytes(20))                    # a second member with reserved flag bits
+    hdr = bytearray(_member(raw[:50_000])); hdr[14] ^= 0x01            # a byte of the extra field: the header's CRC-16 no longer matches (zlib and flate2 check it)
+    fails(bytes(hdr))
     bg = bytearray(_bgzf(raw))
     bg[len(bg) // 2] ^= 0x04
     fails(bytes(bg), threads=1)
