@@ -23,6 +23,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include <immintrin.h>
@@ -37,6 +38,13 @@
 
 namespace gz {
 typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
+// vectors whose resize does not fill: the buffers below grow by tens of MB and are written front to back right after
+template <class T> struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a) { if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<u8, NoInit<u8>> Bytes;
+typedef std::vector<u16, NoInit<u16>> Syms;
 
 // ---- CRC-32 (IEEE 802.3, reflected; RFC 1952 section 8) -----------------------------------------------------------------------
 struct CrcTables {
@@ -604,8 +612,8 @@ inline bool parse_header(const u8* p, size_t n, size_t at, Member& m) {
 struct SpecChunk {
     size_t start_bit = 0, end_bit = 0; bool found = false, hit_end = false, gave_up = false;
     size_t sym_cap = 32u << 20, byte_cap = 256u << 20;        // a piece that needs more is left to the sequential decoder (very compressible data): set by the caller
-    std::vector<u16> sym; size_t nsym = 0;            // decoded without history: bytes and markers
-    std::vector<u8> bytes; size_t nbytes = 0;         // ... and from where no marker can be referred to any more: [0, 32768) repeats the end of sym
+    Syms sym; size_t nsym = 0;                        // decoded without history: bytes and markers
+    Bytes bytes; size_t nbytes = 0;         // ... and from where no marker can be referred to any more: [0, 32768) repeats the end of sym
     // the first block at or behind from_bit (searched up to limit_bit) from which the stream decodes up to the first block boundary at or behind stop_bit
     void decode(const u8* in, size_t n, size_t from_bit, size_t limit_bit, size_t stop_bit, Inflater& f) {
         found = false; gave_up = false;
@@ -647,7 +655,7 @@ struct GzIn {
     bool in_member = false, bad = false, done = false, is_bgzf = false;
     const char* err = nullptr;
     Inflater* inf = nullptr;
-    std::vector<u8> win; size_t lo = 0, rd = 0, wr = 0;               // window: history from lo, unread bytes [rd, wr)
+    Bytes win; size_t lo = 0, rd = 0, wr = 0;                         // window: history from lo, unread bytes [rd, wr)
     u32 crc = 0; u64 produced = 0;                                     // of the member being decoded
     static constexpr size_t HIST = 32768, CHUNK = 1u << 20;
 
