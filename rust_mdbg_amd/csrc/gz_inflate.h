@@ -613,7 +613,8 @@ struct SpecChunk {
     size_t start_bit = 0, end_bit = 0; bool found = false, hit_end = false, gave_up = false;
     size_t sym_cap = 32u << 20, byte_cap = 256u << 20;        // a piece that needs more is left to the sequential decoder (very compressible data): set by the caller
     Syms sym; size_t nsym = 0;                        // decoded without history: bytes and markers
-    Bytes bytes; size_t nbytes = 0;         // ... and from where no marker can be referred to any more: [0, 32768) repeats the end of sym
+    Bytes bytes; size_t nbytes = 0;
+    Bytes res;                                        // sym[0, nsym) as bytes, once the 32 KiB in front are known (GzIn::produce_spec)         // ... and from where no marker can be referred to any more: [0, 32768) repeats the end of sym
     // the first block at or behind from_bit (searched up to limit_bit) from which the stream decodes up to the first block boundary at or behind stop_bit
     void decode(const u8* in, size_t n, size_t from_bit, size_t limit_bit, size_t stop_bit, Inflater& f) {
         found = false; gave_up = false;
@@ -707,7 +708,12 @@ struct GzIn {
         lo = 0; rd = wr = keep;
     }
     bool produce() {
-        if (rd != wr) return true;
+        if (rd != wr || seg_i < segs.size()) return true;
+        if (!segs.empty()) {                                            // a round's segments have been read: their end is the history now
+            segs.clear(); seg_i = 0;
+            memcpy(win.data(), tail.data(), tail.size());
+            lo = 0; rd = wr = tail.size();
+        }
         if (wr > HIST || (spec_on && in_member)) slide();
         if (spec_on && in_member) {
             const int r = produce_spec();
@@ -738,6 +744,9 @@ struct GzIn {
     static constexpr int SPEC_MIN_THREADS = 3;                          // (a piece decoded without history costs about twice its sequential time)
     bool spec_on = false, spec_quit = false; size_t cur_bit = 0;
     u64 st_rounds = 0, st_pieces = 0, st_offered = 0;                   // rounds, pieces accepted / started (statistics)
+    struct Seg { const u8* p; size_t n; };
+    std::vector<Seg> segs; size_t seg_i = 0, seg_rd = 0;               // output of a round behind win[rd, wr): the pieces' own buffers, in order
+    Bytes tail;                                                         // its last 32 KiB
     u32 st_member_rounds = 0, spec_skip = 0;                            // rounds of this member so far; members to read sequentially before the next try
     std::vector<SpecChunk> chunks;
     int produce_spec() {
@@ -773,44 +782,54 @@ struct GzIn {
             for (auto& x : th) x.join();
         }
         if (err0) { fail(err0); return -1; }
-        // which pieces follow each other, and where they go
-        struct Place { size_t off, len; const u8* window; u32 crc; };
+        // which pieces follow each other.  Their bytes are NOT copied behind the first piece: read() takes them where they are (segs) — only the symbols of a
+        // piece's first part are turned into bytes (res), with the 32 KiB in front of the piece
+        struct Place { size_t len; const u8* window; u32 crc; };
         std::vector<Place> place((size_t)T);
-        size_t end = end0, w = op0; bool ended = hit_end0; int accepted = 1;
+        size_t end = end0, w = op0, total = op0 - h; bool ended = hit_end0; int accepted = 1;
         for (int k = 1; k < T && !ended; ++k) {
             SpecChunk& c = chunks[(size_t)k];
             if (!c.found || c.start_bit != end) break;
-            // the 32 KiB in front of the piece: the end of the first piece (in the window already) or the marker-free end of the piece before
+            // the 32 KiB in front of the piece: the end of the first piece (in the window) or the marker-free end of the piece before
             const u8* window = nullptr;
-            if (k == 1) { if (w >= 32768) window = win.data() + w - 32768; }      // (win is not resized between here and its use: see below)
+            if (k == 1) { if (w >= 32768) window = win.data() + w - 32768; }
             else { const SpecChunk& p = chunks[(size_t)k - 1]; if (p.nbytes >= 65536) window = p.bytes.data() + p.nbytes - 32768; }
             if (!window && c.nsym) break;                               // rare (a piece of markers only, or a member's first 32 KiB): the next round starts here
             const size_t more = c.nsym + (c.nbytes > 32768 ? c.nbytes - 32768 : 0);
-            place[(size_t)k] = Place{w, more, window, 0};
-            w += more; end = c.end_bit; ended = c.hit_end; ++accepted;
+            place[(size_t)k] = Place{more, window, 0};
+            total += more; end = c.end_bit; ended = c.hit_end; ++accepted;
         }
-        if (win.size() < w + 64) {                                      // (k == 1's window pointer moves with the buffer)
-            const size_t w1 = accepted > 1 ? place[1].off : 0;
-            win.resize(w + w / 8 + 64);
-            if (accepted > 1 && place[1].window) place[1].window = win.data() + w1 - 32768;
-        }
-        auto settle = [&](int k) {                                      // markers replaced, bytes copied behind, CRC of the piece
+        auto settle = [&](int k) {                                      // markers replaced, CRC of the piece
             SpecChunk& c = chunks[(size_t)k]; Place& pl = place[(size_t)k];
-            u8* o = win.data() + pl.off;
+            if (c.res.size() < c.nsym) c.res.resize(c.nsym + c.nsym / 8);
+            u8* o = c.res.data();
             for (size_t i = 0; i < c.nsym; ++i) { const u16 v = c.sym[i]; o[i] = v < 256 ? (u8)v : pl.window[v - 256]; }
-            if (c.nbytes > 32768) memcpy(o + c.nsym, c.bytes.data() + 32768, c.nbytes - 32768);
-            pl.crc = crc32(0, o, pl.len);
+            pl.crc = crc32(0, o, c.nsym);
+            if (c.nbytes > 32768) pl.crc = crc32(pl.crc, c.bytes.data() + 32768, c.nbytes - 32768);
         };
         if (accepted > 1) {
-            // place[1].window may lie in win right in front of piece 1's own output: it is read while only places behind it are written
             std::vector<std::thread> th;
             for (int k = 2; k < accepted; ++k) th.emplace_back(settle, k);
             settle(1);
             for (auto& x : th) x.join();
         }
+        segs.clear(); seg_i = 0; seg_rd = 0;
+        for (int k = 1; k < accepted; ++k) {
+            const SpecChunk& c = chunks[(size_t)k];
+            if (c.nsym) segs.push_back(Seg{c.res.data(), c.nsym});
+            if (c.nbytes > 32768) segs.push_back(Seg{c.bytes.data() + 32768, c.nbytes - 32768});
+        }
+        // the last 32 KiB of the round (history of what follows), gathered from the back: put in front of the window when the segments have been read
+        tail.clear();
+        if (!segs.empty()) {
+            size_t need = HIST; std::vector<Seg> back;
+            for (size_t i = segs.size(); i-- > 0 && need;) { const size_t t = std::min(need, segs[i].n); back.push_back(Seg{segs[i].p + segs[i].n - t, t}); need -= t; }
+            if (need) { const size_t t = std::min(need, w); back.push_back(Seg{win.data() + w - t, t}); }      // (history + first piece, as far as it goes)
+            for (size_t i = back.size(); i-- > 0;) tail.insert(tail.end(), back[i].p, back[i].p + back[i].n);
+        }
         crc = (u32)::crc32_combine(crc, crc0, (z_off_t)(op0 - h));
         for (int k = 1; k < accepted; ++k) crc = (u32)::crc32_combine(crc, place[(size_t)k].crc, (z_off_t)place[(size_t)k].len);
-        produced += w - h;
+        produced += total;
         cur_bit = end;
         rd = h; wr = w;
         ++st_rounds; st_pieces += (u64)accepted; st_offered += (u64)T;
@@ -825,7 +844,7 @@ struct GzIn {
             at = q + 8; in_member = false; spec_on = false;
             if (accepted == 1 && rounds_before == 0) spec_skip = 64;    // the whole member was inside the first piece: the next ones sequentially
         } else if (accepted == 1) spec_quit = true;                     // nothing found behind the first piece (stored data?): the rest of the member sequentially
-        return w > h ? 1 : ended ? 2 : 0;
+        return total ? 1 : ended ? 2 : 0;
     }
     // BGZF: the next blocks (about CHUNK bytes of text per thread), every one inflated on its own into its place
     std::vector<Inflater*> pool;
@@ -882,9 +901,15 @@ struct GzIn {
     int read(u8* dst, size_t want) {                                   // bytes delivered, 0 at the end, -1 on a malformed stream
         size_t got = 0;
         while (got < want) {
-            if (rd == wr) { if (done || bad || !produce()) break; continue; }
-            const size_t take = std::min(want - got, wr - rd);
-            memcpy(dst + got, win.data() + rd, take); rd += take; got += take;
+            if (rd != wr) {
+                const size_t take = std::min(want - got, wr - rd);
+                memcpy(dst + got, win.data() + rd, take); rd += take; got += take;
+            } else if (seg_i < segs.size()) {
+                const Seg& sg = segs[seg_i];
+                const size_t take = std::min(want - got, sg.n - seg_rd);
+                memcpy(dst + got, sg.p + seg_rd, take); seg_rd += take; got += take;
+                if (seg_rd == sg.n) { ++seg_i; seg_rd = 0; }
+            } else if (done || bad || !produce()) break;
         }
         return bad ? -1 : (int)got;
     }
