@@ -109,7 +109,8 @@ typedef struct mdbg_stats {
     double ms_sketch_tile;      /* of ms_sketch: time inside sketch_tile_kernel launches only (HIP events around each launch) */
     uint64_t n_sketch_tile_launches;
     uint64_t n_sketch_tile_bases; /* raw bases covered by those launches */
-    uint64_t reserved[5];
+    uint64_t tile_bases;        /* raw bases a tile owns under this context's parameters (n_tiles = sum over batches of ceil(batch bases / tile_bases)) */
+    uint64_t reserved[4];
 } mdbg_stats;
 
 mdbg_ctx* mdbg_create(const mdbg_params* p, int* err);

@@ -9,12 +9,20 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 // ---- tile geometry of the sketch kernel (sketch.hip) ----------------------------------------------
-// One workgroup = 256 lanes stages TILE_RAW_WORDS words of 32 raw bases: HALO_BASES of look-back (owned by the tile
-// in front) followed by the TILE_STRIDE bases whose l-mer END positions the tile owns.
-constexpr int TILE_THREADS = 256;
-constexpr int TILE_RAW_WORDS = 1024;
-constexpr int HALO_BASES = 256;
-constexpr int TILE_STRIDE = TILE_RAW_WORDS * 32 - HALO_BASES;   // 32,512 raw bases per tile
+// A tile is staged by NW waves of 64 lanes, four words of 32 raw bases per lane: HALO bases of look-back (owned by the tile in
+// front) followed by the STRIDE bases whose l-mer END positions the tile owns.  Two geometries are compiled:
+//   NW = 1  one WAVE per tile (8,192 bases staged, 128 of look-back): no workgroup barrier anywhere in the tile's life, the waves of
+//           a CU drift apart and their phases (compaction: VALU, filter: VALU + crossbar, exact evaluation: LDS + scalar) overlap;
+//   NW = 4  one 256-lane workgroup per tile (32,768 staged, 256 of look-back): rounds 1-3; still used by the syncmer scheme.
+// The host picks one per context (TileShape); everything behind the tile kernel (slabs, scans, gather) only sees tile counts.
+constexpr int TILE_WPT = 4;                       // raw words per lane
+template <int NW> struct TileGeo {
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int RAW_WORDS = TILE_WPT * THREADS;
+    static constexpr int HALO_BASES = NW == 1 ? 128 : 256;
+    static constexpr int STRIDE = RAW_WORDS * 32 - HALO_BASES;       // NW = 4: 32,512 raw bases per tile; NW = 1: 8,064
+};
+struct TileShape { u32 nw, tpw, stride, halo; };   // tpw: tiles per workgroup of the launch (NW = 1: 1 or 4 waves per workgroup)
 constexpr int MDBG_MAX_L_DEV = 32;                // = MDBG_MAX_L of the C ABI
 
 // the table slots keep the A smallest ordinals of a k-min-mer for A up to this; larger min_abundance values get the A-th sighting from a
@@ -78,6 +86,24 @@ __device__ inline u32 block_excl_scan_256(u32 v, u32* tmp, u32& total) {
     for (int i = 0; i < 4; ++i) { u32 t = tmp[i]; if (i < w) base += t; tot += t; }
     total = tot;
     return base + inc - v;
+}
+
+// ---- the same two primitives for a tile of NW waves --------------------------------------------------
+// NW = 1: the tile is one wave.  LDS instructions of one wave execute in issue order, so a store is visible to every later load of the
+// same wave whichever lane issued it: "barrier" = keep the compiler from moving LDS accesses across it, no instruction at all.
+template <int NW> __device__ __forceinline__ void tile_sync() {
+    if constexpr (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+template <int NW> __device__ __forceinline__ u32 tile_excl_scan(u32 v, u32* tmp, u32& total) {
+    if constexpr (NW == 1) {
+        const u32 inc = wave_incl_scan(v);
+        total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        return inc - v;
+    } else {
+        static_assert(NW == 4, "block scan over 256 threads");
+        return block_excl_scan_256(v, tmp, total);
+    }
 }
 
 // Sharded counters.  Same-address device atomics serialise at ~12 ns each on MI355X (MI355X_MICROARCH.md "fanin"), so

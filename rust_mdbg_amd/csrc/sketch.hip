@@ -33,8 +33,8 @@ struct SketchArgs {
     const u32* bread;            // read containing the first staged base of tile t, [n_tiles + 2]
     const TileRec* recs;         // [n_tiles] (tile_rec_kernel)
     u32 n_tiles;
-    u32 tile0;                   // workgroup b runs tile tile0 + b
-    Rec* slab; u32 slab_cap;     // records of workgroup b: slab[b * slab_cap ..), in position order
+    u32 tile0, tile_end;         // the launch runs the tiles [tile0, tile_end): workgroup b, tile slot ts -> tile tile0 + b * TPW + ts
+    Rec* slab; u32 slab_cap;     // records of the launch's i-th tile: slab[i * slab_cap ..), in position order
     u32* n_valid;                // [n_tiles] number of minimizers whose l-mer ENDS in the tile
     u32* n_scan;                 // [n_tiles] slab slots the tile used when they are NOT all valid records (dense settings: rejected candidates
                                  // stay in the slab with read = 0xFFFFFFFF and the gather squeezes them out), else 0
@@ -72,12 +72,13 @@ static_assert(sizeof(TileRec) == 48, "three 16-byte words");
 // loads each in flight together; two kernels in a row were 10 + 6 us and a launch)
 // init: scalars the sketch starts from (three zeroed, one set), folded in here: one launch less in front of the tile kernel
 struct SketchInit { u64* zero[4]; u64* set_p; u64 set_v; };
-__global__ void tile_rec_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bases, u32 n_tiles, u32* __restrict__ bread, TileRec* __restrict__ recs, SketchInit init) {
+__global__ void tile_rec_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bases, u32 n_tiles, u32* __restrict__ bread, TileRec* __restrict__ recs, SketchInit init,
+                                int64_t stride, int64_t halo) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) { for (int i = 0; i < 4; ++i) if (init.zero[i]) *init.zero[i] = 0; if (init.set_p) *init.set_p = init.set_v; }
     if (t >= n_tiles + 2) return;
     auto first_pos = [&](u32 e) -> u64 {
-        int64_t p = (int64_t)e * TILE_STRIDE - HALO_BASES;
+        int64_t p = (int64_t)e * stride - halo;
         if (p < 0) p = 0;
         if ((u64)p >= n_bases) p = n_bases ? (int64_t)n_bases - 1 : 0;
         return (u64)p;
@@ -92,7 +93,7 @@ __global__ void tile_rec_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_
     }
     bread[t] = lo0;
     if (t >= n_tiles) return;
-    const int64_t raw0 = (int64_t)t * TILE_STRIDE - HALO_BASES;
+    const int64_t raw0 = (int64_t)t * stride - halo;
     TileRec r;
     r.rl = lo0; r.rh = lo2;
     r.start0 = (int64_t)off[r.rl] - raw0;
@@ -167,46 +168,58 @@ __device__ inline bool walk_lmer(const Src& s, u64 rlo, u64 p, u32 l, u64& start
 }
 
 // ---- tile state in LDS ------------------------------------------------------------------------------------
-constexpr int RW = TILE_RAW_WORDS;            // raw words staged per tile (halo included)
-constexpr int HW = HALO_BASES / 32;           // leading halo words
-constexpr int TT = TILE_THREADS;
-constexpr int WPT = RW / TT;                  // raw words per thread
+constexpr int WPT = TILE_WPT;                 // raw words per thread
 constexpr int DPAD = 4;                       // zero words in front of the dense stream (look-back of the first words)
-constexpr int QCAP = 704;                     // candidates that fit the unordered list (evaluated in rounds of TILE_THREADS); more: the word-wise rounds
-constexpr int RS_CAP = 32;                    // read starts of a tile kept in LDS (more: binary search in global memory)
+template <int NW> struct TG {                 // geometry of a tile staged by NW waves
+    static constexpr int TT = TileGeo<NW>::THREADS;
+    static constexpr int RW = TileGeo<NW>::RAW_WORDS;       // raw words staged per tile (halo included)
+    static constexpr int HALO = TileGeo<NW>::HALO_BASES;
+    static constexpr int HW = HALO / 32;                     // leading halo words
+    static constexpr int STRIDE = TileGeo<NW>::STRIDE;
+    static constexpr int QCAP = NW == 4 ? 704 : 176;         // candidates that fit the unordered list (evaluated in rounds of TT); more: the word-wise rounds
+    static constexpr int RS_CAP = NW == 4 ? 32 : 8;          // read starts of a tile kept in LDS (more: binary search in global memory)
+    static_assert(RW == WPT * TT && HW % WPT == 0 && HW % 2 == 0 && (RW - HW) % 2 == 0, "the halo is a whole number of threads; 16-byte aligned word pairs per thread");
+};
 
-struct __attribute__((aligned(16))) TileLds {
-    u32 dense[2 * (DPAD + RW + 4)];           // dense word D: planes at [2 * (DPAD + D)], [.. + 1]; during phases 1-2 the first RW
+template <int NW> struct __attribute__((aligned(16))) TileLds {
+    typedef TG<NW> G;
+    u32 dense[2 * (DPAD + G::RW + 4)];        // dense word D: planes at [2 * (DPAD + D)], [.. + 1]; during phases 1-2 the first RW
                                               // words hold the read-start bitmap (every reader zeroes what it read)
-    u32 kw[RW];                               // keep mask of raw word w
-    u16 rpre[RW + 8];                         // kept bases in front of raw word w; [RW] = all
-    struct { u32 cand[RW + 8]; u16 cpre[RW + 8]; u16 list[QCAP]; u16 surv[TILE_THREADS]; } c;    // cpre doubles as the survivors' hashes (u64 x TT) before count_words
-    u64 t3[2 << (2 * BS_GS)];                 // exact evaluation: 3-base groups {F, R}
+    u32 kw[G::RW];                            // keep mask of raw word w
+    u16 rpre[G::RW + 8];                      // kept bases in front of raw word w; [RW] = all
+    struct { u32 cand[G::RW + 8]; u16 cpre[G::RW + 8]; u16 list[G::QCAP]; u16 surv[G::TT]; } c;    // cpre doubles as the survivors' hashes (u64 x TT) before count_words
     int64_t rs0;                              // start of read rl relative to the first staged position (may lie far in front of it)
-    int32_t rs_rel[RS_CAP];                   // start of read rl + i, i >= 1, likewise (clamped to 2^31 - 1)
-    u32 misc[32];                             // [0..4] scan scratch, [8] slow, [11] Hh, [16] next round, [17] list fill, [18..20] survivors per round
+    int32_t rs_rel[G::RS_CAP];                // start of read rl + i, i >= 1, likewise (clamped to 2^31 - 1)
+    u32 misc[NW == 4 ? 32 : 24];              // [0..4] scan scratch, [8] slow, [11] Hh, [16] next round, [17] list fill, [18..20] survivors per round
 #ifdef MDBG_LDS_PAD
     u32 pad_experiment[MDBG_LDS_PAD / 4];     // occupancy experiments only (scratch/build_variant.sh)
 #endif
 };
-template <int SCHEME> struct TileLdsS : TileLds {};
+constexpr int T3_WORDS = 2 << (2 * BS_GS);    // exact evaluation: 3-base groups {F, R}, one table per WORKGROUP (every wave writes the same values into it)
+template <int SCHEME, int NW> struct TileLdsS : TileLds<NW> {};
 // syncmers: + a bitmap over DENSE positions (a read starts here), padded to 32 KB: the generic machine of a flagged tile keeps its ring
 // of s-mer hashes (32 x 256 words) on top of the whole structure, which is dead by then
-template <> struct TileLdsS<1> : TileLds {
-    u32 dstart[RW + 8];
-    u32 pad_to_ring[(32 * TILE_THREADS * 4 - sizeof(TileLds) - (RW + 8) * 4) / 4];
+template <int NW> struct TileLdsS<1, NW> : TileLds<NW> {
+    u32 dstart[TG<NW>::RW + 8];
+    u32 pad_to_ring[(32 * TG<NW>::TT * 4 - sizeof(TileLds<NW>) - (TG<NW>::RW + 8) * 4) / 4];
 };
-static_assert(sizeof(TileLdsS<1>) == 32 * TILE_THREADS * 4, "the ring of the generic syncmer machine covers the tile state exactly");
+static_assert(sizeof(TileLdsS<1, 4>) == 32 * TG<4>::TT * 4, "the ring of the generic syncmer machine covers the tile state exactly");
 // FMT_ASCII stages the half planes of its 16-base chunks (2 * RW words, phase 1 only) in memory that is idle then: the part of the dense
 // stream behind the read-start bitmap plus the keep masks (the stream part is zeroed again before phase 2 writes it)
-constexpr int STAGE_AT = 2 * (DPAD + RW + 4) + RW - 2 * RW;      // index into dense[]: the stage ends where kw[] ends
-static_assert(STAGE_AT >= RW && STAGE_AT % 4 == 0 && offsetof(TileLds, kw) == sizeof(u32) * 2 * (DPAD + RW + 4), "stage = dense[STAGE_AT ..) + kw[]");
-// Six workgroups per CU (23.8 KB each).  Seven fit when the candidate list is cut to 448 entries (23.3 KB): measured the same speed,
-// five are 25 % slower — the kernel is bound by issue throughput (VALU, LDS, scalar), not by latency, from six on.
+template <int NW> struct StageAt {
+    static constexpr int RW = TG<NW>::RW;
+    static constexpr int AT = 2 * (DPAD + RW + 4) + RW - 2 * RW;      // index into dense[]: the stage ends where kw[] ends
+    static_assert(AT >= RW && AT % 4 == 0 && offsetof(TileLds<NW>, kw) == sizeof(u32) * 2 * (DPAD + RW + 4), "stage = dense[AT ..) + kw[]");
+    static_assert((2 * (DPAD + RW + 4) - AT) == 4 * TG<NW>::TT, "one 16-byte store per thread");
+};
+// NW = 4: six workgroups per CU (22.8 KB each + the 1 KB table).  NW = 1: 5.9 KB per wave tile; four of them and one table per 256-lane workgroup
+// (24.6 KB: six per CU = 24 waves), or one per 64-lane workgroup (6.9 KB: 22 per CU).
 #ifndef MDBG_LDS_PAD
-static_assert(sizeof(TileLds) * 6 <= 160 * 1024 && sizeof(TileLds) * 7 > 160 * 1024, "6 workgroups per CU");
+static_assert((sizeof(TileLds<4>) + T3_WORDS * 8) * 6 <= 160 * 1024, "NW = 4: 6 workgroups per CU");
+static_assert((sizeof(TileLds<1>) * 4 + T3_WORDS * 8) * 6 <= 160 * 1024, "NW = 1, four tiles per workgroup: 6 workgroups per CU");
 #endif
-static_assert((RW + 8) * 2 >= TILE_THREADS * 8 && ((RW + 8) * 4) % 8 == 0 && offsetof(TileLds, c) % 16 == 0, "cpre holds one u64 per thread");
+static_assert((TG<4>::RW + 8) * 2 >= TG<4>::TT * 8 && (TG<1>::RW + 8) * 2 >= TG<1>::TT * 8 && ((TG<1>::RW + 8) * 4) % 8 == 0 && offsetof(TileLds<4>, c) % 16 == 0 && offsetof(TileLds<1>, c) % 16 == 0, "cpre holds one u64 per thread");
+static_assert(TG<1>::RS_CAP > TREC_N, "the read starts of a tile record fit rs_rel");
 
 // 16 ASCII bases -> {plane0 half | plane1 half}, MSB first (base 0 in bits 31 / 15); bad != 0: a byte outside ACGT
 __device__ inline u32 ascii16_to_hp(uint4 v, u32& bad) {
@@ -265,11 +278,12 @@ __device__ inline void put_count(const SketchArgs& a, u32 gt, u32 n, bool last_k
 }
 
 // ---- generic exact path for one tile (inside the tile kernel) --------------------------------------------
-template <bool HPC, class Src>
-__device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, TileLds& S) {
-    const int tid = threadIdx.x;
-    const u64 t_lo = (u64)gt * TILE_STRIDE;
-    u64 t_hi = t_lo + TILE_STRIDE; if (t_hi > a.n_bases) t_hi = a.n_bases;
+template <bool HPC, int NW, class Src>
+__device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, TileLds<NW>& S) {
+    constexpr int TT = TG<NW>::TT;
+    const int tid = threadIdx.x % TT;
+    const u64 t_lo = (u64)gt * TG<NW>::STRIDE;
+    u64 t_hi = t_lo + TG<NW>::STRIDE; if (t_hi > a.n_bases) t_hi = a.n_bases;
     const u32 rl = a.bread[gt], rh_ = a.bread[gt + 2];
     const u64 first_base = a.offsets[0];
     u32* tmp = S.misc;
@@ -286,7 +300,7 @@ __device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab
             if (kept_at<HPC>(src, rlo, p) && walk_lmer<HPC>(src, rlo, p, a.l, start, hash) && hash <= a.bound) sel = 1;
         }
         u32 total;
-        const u32 rank = block_excl_scan_256(sel, tmp, total);
+        const u32 rank = tile_excl_scan<NW>(sel, tmp, total);
         if (sel) put_rec(a, slab, running + rank, hash, (u32)(start - rlo), r + a.read_base);
         running += total;
     }
@@ -341,7 +355,8 @@ __device__ inline u32 nt4_code(u8 c) {                         // src/read.rs:23
 
 // dq: per-thread ring of the last <= 32 s-mer hashes (s <= 16: 32 bits), column = thread; sc_tmp: 8 words of scan scratch + 1 flag
 template <bool HPC, class Src>
-__device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[TILE_THREADS], u32* sc_tmp) {
+__device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[TG<4>::TT], u32* sc_tmp) {
+    constexpr int TT = TG<4>::TT, TILE_STRIDE = TG<4>::STRIDE;      // (the syncmer scheme runs on the 256-lane tiles)
     constexpr u32 SEG = (TILE_STRIDE + TT - 1) / TT;           // raw positions per thread
     u32& any_over = sc_tmp[8];
     const int tid = threadIdx.x;
@@ -445,29 +460,37 @@ __device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, co
 // ---- fast tile kernel ---------------------------------------------------------------------------------------------
 struct CandOut { u64 hash; u32 pos, read; };
 
-// One tile per workgroup.  (A persistent variant — workgroups looping over tiles with the next tile's words prefetched — was measured
+// One tile per NW waves; TPW tiles per workgroup (TPW > 1 only with NW = 1: independent wave tiles that share the exact-hash table and
+// never meet at a barrier).  (A persistent variant — workgroups looping over tiles with the next tile's words prefetched — was measured
 // and dropped: the loop makes the compiler keep ~100 more values live across the phases, 3-4 instead of 6 waves per SIMD, 3.4-4.9 ms
 // instead of 2.2 ms; capped to 80 registers it spills and is no better.  profiles/r02_notes.md.)
 // SCHEME 0: density scheme, L = l (compile-time: every shift of the bit-sliced filter is a constant).  SCHEME 1: syncmers, L = 0 and l
 // comes from the arguments (no bit-sliced filter: phase 3 is the window-minimum machine over the dense stream).
 // WMAX (syncmers): the window w = l - s + 1 itself (1 .. 32): the register window of s-mer hashes and its loops are unrolled over exactly w entries
 // with static register indices
-template <int L, int SCHEME = 0, int WMAX = 1>
-__global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArgs a) {
-    __shared__ TileLdsS<SCHEME> S;
+template <int L, int SCHEME = 0, int WMAX = 1, int NW = 4, int TPW = 1>
+__global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArgs a) {
+    typedef TG<NW> G;
+    constexpr int TT = G::TT, RW = G::RW, HW = G::HW, QCAP = G::QCAP, RS_CAP = G::RS_CAP, STAGE_AT = StageAt<NW>::AT;
+    static_assert(TPW == 1 || NW == 1, "several tiles per workgroup: wave tiles only (no workgroup barrier inside a tile)");
+    static_assert(SCHEME == 0 || (NW == 4 && TPW == 1), "the syncmer scheme runs on the 256-lane tiles");
+    __shared__ TileLdsS<SCHEME, NW> S_all[TPW];
+    __shared__ u64 S_t3[T3_WORDS];
     __shared__ u32 sync_tmp[SCHEME ? 16 : 1];       // scan scratch of the generic syncmer machine (its ring covers S)
     const u32 Lr = SCHEME ? a.l : (u32)L;           // l
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tslot = TPW == 1 ? 0 : (int)(threadIdx.x / TT);
+    const int tid = TPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x % TT), lane = tid & 63, wv = NW == 1 ? 0 : tid >> 6;
+    TileLdsS<SCHEME, NW>& S = S_all[tslot];
     const int64_t nb = (int64_t)a.n_bases;
     const int64_t n_pairs = (nb + 31) >> 5;
     const bool hpc = a.hpc != 0;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    static_assert(WPT % 2 == 0 && (HALO_BASES / 32) % 2 == 0 && ((TILE_RAW_WORDS - HALO_BASES / 32) % 2) == 0, "16-byte aligned word pairs per thread");
-    const u32 wg = blockIdx.x, gt = a.tile0 + wg;
+    const u32 wg = blockIdx.x * TPW + (u32)tslot, gt = a.tile0 + wg;       // the launch's wg-th tile
+    if (TPW > 1 && gt >= a.tile_end) return;          // (a whole wave; nothing below waits for it)
     Rec* const slab = a.slab + (size_t)wg * a.slab_cap;
 #define MDBG_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(size_t)gt * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
     MDBG_STAMP(0);
-    const int64_t raw0 = (int64_t)gt * TILE_STRIDE - HALO_BASES;      // first staged raw position (negative for tile 0)
+    const int64_t raw0 = (int64_t)gt * G::STRIDE - G::HALO;      // first staged raw position (negative for tile 0)
     const bool interior = raw0 >= 0 && raw0 + RW * 32 <= nb;
     const TileRec* const rec = a.recs + gt;
     // (the record is read with vector loads — the compiler cannot prove it read-only —, so what is the same in every lane is moved to scalar
@@ -502,14 +525,16 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
     const u32 rl = (u32)__builtin_amdgcn_readfirstlane((int)rec->rl), rh_ = (u32)__builtin_amdgcn_readfirstlane((int)rec->rh);
     static_assert((2 * (DPAD + RW + 4)) % 4 == 0, "the dense stream is a whole number of 16-byte words");
     for (int i = tid; i < 2 * (DPAD + RW + 4) / 4; i += TT) ((uint4*)S.dense)[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (SCHEME == 0) { if (tid < (2 << (2 * BS_GS))) S.t3[tid] = a.t4[tid]; }
-    else {                                            // 8 bits -> 16 bits, bit i to bit 2 i: the exact phase interleaves the code planes with it
+    if (SCHEME == 0) {                                // (TPW > 1: every wave writes the whole table — the same values — so none waits for another)
+        static_assert(T3_WORDS % 64 == 0 && T3_WORDS <= 4 * 64, "the table is copied by the lanes of one wave");
+        for (int i = tid; i < T3_WORDS; i += TT) S_t3[i] = a.t4[i];
+    } else {                                          // 8 bits -> 16 bits, bit i to bit 2 i: the exact phase interleaves the code planes with it
         u32 v = 0;
         for (int i = 0; i < 8; ++i) v |= ((u32)tid >> i & 1u) << (2 * i);
-        ((u16*)S.t3)[tid] = (u16)v;
+        ((u16*)S_t3)[tid] = (u16)v;
     }
     if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[9] = 0; S.misc[11] = 0; S.misc[17] = 0; S.misc[18] = 0; S.misc[19] = 0; S.misc[20] = 0; }
-    __syncthreads();
+    tile_sync<NW>();
     if (rh_ - rl < (u32)TREC_N) {                       // the usual case: the read starts come with the tile's record
         if ((u32)tid <= rh_ - rl) {
             const int64_t rel = tid == 0 ? rec->start0 : (int64_t)rec->rel[tid - 1];
@@ -548,20 +573,20 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
                 }
             }
         }
-        __syncthreads();
+        tile_sync<NW>();
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const uint2 h = *(const uint2*)(stage + 2 * (WPT * tid + i));
             x0[i] = (h.x & 0xFFFF0000u) | (h.y >> 16); x1[i] = (h.x << 16) | (h.y & 0xFFFFu);
         }
         if (tid) { const u32 hp = stage[2 * WPT * tid - 1]; pv0 = hp >> 16; pv1 = hp; }
-        __syncthreads();                                     // the stage has been read: its stream part goes back to zero (the barriers of the scan below order this before the stream writes)
+        tile_sync<NW>();                                     // the stage has been read: its stream part goes back to zero (the barriers of the scan below order this before the stream writes)
         static_assert((2 * (DPAD + RW + 4) - STAGE_AT) == 4 * TT && STAGE_AT % 4 == 0, "one 16-byte store per thread");
         ((uint4*)(S.dense + STAGE_AT))[tid] = make_uint4(0u, 0u, 0u, 0u);
     } else {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) { x0[i] = __brev(pr[i].x); x1[i] = __brev(pr[i].y); }
-        __syncthreads();
+        tile_sync<NW>();
     }
     MDBG_STAMP(1);
     if (a.stop_phase == 1) { if (tid == 0) a.n_valid[gt] = x0[0] == 0x12345u; return; }
@@ -607,7 +632,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         }
     }
     u32 H;
-    u32 off = block_excl_scan_256(mine, S.misc, H);          // (its barriers also order the bitmap reset before the stream writes)
+    u32 off = tile_excl_scan<NW>(mine, S.misc, H);          // (its barriers also order the bitmap reset before the stream writes)
     static_assert(HW % WPT == 0, "the halo is a whole number of threads");
     if (tid == HW / WPT) S.misc[11] = off;                   // kept bases of the halo words
     if (tid == TT - 1) S.rpre[RW] = (u16)H;
@@ -628,7 +653,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         }
         off += n;
     }
-    __syncthreads();
+    tile_sync<NW>();
     MDBG_STAMP(2);
     if (a.stop_phase == 2) { if (tid == 0) a.n_valid[gt] = 0; return; }
     const u32 Hh = S.misc[11];
@@ -639,11 +664,11 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
             if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
             else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
         } else {
-            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); }
-            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TILE_THREADS])&S, sync_tmp); }
+            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); }
+            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); }
         }
     };
-    if (S.misc[8] || (!true_start && Hh < Lr)) { __syncthreads(); run_slow_tile(); return; }
+    if (S.misc[8] || (!true_start && Hh < Lr)) { tile_sync<NW>(); run_slow_tile(); return; }
 
     // ---- phase 3: bit-sliced filter over the dense stream -> candidate bitmap + (unordered) candidate list ---------------
     // candidate plane coordinate x = e + BS_B - 1; owned END positions e in [max(Hh, L-1), H)
@@ -690,7 +715,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         const u32 l = a.l, sm = a.s, w = l - sm + 1, t = (w + 1) / 2;
         const u32 smask = sm ? (sm >= 16 ? 0xFFFFFFFFu : (1u << (2 * sm)) - 1u) : 0u, sshift = sm ? 2 * (sm - 1) : 0;
         for (int i = tid; i < RW + 8; i += TT) { S.dstart[i] = 0; S.c.cand[i] = 0; }
-        __syncthreads();
+        tile_sync<NW>();
         // read starts in DENSE coordinates (a start is a forced run start: its dense index is the number of kept bases in front of it)
         auto mark_start = [&](int64_t rel) {
             if (rel < 0 || rel >= (int64_t)RW * 32) return;
@@ -700,7 +725,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         };
         if (n_rs <= RS_CAP) { for (u32 i = tid; i < n_rs; i += TT) mark_start(i ? (int64_t)S.rs_rel[i] : S.rs0); }
         else for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) mark_start((int64_t)a.offsets[r] - raw0);
-        __syncthreads();
+        tile_sync<NW>();
         // One thread per stretch of the owned END positions [e_lo, H).  Stretches are whole numbers of 32 positions and the look-back is a
         // multiple of 32, and every lane runs the same number of iterations (positions in front of the stream or behind the stretch are
         // idle ones): the iteration index `it` and (p mod 32) are the same in every lane, so word loads, bitmap flushes and the slot of
@@ -716,10 +741,10 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         const u32 a0 = e_lo + (u32)tid * R < H ? e_lo + (u32)tid * R : H, b0 = a0 + R < H ? a0 + R : H;
         // s <= 4: the s-mer hash comes from a table (second half of t3: 256 x u16, filled here)
         const bool use_lut = sm != 0 && sm <= 4;
-        u16* const lut = (u16*)S.t3 + 256;
+        u16* const lut = (u16*)S_t3 + 256;
         const u32 e_lo_s = (u32)__builtin_amdgcn_readfirstlane((int)e_lo);      // a0 = e_lo + tid * R, R and the look-back multiples of 32: p mod 32 = (e_lo + it) mod 32 in every lane
         if (use_lut) lut[tid] = (u16)sync_hash32((u32)tid & smask, smask);
-        __syncthreads();
+        tile_sync<NW>();
         {
             // first look-back: l positions until every s-mer of the window comes from bases behind the start, and some windows to meet a unique
             // minimum in (with s = 4 about nine windows in ten have one)
@@ -793,10 +818,10 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
                 if (__any((int)(mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 2048u)))) break;
             }
         }
-        __syncthreads();
-        if (S.misc[9]) { __syncthreads(); run_slow_tile(); return; }
+        tile_sync<NW>();
+        if (S.misc[9]) { tile_sync<NW>(); run_slow_tile(); return; }
     }
-    __syncthreads();
+    tile_sync<NW>();
     // the (unordered) candidate list: every thread expands the bitmap words 4 tid .. 4 tid + 3.  (Round 2 and the first version of this
     // round appended to the list inside the filter loop: one LDS fetch-add and a bit loop per step, 12 times per wave instead of once.)
     {
@@ -816,7 +841,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
             }
         }
     }
-    __syncthreads();
+    tile_sync<NW>();
     MDBG_STAMP(3);
     if (a.stop_phase == 3) { if (tid == 0) a.n_valid[gt] = 0; return; }
 
@@ -826,11 +851,11 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         const u32 c0 = bs_popc(cw.x), c1 = bs_popc(cw.y), c2 = bs_popc(cw.z), c3 = bs_popc(cw.w);
         const u32 last = tid == TT - 1 ? bs_popc(S.c.cand[RW]) : 0u;       // the last thread also takes word RW
         u32 total;
-        const u32 o = block_excl_scan_256(c0 + c1 + c2 + c3 + last, S.misc, total);
+        const u32 o = tile_excl_scan<NW>(c0 + c1 + c2 + c3 + last, S.misc, total);
         const u32 o1 = o + c0, o2 = o1 + c1, o3 = o2 + c2;
         *(uint2*)(S.c.cpre + WPT * tid) = make_uint2(o | o1 << 16, o2 | o3 << 16);
         if (tid == TT - 1) S.c.cpre[RW] = (u16)(o3 + c3);
-        __syncthreads();
+        tile_sync<NW>();
         return total;
     };
     // tile-relative raw position of dense position r.  The kept fraction is nearly uniform along a tile, so r * RW / H lands within a word
@@ -850,11 +875,11 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         const u32 wi = e >> 5, s = e & 31;
         const u32* dw = S.dense + 2 * (DPAD + wi);
         const u32 v0 = bs_alignbit(dw[-2], dw[0], 31 - s), v1 = bs_alignbit(dw[-1], dw[1], 31 - s);      // bit u = dense position e - u
-        if constexpr (SCHEME == 0) return bs_exact_hash<BS_GS, L>(v0, v1, S.t3);
+        if constexpr (SCHEME == 0) return bs_exact_hash<BS_GS, L>(v0, v1, S_t3);
         else {
             const u32 lm = Lr >= 32 ? 0xFFFFFFFFu : (1u << Lr) - 1u;
             const u32 r0 = (v0 ^ v1) & lm, r1 = v1 & lm;              // the reference's code bits of the base at distance u from the end
-            const u16* sp = (const u16*)S.t3;
+            const u16* sp = (const u16*)S_t3;
             const u32 lo = ((u32)sp[r0 & 255u] | (u32)sp[(r0 >> 8) & 255u] << 16) | ((u32)sp[r1 & 255u] | (u32)sp[(r1 >> 8) & 255u] << 16) << 1;
             const u32 hi = ((u32)sp[(r0 >> 16) & 255u] | (u32)sp[r0 >> 24] << 16) | ((u32)sp[(r1 >> 16) & 255u] | (u32)sp[r1 >> 24] << 16) << 1;
             const u64 lmask = (1ull << (2 * Lr)) - 1ull;
@@ -907,26 +932,34 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if ((u32)(TT * i) < n) {
-                if (i) __syncthreads();                               // the previous sub-round's survivors have been read
+                if (i) tile_sync<NW>();                               // the previous sub-round's survivors have been read
                 const u32 j = tid + TT * i;
                 bool pass = false; u32 e = 0; u64 h = 0;
                 if (j < n) { e = S.c.list[j]; h = exact(e); pass = h <= a.bound; if (!pass) clear_bit(e); }
                 const u64 bal = __ballot(pass);
-                if (bal) {
-                    u32 base = 0;
-                    if (lane == 0) base = atomicAdd(&S.misc[18 + i], (u32)__popcll(bal));
-                    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                    if (pass) { const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)); S.c.surv[slot] = (u16)e; s_h[slot] = h; }
+                u32 n_surv;
+                if constexpr (NW == 1) {                               // one wave: its own ballot is the whole round
+                    n_surv = (u32)__popcll(bal);
+                    if (pass) { const u32 slot = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)); S.c.surv[slot] = (u16)e; s_h[slot] = h; }
+                    tile_sync<NW>();
+                } else {
+                    if (bal) {
+                        u32 base = 0;
+                        if (lane == 0) base = atomicAdd(&S.misc[18 + i], (u32)__popcll(bal));
+                        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                        if (pass) { const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)); S.c.surv[slot] = (u16)e; s_h[slot] = h; }
+                    }
+                    tile_sync<NW>();
+                    n_surv = S.misc[18 + i];
                 }
-                __syncthreads();
-                if ((u32)tid < S.misc[18 + i]) {
+                if ((u32)tid < n_surv) {
                     e = S.c.surv[tid];
                     keep_e[i] = e;
                     if (place(e, s_h[tid], keep[i])) keep_ok |= 1u << i; else clear_bit(e);
                 }
             }
         }
-        __syncthreads();
+        tile_sync<NW>();
         MDBG_STAMP(4);
         const u32 left = count_words();
         MDBG_STAMP(5);
@@ -951,7 +984,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
         // barriers, no second evaluation; the gather squeezes the holes out (it is a copy anyway).  Round 2 validated all candidates in
         // one pass and evaluated the survivors again to write them; a first version of this round ran the two-stage rounds of the fast
         // path over stretches of the bitmap: 0.43 Tbases/s at d = 0.1, most of it spent at ~100 barriers per tile.
-        __syncthreads();
+        tile_sync<NW>();
         const u32 C = count_words();
         const u32 per = (C + TT - 1) / TT;
         const u32 r0 = (u32)tid * per < C ? (u32)tid * per : C, r1 = r0 + per < C ? r0 + per : C;
@@ -974,7 +1007,7 @@ __global__ __launch_bounds__(TT, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArg
             }
         }
         u32 nv;
-        block_excl_scan_256(surv, S.misc, nv);
+        tile_excl_scan<NW>(surv, S.misc, nv);
         if (tid == 0) {
             a.n_valid[gt] = nv; if (a.n_scan) a.n_scan[gt] = C;
             if (a.last_read) a.last_read[gt] = nv ? LAST_IN_SLAB : LAST_NONE;
@@ -1021,7 +1054,7 @@ __global__ __launch_bounds__(256) void tile_scan_top_kernel(u32 n_blocks, u64* _
     }
     if (tid == 0) carry[0] = run;
 }
-// self_base: block_base holds the plain block sums (at most 256 blocks of 1024 tiles, no tile_scan_top launch): the workgroup adds up the
+// self_base: block_base holds the plain block sums (at most 1024 blocks of 1024 tiles, no tile_scan_top launch): the workgroup adds up the
 // sums in front of its block itself (the gather's last wave then moves the running total on)
 __global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base,
                                                               u32 self_base, const u64* __restrict__ carry) {
@@ -1033,7 +1066,9 @@ __global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* 
     for (int q = 0; q < 4; ++q) { v[q] = i0 + q < n ? n_valid[i0 + q] : 0u; mine += v[q]; }
     u64 bb;
     if (self_base) {
-        u64 x = threadIdx.x < blockIdx.x ? block_base[threadIdx.x] : 0ull;
+        u64 x = 0;
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) if (4 * threadIdx.x + q < blockIdx.x) x += block_base[4 * threadIdx.x + q];
         for (int d = 32; d; d >>= 1) x += __shfl_down(x, d, 64);
         if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = x;
         __syncthreads();
@@ -1057,6 +1092,7 @@ struct GatherArgs {
     u64* out_hash; u32* out_pos; u32* out_read; u64 out_cap;
     u64 m0; u32 slot0, n_reads; u64* off; u32 last_launch;        // m0: first store index of the batch
     u64* carry;                                                   // non-null: <- running total behind this launch's last tile (the scan ran without tile_scan_top)
+    u32 tiles_per_wave;                                           // gather_multi_kernel: consecutive tiles one wave takes (small tiles)
 };
 constexpr u32 REC_REJECTED = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
@@ -1128,6 +1164,84 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
     }
 }
 
+// Small tiles (a wave tile holds a few dozen records at the usual densities): one wave takes T consecutive tiles and walks their slab
+// slots as ONE flattened sequence, so the stores stay 64 records wide and the chain of dependent round trips (counts -> records ->
+// stores) is paid once per T tiles.  Same contract as gather_kernel.
+__global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs g) {
+    const u32 T0 = g.tiles_per_wave;
+    const u32 b0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * T0;       // first tile of the wave (launch-local)
+    if (b0 >= g.n) return;
+    const u32 lane = threadIdx.x & 63;
+    const u32 T = g.n - b0 < T0 ? g.n - b0 : T0;                      // (<= 64)
+    u32 nv = 0, ns = 0;
+    if (lane < T) { nv = g.n_valid[g.tile0 + b0 + lane]; ns = g.n_scan ? g.n_scan[g.tile0 + b0 + lane] : 0u; }
+    const u64 base = g.tile_base[b0];
+    u32 lr = LAST_IN_SLAB;
+    if (g.last_read && b0) lr = g.last_read[g.tile0 + b0 - 1];
+    u32 slots = ns ? ns : nv;                                         // slab slots to look at (ns != 0: some hold rejected candidates)
+    if (slots > g.slab_cap) slots = 0;                                // the tile's records did not fit: skipped (the host runs the batch again)
+    const u32 inc = wave_incl_scan(slots);                            // inclusive prefix over the wave's tiles (lanes >= T: the total)
+    const u32 S = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    const u32 nv_all = (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(nv), 63);
+    const bool tail = g.last_launch && b0 + T == g.n;
+    if (g.carry && b0 + T == g.n && lane == 0) *g.carry = base + nv_all;
+    if (!S && !tail) return;
+    const Rec* const s0 = g.slab + (size_t)b0 * g.slab_cap;
+    // slot j of the flattened sequence -> its record (tile = number of prefixes <= j)
+    auto fetch = [&](u32 j) -> Rec {
+        Rec r{}; r.read = REC_REJECTED;
+        u32 ti = 0, ex = 0;                                           // (found by every lane: the loop and its lane reads are wave-uniform)
+        for (u32 t = 0; t + 1 < T; ++t) { const u32 it = (u32)__builtin_amdgcn_readlane((int)inc, (int)t); if (j >= it) { ti = t + 1; ex = it; } }
+        if (j < S) r = s0[(size_t)ti * g.slab_cap + (j - ex)];
+        return r;
+    };
+    Rec cur = fetch(lane);
+    int64_t prev = (int64_t)g.slot0 - 1;                              // read of the record in front of this wave's first
+    if (b0 && lr < LAST_IN_SLAB) prev = (int64_t)lr;
+    else {
+        int64_t q = (int64_t)b0 - 1;
+        while (q >= 0 && g.n_valid[g.tile0 + q] == 0) --q;
+        if (q >= 0) {
+            const u32 lq = g.last_read ? g.last_read[g.tile0 + q] : LAST_IN_SLAB;
+            if (lq < LAST_IN_SLAB) prev = (int64_t)lq;
+            else {
+                const u32 cq = g.n_valid[g.tile0 + q], sq = g.n_scan ? g.n_scan[g.tile0 + q] : 0u;
+                int64_t j = (int64_t)(sq ? sq : cq) - 1;
+                if (j < (int64_t)g.slab_cap) {
+                    const Rec* t = g.slab + (size_t)q * g.slab_cap;
+                    while (j >= 0 && t[j].read == REC_REJECTED) --j;
+                    if (j >= 0) prev = (int64_t)t[j].read;
+                }
+            }
+        } else { const u64 bb = g.tile_base[0]; if (bb > g.m0 && bb <= g.out_cap) prev = (int64_t)g.out_read[bb - 1]; }
+    }
+    const int64_t lo = (int64_t)g.slot0 - 1, hi = (int64_t)g.slot0 + g.n_reads;
+    if (prev < lo) prev = lo;
+    u64 out = base;
+    for (u32 j0 = 0; j0 < S; j0 += 64) {
+        const Rec r = cur;
+        if (j0 + 64 < S) cur = fetch(j0 + 64 + lane);                 // the next round is in flight while this one is placed
+        const bool valid = r.read != REC_REJECTED;
+        const u64 bal = __ballot(valid);
+        const u64 lower = bal & ((1ull << lane) - 1ull);
+        const u32 from_lane = __shfl(r.read, lower ? 63 - __clzll((long long)lower) : 0, 64);      // the valid record in front of mine in this round
+        const int64_t pr = lower ? (int64_t)from_lane : prev;
+        const u32 last_valid = __shfl(r.read, bal ? 63 - __clzll((long long)bal) : 0, 64);
+        if (valid) {
+            const u64 idx = out + (u64)__popcll(lower);
+            if (idx < g.out_cap) { g.out_hash[idx] = r.hash; g.out_pos[idx] = r.pos; g.out_read[idx] = r.read; }
+            int64_t c = (int64_t)r.read; if (c > hi) c = hi;
+            for (int64_t x = pr + 1; x <= c; ++x) g.off[x] = idx;
+        }
+        if (bal) prev = (int64_t)last_valid;
+        out += (u64)__popcll(bal);
+    }
+    if (tail) {
+        int64_t last = prev < lo ? lo : prev;
+        for (int64_t x = last + 1 + lane; x <= hi; x += 64) g.off[x] = out;
+    }
+}
+
 // Error path only (a byte outside ACGTN was seen somewhere in the batch): the reference's exact rule — nthash panics iff a
 // read whose HPC string has at least l bases holds such a byte (src/read.rs:157-174 decides the length).  One wave per
 // read; *which = smallest offending read index (~0: none).
@@ -1150,13 +1264,13 @@ __global__ __launch_bounds__(256) void alphabet_rule_kernel(Src src, const u64* 
 }
 
 // FMT_PLANES: marks the tiles whose staged range [t * STRIDE - HALO, (t + 1) * STRIDE) holds a listed exception
-__global__ void tile_flags_kernel(const u64* __restrict__ exc_pos, u32 n_exc, u32 n_tiles, u8* __restrict__ flags) {
+__global__ void tile_flags_kernel(const u64* __restrict__ exc_pos, u32 n_exc, u32 n_tiles, u8* __restrict__ flags, u64 stride, u64 halo) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_exc) return;
     const u64 p = exc_pos[i];
-    const u64 t = p / TILE_STRIDE;
+    const u64 t = p / stride;
     if (t < n_tiles) flags[t] = 1;
-    if (t + 1 < n_tiles && p + HALO_BASES >= (t + 1) * (u64)TILE_STRIDE) flags[t + 1] = 1;      // falls into the next tile's look-back window
+    if (t + 1 < n_tiles && p + halo >= (t + 1) * stride) flags[t + 1] = 1;      // falls into the next tile's look-back window
 }
 
 // ---- ASCII -> 2-bit planes on the device (mdbg_pack_device) -------------------------------------------------------
@@ -1194,12 +1308,27 @@ void launch_pack_planes(const u8* bases, u64 n_bases, uint2* words, u64* exc_pos
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
-void launch_bread(const u64* offsets, u32 n_reads, u64 n_bases, u32 n_tiles, u32* bread, TileRec* recs, const SketchInit& init, hipStream_t s) {
+void launch_bread(const u64* offsets, u32 n_reads, u64 n_bases, u32 n_tiles, u32* bread, TileRec* recs, const SketchInit& init, const TileShape& sh, hipStream_t s) {
     const u32 n = n_tiles + 2;
-    hipLaunchKernelGGL(tile_rec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, offsets, n_reads, n_bases, n_tiles, bread, recs, init);
+    hipLaunchKernelGGL(tile_rec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, offsets, n_reads, n_bases, n_tiles, bread, recs, init, (int64_t)sh.stride, (int64_t)sh.halo);
 }
-void launch_tile_flags(const u64* exc_pos, u32 n_exc, u32 n_tiles, u8* flags, hipStream_t s) {
-    if (n_exc) hipLaunchKernelGGL(tile_flags_kernel, dim3((n_exc + 255) / 256), dim3(256), 0, s, exc_pos, n_exc, n_tiles, flags);
+void launch_tile_flags(const u64* exc_pos, u32 n_exc, u32 n_tiles, u8* flags, const TileShape& sh, hipStream_t s) {
+    if (n_exc) hipLaunchKernelGGL(tile_flags_kernel, dim3((n_exc + 255) / 256), dim3(256), 0, s, exc_pos, n_exc, n_tiles, flags, (u64)sh.stride, (u64)sh.halo);
+}
+// The tile geometry of a context.  256-lane tiles are the default: the wave tiles (MDBG_TILE = "1x4": four to a workgroup, "1x1": one
+// 64-lane workgroup each) were built to take the ~20 workgroup barriers out of a tile's life, and measured SLOWER by 7 - 9 % on configs[2]
+// (profiles/r04_b_tile_shapes_ab.txt): the kernel follows its VALU instruction count, and a wave tile spends more of them per base (four
+// filter steps of 63 words for 193 dense words, a placement pass per 24 instead of 97 survivors, twice the look-back share).
+// The switch is read once; the syncmer scheme only exists on the 256-lane tiles.
+TileShape tile_shape_for(u32 scheme) {
+    static const char* const env = getenv("MDBG_TILE");
+    u32 nw = 4, tpw = 1;
+    if (env && env[0] == '1' && env[1] == 'x' && env[2] == '4') { nw = 1; tpw = 4; }
+    else if (env && env[0] == '1' && env[1] == 'x' && env[2] == '1') { nw = 1; tpw = 1; }
+    if (scheme == 1) { nw = 4; tpw = 1; }
+    TileShape sh; sh.nw = nw; sh.tpw = tpw;
+    sh.stride = nw == 4 ? (u32)TileGeo<4>::STRIDE : (u32)TileGeo<1>::STRIDE; sh.halo = nw == 4 ? (u32)TileGeo<4>::HALO_BASES : (u32)TileGeo<1>::HALO_BASES;
+    return sh;
 }
 void launch_alphabet_rule(const SketchArgs& a, unsigned long long* which, hipStream_t s) {
     if (!a.n_reads) return;
@@ -1208,29 +1337,39 @@ void launch_alphabet_rule(const SketchArgs& a, unsigned long long* which, hipStr
     else hipLaunchKernelGGL(alphabet_rule_kernel<PlaneSrc>, g, b, 0, s, PlaneSrc{a.planes, a.exc_pos, a.exc_val, a.n_exc}, a.offsets, a.n_reads, a.l, a.hpc, which);
 }
 
-template <int L> static void launch_bs(const SketchArgs& a, u32 n_wg, hipStream_t s) {
-    hipLaunchKernelGGL(sketch_bs_kernel<L>, dim3(n_wg), dim3(TT), 0, s, a);
+template <int L> static void launch_bs(const SketchArgs& a, u32 n_tiles, const TileShape& sh, hipStream_t s) {
+    if (sh.nw == 4) hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 4, 1>), dim3(n_tiles), dim3(256), 0, s, a);
+    else if (sh.tpw == 1) hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 1, 1>), dim3(n_tiles), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 1, 4>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, a);
 }
-// one launch covers the whole batch (launch boundaries would only re-synchronise the workgroups' phases); n_wg = tiles to run
-void launch_sketch(const SketchArgs& a, u32 n_wg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
-    if (!n_wg) return;
+// one launch covers the whole batch (launch boundaries would only re-synchronise the workgroups' phases); n_tiles = tiles to run from a.tile0
+void launch_sketch(SketchArgs a, u32 n_tiles, const TileShape& sh, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+    if (!n_tiles) return;
+    a.tile_end = a.tile0 + n_tiles;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     if (a.scheme == 1) {                              // syncmers: l is a run-time value, the window a compile-time one
+#ifndef MDBG_ONLY_L
         switch (a.l - a.s + 1) {
-#define MDBG_W(n) case n: hipLaunchKernelGGL((sketch_bs_kernel<0, 1, n>), dim3(n_wg), dim3(TT), 0, s, a); break;
+#define MDBG_W(n) case n: hipLaunchKernelGGL((sketch_bs_kernel<0, 1, n>), dim3(n_tiles), dim3(256), 0, s, a); break;
             MDBG_W(1) MDBG_W(2) MDBG_W(3) MDBG_W(4) MDBG_W(5) MDBG_W(6) MDBG_W(7) MDBG_W(8) MDBG_W(9) MDBG_W(10) MDBG_W(11) MDBG_W(12) MDBG_W(13) MDBG_W(14) MDBG_W(15) MDBG_W(16)
             MDBG_W(17) MDBG_W(18) MDBG_W(19) MDBG_W(20) MDBG_W(21) MDBG_W(22) MDBG_W(23) MDBG_W(24) MDBG_W(25) MDBG_W(26) MDBG_W(27) MDBG_W(28) MDBG_W(29) MDBG_W(30) MDBG_W(31)
 #undef MDBG_W
-            default: hipLaunchKernelGGL((sketch_bs_kernel<0, 1, 32>), dim3(n_wg), dim3(TT), 0, s, a); break;
+            default: hipLaunchKernelGGL((sketch_bs_kernel<0, 1, 32>), dim3(n_tiles), dim3(256), 0, s, a); break;
         }
+#endif
     }
     else switch (a.l) {
-#define MDBG_L(n) case n: launch_bs<n>(a, n_wg, s); break;
+#define MDBG_L(n) case n: launch_bs<n>(a, n_tiles, sh, s); break;
+#ifdef MDBG_ONLY_L                                    // quick experiment builds: one l, no syncmers
+        MDBG_L(MDBG_ONLY_L)
+        default: break;
+#else
         MDBG_L(2) MDBG_L(3) MDBG_L(4) MDBG_L(5) MDBG_L(6) MDBG_L(7) MDBG_L(8) MDBG_L(9) MDBG_L(10) MDBG_L(11) MDBG_L(12) MDBG_L(13)
         MDBG_L(14) MDBG_L(15) MDBG_L(16) MDBG_L(17) MDBG_L(18) MDBG_L(19) MDBG_L(20) MDBG_L(21) MDBG_L(22) MDBG_L(23) MDBG_L(24)
         MDBG_L(25) MDBG_L(26) MDBG_L(27) MDBG_L(28) MDBG_L(29) MDBG_L(30) MDBG_L(31) MDBG_L(32)
+        default: launch_bs<32>(a, n_tiles, sh, s); break;      // l > 32: every tile takes the generic walker (force_slow is set by the host)
+#endif
 #undef MDBG_L
-        default: launch_bs<32>(a, n_wg, s); break;      // l > 32: every tile takes the generic walker (force_slow is set by the host)
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
 }
@@ -1248,11 +1387,12 @@ void launch_gather(const GatherArgs& g, u64* scan_tmp, u64* tile_base, u64* carr
     if (!g.n) return;
     const u32 n = g.n, nb = (n + 1023) / 1024;
     hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp);
-    const u32 self_base = nb <= 256 ? 1u : 0u;      // up to 262,144 tiles = 8.6 Gbases per launch: two scan launches instead of three
+    const u32 self_base = nb <= 1024 ? 1u : 0u;     // up to 1,048,576 tiles (8.5 Gbases of wave tiles) per launch: two scan launches instead of three
     if (!self_base) hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
     hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp, tile_base, self_base, carry);
     GatherArgs a = g; a.tile_base = tile_base; a.carry = self_base ? carry : nullptr;
-    hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, a);
+    if (a.tiles_per_wave > 1) { const u32 nw = (n + a.tiles_per_wave - 1) / a.tiles_per_wave; hipLaunchKernelGGL(gather_multi_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, a); }
+    else hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, a);
 }
 
 // ---- --lmer-counts (src/read.rs:200-205, src/minimizers.rs:53-113): keep a selected minimizer only if its l-mer is in a given set ---------

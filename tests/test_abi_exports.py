@@ -60,7 +60,7 @@ def test_ctypes_mirrors_match_the_c_compiler(tmp_path):
         "mdbg_params": (api.Params, ["k", "l", "density", "min_abundance", "reads_already_hpc", "device", "flags", "table_capacity_hint", "scheme", "syncmer_s"]),
         "mdbg_packed_batch": (api.PackedBatch, ["words", "offsets", "n_reads", "exc_pos", "exc_val", "n_exc"]),
         "mdbg_nodes": (api.Nodes, ["n", "k", "keys", "index", "abundance", "seqlen", "shift", "shift_full", "src_read", "src_start", "src_end", "reversed", "n_distinct", "n_wrapped"]),
-        "mdbg_stats": (api.Stats, ["n_reads", "n_minimizers", "ms_sketch", "ms_sketch_tile"]),
+        "mdbg_stats": (api.Stats, ["n_reads", "n_minimizers", "ms_sketch", "ms_sketch_tile", "tile_bases"]),
         "mdbg_comm": (dist_c.Comm, ["self", "rank", "world", "allgather_u64", "exchange", "allreduce_sum_u64", "exchange_begin", "exchange_wait"]),
         "mdbg_edges": (emit.Edges, ["n", "n1", "o1", "n2", "o2", "overlap", "presimp_removed"]),
     }

@@ -86,7 +86,7 @@ def test_config4_full_shard_properties_and_multik_sweep():
         st = m.stats()
         one = _node_tensors(torch, nd, 35)
         n = int(nd.n)
-        assert st["n_slow_tiles"] == 0 and st["n_tiles"] == (nb + 32511) // 32512 and n > 1_000_000
+        assert st["n_slow_tiles"] == 0 and st["n_tiles"] == -(-nb // st["tile_bases"]) and n > 1_000_000
         # 1. rows sorted by index, unique, below the number of distinct keys
         idx = one["index"].to(torch.int64) & 0xFFFFFFFF
         assert bool((idx[1:] > idx[:-1]).all()) and int(idx[-1]) < int(nd.n_distinct)

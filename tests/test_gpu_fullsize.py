@@ -60,7 +60,7 @@ def test_config3_size_properties():
         m.ingest_device(db, do, n_reads, nb, 0)
         one = m.finalize()
         st = m.stats()
-        assert st["n_slow_tiles"] == 0 and st["n_tiles"] == (nb + 32511) // 32512
+        assert st["n_slow_tiles"] == 0 and st["n_tiles"] == -(-nb // st["tile_bases"])
         # 1. node rows are sorted by index, indices are unique and < number of distinct keys
         assert np.all(np.diff(one["index"].astype(np.int64)) > 0) and int(one["index"][-1]) < one["n_nodes_before"]
         # 2. abundance filter and metadata identities (src/main.rs:778: seqlen = last - first + 2; end = last + l)
@@ -142,7 +142,7 @@ def test_batch_larger_than_2_33_bases_equals_split_batches():
         m.ingest_device(db, do, n_reads, nb, 0)
         one = m.finalize()
         st = m.stats()
-        assert st["n_tiles"] == (nb + 32511) // 32512 > 262144 and 1 <= st["n_sketch_tile_launches"] <= 4
+        assert st["n_tiles"] == -(-nb // st["tile_bases"]) > 262144 and 1 <= st["n_sketch_tile_launches"] <= 4
         offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
         half = n_reads // 2
         cut = int(offs[half]) // 16 * 16                      # the device bases pointer must stay 16-byte aligned
