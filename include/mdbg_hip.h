@@ -205,6 +205,11 @@ int mdbg_get_stats(mdbg_ctx* ctx, mdbg_stats* out);
 const char* mdbg_strerror(int err);
 const char* mdbg_last_error(mdbg_ctx* ctx); /* detail of the last failure on ctx ("" if none) */
 uint32_t mdbg_abi_version(void);
+/* Device memory that contexts of this process have released is kept by the library for the next allocation (a hipMalloc that follows large
+ * frees takes seconds on this stack); at most MDBG_CACHE_MB megabytes (environment; default a third of the device, 0 = keep nothing).
+ * This hands all of it back to the runtime and returns the number of bytes released.  Never needed for correctness: an allocation that
+ * runs out of memory empties the cache itself before it fails. */
+uint64_t mdbg_release_cached_memory(void);
 
 /* ---- device-resident stage entry points (used by the multi-GPU driver and the benchmark) -------------
  * Sketch stage only, device buffers in, results appended to the context's resident sketch store. */

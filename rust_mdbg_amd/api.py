@@ -82,7 +82,8 @@ EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_dev
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
            "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
-           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed", "mdbg_mark", "mdbg_rewind", "mdbg_set_lmer_filter"]
+           "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed", "mdbg_mark", "mdbg_rewind", "mdbg_set_lmer_filter",
+           "mdbg_release_cached_memory"]
 
 
 def lib_path():
@@ -108,6 +109,7 @@ def load_library():
     L = C.CDLL(p)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.mdbg_abi_version.restype = u32
+    L.mdbg_release_cached_memory.restype = u64
     L.mdbg_create.restype = vp
     L.mdbg_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_int)]
     L.mdbg_destroy.restype = None
@@ -173,6 +175,11 @@ def load_library():
         getattr(L, f).restype = C.c_int
     _LIB = L
     return L
+
+
+def release_cached_memory():
+    """hands the device blocks the library keeps for reuse back to the runtime; returns the number of bytes released (include/mdbg_hip.h)"""
+    return int(load_library().mdbg_release_cached_memory())
 
 
 def _np(ptr, n, dtype):

@@ -3,6 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Device memory of the library comes from a process-wide cache of blocks (api.inc): hipMalloc after large frees takes SECONDS on this stack
+// (the driver releases memory lazily and the next allocation waits for it: profiles/r04_c_alloc_trace.txt), so freed blocks of 1 MB and more
+// are kept and handed out again.  *cap <- usable size (>= bytes).
+hipError_t mdbg_block_alloc(void** p, size_t bytes, size_t* cap);
+void mdbg_block_free(void* p, size_t cap);
+
 struct EdgeNodes {                 // device-resident node table of the last finalize (rows in index order)
     const uint64_t* keys; const uint32_t* index; const uint16_t* abund; const uint32_t* seqlen; const uint16_t* shift;
     uint64_t n; uint32_t k;

@@ -25,14 +25,12 @@ constexpr u64 EMPTY64 = ~0ull;
 
 struct Buf {
     void* p = nullptr; size_t cap = 0;
-    ~Buf() { if (p) (void)hipFree(p); }
+    ~Buf() { if (p) mdbg_block_free(p, cap); }
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) mdbg_block_free(p, cap);
         p = nullptr; cap = 0;
-        hipError_t e = hipMalloc(&p, bytes + bytes / 8 + 256);
-        if (e == hipSuccess) cap = bytes + bytes / 8 + 256;
-        return e;
+        return mdbg_block_alloc(&p, bytes + bytes / 8 + 256, &cap);
     }
     template <class T> T* as() const { return (T*)p; }
 };

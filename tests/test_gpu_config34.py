@@ -205,7 +205,7 @@ def test_config3_whole_genome_streamed_through_one_gpu():
         growth = sum(1 for i in range(1, len(caps)) if caps[i] != caps[i - 1])
         rec.update(total_bases=total_bases, nodes=n, distinct=n_distinct, windows=n_windows, minimizers=n_min, ingest_ms=t_ingest * 1e3, finalize_ms=t_fin * 1e3,
                    gbases_per_s=total_bases / (t_ingest + t_fin) / 1e9, table_growth_events=growth, table_capacity_final=st["table_capacity"],
-                   peak_hbm_gb=(free0 - min_free) / 1e9, note="ingest_ms = sketch + windows + table per batch, inputs packed and resident; synth + pack are outside")
+                   peak_hbm_gb=(torch.cuda.mem_get_info()[1] - min_free) / 1e9, note="peak_hbm_gb = device memory not free at the lowest point (other users and the library's block cache included); ingest_ms = sketch + windows + table per batch, inputs packed and resident; synth + pack are outside")
         keys_sum = int(kk.sum(dtype=torch.int64))                         # (wraps: a checksum, compared below)
         idx_sum = int(idx.sum()); ab_sum = int(ab.sum())
         del kk, idx, ab, sl, sr
@@ -241,4 +241,4 @@ def test_config3_whole_genome_streamed_through_one_gpu():
     print("FULL_HUMAN " + json.dumps(rec))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out) and os.access(out, os.W_OK):
-        json.dump(rec, open(os.path.join(out, "r03_full_human.json"), "w"), indent=1)
+        json.dump(rec, open(os.path.join(out, "full_human.json"), "w"), indent=1)
