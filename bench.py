@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — Gbases/s ingested to the k-min-mer graph on synthetic HiFi-shaped reads (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch already resident in HBM:
-    reset -> sketch (HPC + ntHash + density filter) -> k-min-mer windows -> counting table -> finalized node table.
-Workload at N=1: BASELINE.json configs[2] (synthetic D. melanogaster: 140 Mb genome @50x, ~15 kb reads, 0.1 % errors,
-k=35 l=12 d=0.002 minabund=2).  For N>1: BASELINE.json configs[3] (synthetic human 3 Gb @52x over 8 GPUs = 375 Mb of genome
-and 19.5 Gbases of reads per GPU, k=35 l=14 d=0.003; weak scaling: the genome grows with N, coverage constant) and the
-table is partitioned by key range; the ranks exchange the hashes of their sketches over RCCL send/recv pairs inside libmdbg_hip.so
-(include/mdbg_dist.h; default) or route the k-min-mer occurrences to their owner with one RCCL all-to-all per step (--dist-mode route;
-rust_mdbg_amd/dist.py).  `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, one rank per GPU) and exits
+A "step" = one pass of the hot path over reads already resident in HBM:
+    reset -> [per batch: sketch (HPC + ntHash + density filter) -> k-min-mer windows -> counting table] -> finalized node table.
+Workloads (--workload):
+  fly    BASELINE.json configs[2], the single-GPU configuration and the default at N=1: synthetic D. melanogaster, 140 Mb genome @50x per GPU
+         (~15 kb reads, 0.1 % errors), k=35 l=12 d=0.002 minabund=2, one batch per step.
+  human  BASELINE.json configs[3], the default at N>1: synthetic human, 3 Gb genome @52x = 10.4 M reads = 156 Gbases, k=35 l=14 d=0.003, held as the
+         EIGHT shards of the 8-GPU configuration (19.5 Gbases each).  The SAME data set at every N (strong scaling): rank r of N takes the shards
+         [8 r / N, 8 (r + 1) / N) and pushes them through the multi-GPU layer as 8 / N batches per step; `--gpus 1 --workload human` streams all eight
+         through one context — the N=1 point of the 1 -> 8 curve (the default N=1 line is the other workload).
+At N>1 the table is partitioned by key range; the ranks exchange window lists + the sketch hashes they need over RCCL send/recv pairs inside
+libmdbg_hip.so (include/mdbg_dist.h; default) or route the k-min-mer occurrences to their owner with one RCCL all-to-all per step (--dist-mode route;
+rust_mdbg_amd/dist.py, fly workload only).  `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, one rank per GPU) and exits
 non-zero when fewer than N GPUs are visible; under an external launcher WORLD_SIZE must equal --gpus; `n_gpus` in the line is the
-number of ranks that took part in an all-reduce.  At N>1 the line also carries `no_exchange_anchor`: the same ranks, each pushing its own shard through one local
-context right after the timed region (no exchange, table not partitioned) — N=1 of this script is another workload (configs[2]), so the weak-scaling efficiency of
-the multi-GPU path for ITS workload is value / no_exchange_anchor.value.
-The reads sit in HBM in the north star's layout, packed 2 bits per base (--input ascii: one byte per base).
+number of ranks that took part in an all-reduce.  `--comm host` is a DRY RUN of the same multi-process path on fewer GPUs than ranks: the transfers are
+staged through host memory and carried by gloo (rust_mdbg_amd/dist_c.py HostStagedComm), several ranks share a device, and the line says so — not RCCL, not a result.
+At N>1 the line also carries `no_exchange_anchor`: the same ranks, each pushing its own shards through one local context right after the timed region
+(no exchange, table not partitioned), and `n1_same_workload`: the committed N=1 line of the same workload.
+The reads sit in HBM in the north star's layout, packed 2 bits per base (--input ascii: one byte per base, fly only); at N=1 the line also carries
+`ascii_in`: the same steps fed ASCII, and the time of the device packer, so that the GPU and the CPU leg can be read from the same starting bytes.
 
 Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_bs_kernel) as fed in the timed region and
 is measured live with HIP events on the stream the kernel is launched on; `roofline_ascii` is the same kernel fed ASCII
@@ -31,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HUMAN_SHARDS = 8            # --workload human: the data set is held as the eight shards of BASELINE.json configs[3]
 
 
 def parse():
@@ -38,11 +45,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--genome-mb", type=float, default=None, help="genome size per GPU in Mb (default: 140 at N=1, 375 at N>1)")
-    ap.add_argument("--coverage", type=float, default=None, help="default: 50 at N=1, 52 at N>1")
+    ap.add_argument("--workload", choices=["auto", "fly", "human"], default="auto", help="auto: fly (configs[2]) at N=1, human (configs[3]) at N>1")
+    ap.add_argument("--genome-mb", type=float, default=None, help="fly: genome per GPU in Mb (default 140); human: the WHOLE genome in Mb (default 3000)")
+    ap.add_argument("--coverage", type=float, default=None, help="default: 50 (fly), 52 (human)")
     ap.add_argument("-k", type=int, default=35)
-    ap.add_argument("-l", type=int, default=None, help="default: 12 at N=1, 14 at N>1")
-    ap.add_argument("--density", type=float, default=None, help="default: 0.002 at N=1, 0.003 at N>1")
+    ap.add_argument("-l", type=int, default=None, help="default: 12 (fly), 14 (human)")
+    ap.add_argument("--density", type=float, default=None, help="default: 0.002 (fly), 0.003 (human)")
+    ap.add_argument("--comm", choices=["rccl", "host"], default="rccl",
+                    help="N>1 transport: RCCL (one GPU per rank), or host-staged over gloo: a DRY RUN of the multi-process path with several ranks per GPU, labelled as such")
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="layout of the reads in HBM during the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
@@ -61,41 +71,69 @@ def parse():
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        self_launch(a.gpus)                    # does not return
+        self_launch(a.gpus, a.comm)            # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): start it as `python bench.py --gpus N` or under "
                          "torch.distributed.run --nproc-per-node N with the same N" % (a.gpus, world))
     if a.dist_mode == "route":
         a.dist_impl = "py"                     # the record routing exists in the Python harness only
-    cfg3 = world > 1 or a.force_dist            # BASELINE.json configs[3] shard per GPU, else configs[2]
-    if a.genome_mb is None: a.genome_mb = 375.0 if cfg3 and world > 1 else 140.0
-    if a.coverage is None: a.coverage = 52.0 if cfg3 and world > 1 else 50.0
-    if a.l is None: a.l = 14 if cfg3 and world > 1 else 12
-    if a.density is None: a.density = 0.003 if cfg3 and world > 1 else 0.002
+    if a.workload == "auto":
+        a.workload = "human" if world > 1 and a.dist_impl == "c" else "fly"      # (the Python harness drives one batch per step: fly)
+    human = a.workload == "human"
+    if human and HUMAN_SHARDS % world:
+        ap.error("--workload human is held as %d shards: --gpus must divide %d" % (HUMAN_SHARDS, HUMAN_SHARDS))
+    if human and (a.input != "packed" or a.dist_impl != "c"):
+        ap.error("--workload human: packed input and the C layer only")
+    if a.genome_mb is None: a.genome_mb = 3000.0 if human else 140.0
+    if a.coverage is None: a.coverage = 52.0 if human else 50.0
+    if a.l is None: a.l = 14 if human else 12
+    if a.density is None: a.density = 0.003 if human else 0.002
     return a
 
 
-def expected_graph(args, world, reads_per_gpu, n_bases):
-    """the graph this workload must produce (tests/golden/bench_counts.json), or None for a workload that has no recorded counts"""
+def expected_graph(args, world, shard_reads, total_bases):
+    """the graph this workload must produce (tests/golden/bench_counts.json), or None for a workload that has no recorded counts.  The human
+    workload is the same data set at every N: its GLOBAL node count is pinned for every N, the other counts (per-rank stores) at N=1."""
     try:
         ref = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))
     except OSError:
         return None
     for w in ref["workloads"]:
-        if (w["k"], w["l"], w["density"], w["minabund"], w["genome_mb"], w["coverage"], w["n_gpus"], w["reads_per_gpu"], w["bases_per_gpu"]) == \
-           (args.k, args.l, args.density, args.minabund, args.genome_mb, args.coverage, world, reads_per_gpu, n_bases):
+        if (w.get("workload", "fly"), w["k"], w["l"], w["density"], w["minabund"], w["genome_mb"], w["coverage"]) != \
+           (args.workload, args.k, args.l, args.density, args.minabund, args.genome_mb, args.coverage):
+            continue
+        if args.workload == "human":
+            if w["total_bases"] != total_bases:
+                continue
+            return dict(w["graph"]) if world == 1 else {"nodes": w["graph"]["nodes"]}
+        if (w["n_gpus"], w["reads_per_gpu"], w["bases_per_gpu"]) == (world, shard_reads, total_bases):
             return w["graph"]
     return None
 
 
-def self_launch(n):
+def n1_same_workload(args):
+    """the committed N=1 line of the same workload (profiles/r*_human_n1.json: `bench.py --gpus 1 --workload human` on one MI355X), for the N>1 lines"""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_human_n1.json")), reverse=True):
+        try:
+            j = json.load(open(p))
+            c = j["config"]
+            if (c["k"], c["l"], c["density"], c["minabund"], c["genome_mb"], c["coverage"]) == (args.k, args.l, args.density, args.minabund, args.genome_mb, args.coverage):
+                return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "source": os.path.relpath(p, ROOT),
+                        "what": "the same data set streamed through ONE GPU as %d batches (bench.py --gpus 1 --workload human), recorded earlier" % HUMAN_SHARDS}
+        except Exception:
+            continue
+    return None
+
+
+def self_launch(n, comm="rccl"):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run on this node and become
     that launcher.  Fewer than N visible GPUs is an error, not an N=1 run."""
     import socket
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    if have < (n if comm == "rccl" else 1):
         raise SystemExit("bench.py: --gpus %d needs %d GPUs, %d visible on this node (one rank per GPU; RCCL does not run two ranks on one device)"
                          % (n, n, have))
     with socket.socket() as sk:
@@ -194,81 +232,129 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    if torch.cuda.device_count() < world:
-        raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU)" % (world, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    host_comm = args.comm == "host" and world > 1
+    n_dev = torch.cuda.device_count()
+    if n_dev < world and not host_comm:
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU)" % (world, n_dev))
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
     dist = None
     routed = world > 1 or args.force_dist
+    human = args.workload == "human"
     if routed:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if host_comm:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+    red_dev = "cpu" if host_comm else "cuda"          # where the scalars of the bench's own all-reduces live
+
+    def allreduce(vals, dtype, op=None):
+        t = torch.tensor(vals, device=red_dev, dtype=dtype)
+        dist.all_reduce(t, op=op if op is not None else dist.ReduceOp.SUM)
+        return t.tolist()
     import rust_mdbg_amd as R
 
-    genome_len = int(args.genome_mb * 1e6) * world            # weak scaling: coverage constant, genome grows with N
-    reads_per_gpu = int(args.genome_mb * 1e6 * args.coverage / 15000.0)
-    m = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank)
-    d_bases, d_off, n_bases = m.synth_reads_device(seed=1, genome_len=genome_len, n_reads=reads_per_gpu, mean_len=15000, sd_len=1500,
-                                                   min_len=8000, max_len=25000, err_ppm=1000, first_read=rank * reads_per_gpu)
-    first_ordinal = rank * reads_per_gpu
     packed = args.input == "packed"
-    d_words = None
-    if packed:          # outside the timed region: the batch as the host packer (mdbg_pack_reads) would have delivered it
-        words = torch.zeros((n_bases + 31) // 32 + 2, dtype=torch.int64, device="cuda")
-        exc = (torch.zeros(64, dtype=torch.int64, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda"))
-        torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
-        assert m.pack_device(d_bases, n_bases, words.data_ptr(), exc[0].data_ptr(), exc[1].data_ptr(), 64) == 0      # synthetic reads are pure ACGT
-        d_words = words.data_ptr()
-    d_in = d_words if packed else d_bases
+    m = R.Mdbg(args.k, args.l, args.density, args.minabund, device=device_index)
+    # ---- the reads of this rank: a list of batches (device pointers) --------------------------------------------------------------
+    keep = []                                         # tensors that own the batches' memory
+    batches = []                                      # (d_in, d_off, n_reads, n_bases, first_ordinal)
+    d_bases = d_off0 = None                           # ASCII of the (last generated) batch: owned by the context
+    pack_ms = None
+    if human:
+        genome_len = int(args.genome_mb * 1e6)
+        shard_reads = int(args.genome_mb * 1e6 * args.coverage / 15000.0) // HUMAN_SHARDS
+        per_rank = HUMAN_SHARDS // world
+        for j in range(per_rank):
+            g = rank * per_rank + j
+            d_bases, d_off0, nb = m.synth_reads_device(seed=1, genome_len=genome_len, n_reads=shard_reads, mean_len=15000, sd_len=1500,
+                                                       min_len=8000, max_len=25000, err_ppm=1000, first_read=g * shard_reads)
+            words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+            offs = torch.from_numpy(m.to_host(d_off0, (shard_reads + 1) * 8, np.uint64).view(np.int64).copy()).cuda()
+            torch.cuda.synchronize()
+            assert m.pack_device(d_bases, nb, words.data_ptr()) == 0      # synthetic reads are pure ACGT
+            m.sync()
+            keep += [words, offs]
+            batches.append((words.data_ptr(), offs.data_ptr(), shard_reads, nb, g * shard_reads))
+        reads_per_gpu = shard_reads * per_rank
+    else:
+        genome_len = int(args.genome_mb * 1e6) * world            # weak scaling: coverage constant, genome grows with N
+        reads_per_gpu = shard_reads = int(args.genome_mb * 1e6 * args.coverage / 15000.0)
+        d_bases, d_off0, nb = m.synth_reads_device(seed=1, genome_len=genome_len, n_reads=reads_per_gpu, mean_len=15000, sd_len=1500,
+                                                   min_len=8000, max_len=25000, err_ppm=1000, first_read=rank * reads_per_gpu)
+        d_in = d_bases
+        if packed:          # outside the timed region: the batch as the host packer (mdbg_pack_reads) would have delivered it
+            words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+            exc = (torch.zeros(64, dtype=torch.int64, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda"))
+            torch.cuda.synchronize()      # the fills above ran on torch's stream, the packer runs on the context's
+            for _ in range(2):            # (second pass timed: what the device packer costs on top of a step that starts from ASCII)
+                m.sync()
+                t1 = time.perf_counter()
+                assert m.pack_device(d_bases, nb, words.data_ptr(), exc[0].data_ptr(), exc[1].data_ptr(), 64) == 0      # synthetic reads are pure ACGT
+                m.sync()
+                pack_ms = (time.perf_counter() - t1) * 1e3
+            keep += [words, exc]
+            d_in = words.data_ptr()
+        batches.append((d_in, d_off0, reads_per_gpu, nb, rank * reads_per_gpu))
+    n_bases = sum(b[3] for b in batches)
 
     cdist = None
     replicate = args.dist_mode == "replicate"
+    n_chunks = 1
     if routed and args.dist_impl == "c":
         from rust_mdbg_amd import dist_c
-        cdist = dist_c.DistMdbg(args.k, args.l, args.density, args.minabund, rank, world, dist, device=local_rank)
+        cdist = dist_c.DistMdbg(args.k, args.l, args.density, args.minabund, rank, world, dist, device=device_index, transport="host" if host_comm else "rccl")
         n_chunks = args.chunks if args.chunks > 0 else (4 if args.dist_exchange == "whole" else 2)      # segments: a rank's share of a round is a few tens of MB per link
         cdist.set_pipeline(n_chunks)          # the exchange of chunk i overlaps the tile kernel of chunk i+1 (mdbg_dist_set_pipeline)
         cdist.set_exchange(args.dist_exchange == "whole")
     if routed and cdist is None:
         from rust_mdbg_amd import dist as D
-        dev = torch.device("cuda", local_rank)
-        replicate = args.dist_mode == "replicate"
+        dev = torch.device("cuda", device_index)
         n_chunks = args.chunks if args.chunks > 0 else (4 if replicate else 1)
         chunked = n_chunks > 1 and not args.profile_dist
-        mt = R.Mdbg(args.k, args.l, args.density, args.minabund, device=local_rank) if chunked and not replicate else None     # owner-side context
+        mt = R.Mdbg(args.k, args.l, args.density, args.minabund, device=device_index) if chunked and not replicate else None     # owner-side context
         engine = D.GpuEngine(m, torch, dev, table=mt)
         engine.packed = packed
         comm = D.TorchDistComm(dist, torch, dev)
         runner = D.ReplicatedMdbg(engine, comm, torch) if replicate else D.DistributedMdbg(engine, comm, torch, profile=args.profile_dist)
+        d_in, d_off, _, _, first_ordinal = batches[0]
         if chunked:
-            import numpy as np
             plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), n_chunks, keep_empty=replicate)
             offs_t = engine._view(d_off, (reads_per_gpu + 1,))
+
+    def local_step(ascii_in=False):
+        """the whole hot path on this rank's own context (no exchange): reset -> batches -> finalize"""
+        m.reset(0)
+        for (b_in, b_off, b_reads, b_bases, b_first) in batches:
+            if ascii_in:
+                m.ingest_device(d_bases, b_off, b_reads, b_bases, b_first)
+            elif packed:
+                m.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first)
+            else:
+                m.ingest_device(b_in, b_off, b_reads, b_bases, b_first)
+        return m.finalize_device().n
 
     def step():
         if cdist is not None:
             cdist.reset(0)
-            if packed:
-                cdist.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
-            else:
-                cdist.ingest_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
+            for (b_in, b_off, b_reads, b_bases, b_first) in batches:
+                if packed:
+                    cdist.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first)
+                else:
+                    cdist.ingest_device(b_in, b_off, b_reads, b_bases, b_first)
             nd, _, ng = cdist.finalize()
             cdist.last_local = int(nd.n)
             return ng
-        if routed:
-            runner.reset() if replicate else engine.reset()
-        else:
-            m.reset(0)
         if not routed:
-            if packed:
-                m.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
-            else:
-                m.ingest_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
-            return m.finalize_device().n
+            return local_step()
+        runner.reset() if replicate else engine.reset()
         if chunked:
             runner.ingest_device_chunked(d_in, offs_t, plan, first_ordinal)
         else:
@@ -298,57 +384,45 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        nb = torch.tensor([n_bases, 1], device="cuda", dtype=torch.int64)      # [bases, 1]: the second sum = ranks RCCL actually reached
-        dist.all_reduce(nb)
-        total_bases, n_ranks = int(nb[0].item()), int(nb[1].item())
+        dt = float(allreduce([dt], torch.float64, dist.ReduceOp.MAX)[0])
+        total_bases, n_ranks = (int(v) for v in allreduce([n_bases, 1], torch.int64))      # [bases, 1]: the second sum = ranks the collective actually reached
     else:
         total_bases, n_ranks = n_bases, 1
     if n_ranks != args.gpus:
         raise SystemExit("bench.py: --gpus %d but %d rank(s) took part in the all-reduce" % (args.gpus, n_ranks))
     consistent = None
     if routed:               # outside the timed region: the ranks' partitions must add up to the global node count
-        loc = torch.tensor([(cdist if cdist is not None else runner).last_local], device="cuda", dtype=torch.int64)
-        dist.all_reduce(loc)
-        consistent = bool(int(loc.item()) == int(n_nodes))
+        loc = int(allreduce([(cdist if cdist is not None else runner).last_local], torch.int64)[0])
+        consistent = bool(loc == int(n_nodes))
     exchange = None
     if cdist is not None:    # what went over the links in the last step, and how even the partition is (mdbg_dist_traffic; outside the timed region)
         b_in, b_out, n_q = cdist.traffic()
-        tmax = torch.tensor([b_in, int(cdist.last_local)], device="cuda", dtype=torch.int64)
-        tsum = tmax.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tsum)
-        exchange = {"mode": args.dist_exchange, "chunks_per_step": n_chunks, "bytes_in_busiest_rank_per_step": int(tmax[0].item()), "bytes_in_mean_per_step": float(tsum[0].item()) / world,
-                    "nodes_busiest_rank_over_mean": (float(tmax[1].item()) * world / float(tsum[1].item())) if int(tsum[1].item()) else None}
+        tmax = allreduce([b_in, int(cdist.last_local)], torch.int64, dist.ReduceOp.MAX)
+        tsum = allreduce([b_in, int(cdist.last_local)], torch.int64)
+        exchange = {"mode": args.dist_exchange, "chunks_per_step": n_chunks * len(batches), "bytes_in_busiest_rank_per_step": int(tmax[0]), "bytes_in_mean_per_step": float(tsum[0]) / world,
+                    "nodes_busiest_rank_over_mean": (float(tmax[1]) * world / float(tsum[1])) if int(tsum[1]) else None,
+                    "transport": "host-staged over gloo (--comm host: DRY RUN, not RCCL)" if host_comm else "RCCL (grouped ncclSend / ncclRecv inside libmdbg_hip.so)"}
     anchor = None
-    if cdist is not None:    # outside the timed region: what the same ranks do WITHOUT the exchange — every rank pushes its own shard through one local context
-        # (table not partitioned).  N x this rate is the ceiling of the weak-scaling curve on this node for THIS workload; the N=1 line of `bench.py` is another
-        # workload (configs[2]), so value / anchor.value is the efficiency the exchange and the partitioning leave.
+    if cdist is not None:    # outside the timed region: what the same ranks do WITHOUT the exchange — every rank pushes its own shards through one local context
+        # (table not partitioned).  N x this rate is the ceiling on this node for this split of the data.
         t_loc = -1.0
         try:
             ts = []
             for _ in range(3):
                 torch.cuda.synchronize(); m.sync()
                 t1 = time.perf_counter()
-                m.reset(0)
-                if packed:
-                    m.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
-                else:
-                    m.ingest_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)
-                m.finalize_device()
+                local_step()
                 m.sync()
                 ts.append(time.perf_counter() - t1)
             t_loc = min(ts[1:])          # the first pass sizes the store and the table
             m.reset(0)
         except Exception as ex:          # (the line above it is the result; a failure here must not lose it — but every rank still joins the all-reduce)
             print("bench.py: local anchor pass failed on rank %d: %r" % (rank, ex), file=sys.stderr)
-        ta = torch.tensor([t_loc, -t_loc], device="cuda", dtype=torch.float64)
-        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
-        t_max, t_min = float(ta[0].item()), -float(ta[1].item())
+        ta = allreduce([t_loc, -t_loc], torch.float64, dist.ReduceOp.MAX)
+        t_max, t_min = float(ta[0]), -float(ta[1])
         if t_min > 0:
-            anchor = {"what": "the same %d rank(s), each pushing its own shard through one local context: no exchange, table not partitioned (after the timed region; "
-                              "slowest rank)" % world, "value": total_bases / t_max / 1e9, "unit": "Gbases/s", "ms_per_step": t_max * 1e3}
+            anchor = {"what": "the same %d rank(s), each pushing its own %d batch(es) through one local context: no exchange, table not partitioned (after the timed region; "
+                              "slowest rank)" % (world, len(batches)), "value": total_bases / t_max / 1e9, "unit": "Gbases/s", "ms_per_step": t_max * 1e3}
     st = m.stats()          # stats of the last step only (reset clears the timers)
     if cdist is not None:
         m_stats = api_stats_of(cdist)
@@ -388,52 +462,83 @@ def main():
             roof["traffic"], roof["traffic_source"] = pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args)
             sq = sq_counters(args)
             if sq:
-                roof.update(valu_util=sq.get("valu_util"), valu_lane_ops_per_base=sq.get("valu_lane_ops_per_base"), sq_source=sq.get("source"))
+                roof.update(valu_lane_ops_per_base=sq.get("valu_lane_ops_per_base"), wave_time_split=sq.get("wave_time_split"), sq_source=sq.get("source"))
             if packed:
                 roof["note"] = ("b_in = 0.25 B/base (2-bit packed input, the north-star layout): the kernel is bound by instruction issue (integer VALU, LDS, scalar), "
                                 "not by HBM (valu_lane_ops_per_base%s); the same kernel on the b_in = 1.0 accounting is in roofline_ascii"
                                 % ("; traffic = %.2fx the algorithmic bytes" % (roof["traffic"] / roof["algorithmic_bytes_per_launch"]) if roof["traffic"] else ""))
-        roof_ascii = None
-        if packed and not routed:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
+        roof_ascii = ascii_in = None
+        if packed and not routed and not human:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
             for _ in range(2):
                 m.reset(0)
-                m.sketch_device(d_bases, d_off, reads_per_gpu, n_bases, first_ordinal)
+                m.sketch_device(d_bases, d_off0, reads_per_gpu, n_bases, rank * reads_per_gpu)
             sta = m.stats()
             roof_ascii = roofline(sta, 1.0, "ascii")
             if roof_ascii:
                 roof_ascii["traffic"], roof_ascii["traffic_source"] = pmc_traffic(sta["n_sketch_tile_bases"] / sta["n_sketch_tile_launches"], args, "ascii")
-            m.reset(0)
-            m.ingest_packed_device(d_in, d_off, reads_per_gpu, n_bases, first_ordinal)      # the table the edge stage and the baseline below refer to
-            m.finalize_device()
+            # the same STEPS fed ASCII (both legs start from ASCII, concatenated + offsets): the timed region above starts from the packed layout,
+            # which the device packer produces in pack_ms
+            local_step(ascii_in=True)
+            m.sync()
+            t1 = time.perf_counter()
+            na = max(3, min(10, args.steps))
+            for _ in range(na):
+                local_step(ascii_in=True)
+            m.sync()
+            ms_a = (time.perf_counter() - t1) / na * 1e3
+            ascii_in = {"ms_per_step": ms_a, "value": n_bases / ms_a / 1e6, "unit": "Gbases/s", "steps": na, "pack_ms": pack_ms,
+                        "value_pack_then_packed": n_bases / (pack_ms + ms_step) / 1e6 if pack_ms else None,
+                        "what": "the same steps with the reads resident as ASCII (one byte per base): the tile kernel converts on the fly; pack_ms = mdbg_pack_device "
+                                "(ASCII -> 2-bit planes) alone; value_pack_then_packed = bases / (pack_ms + ms_per_step of the timed region)"}
+            local_step()      # the table the edge stage and the baseline below refer to
         edges = None
-        if not routed:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
+        if not routed and not human:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
             m.graph_edges_device(0.01)
             t1 = time.perf_counter()
             e = m.graph_edges_device(0.01)
             edges = {"ms": (time.perf_counter() - t1) * 1e3, "n_edges": int(e.n), "presimp_removed": int(e.presimp_removed)}
         cpu = None
         if args.cpu_seconds > 0 and world == 1:          # rank 0 at N=1 only: at N>1 the other ranks would wait for it
-            cpu = cpu_baseline(m, d_bases, d_off, reads_per_gpu, n_bases, args)
+            # (human: d_bases / d_off0 hold the ASCII of the last shard generated — a sample of the same data set)
+            cpu = cpu_baseline(m, d_bases, d_off0, shard_reads, batches[-1][3], args)
         graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
-        want = expected_graph(args, world, reads_per_gpu, n_bases)
+        want = expected_graph(args, world, shard_reads, total_bases)
         if want is not None and not os.environ.get("MDBG_STOP_PHASE") and any(graph[f] != want[f] for f in want):
             raise SystemExit("bench.py: the graph of this run %r differs from the recorded one %r (tests/golden/bench_counts.json): no line printed" % (graph, want))
+        if human:
+            wl = ("synthetic human %.0f Mb @%.0fx (BASELINE.json configs[3]): %.1f Gbases of ~15 kb HiFi-shaped reads, 0.1%% errors, held as %d shards; the SAME data set at "
+                  "every N: %d batch(es) per rank and step" % (args.genome_mb, args.coverage, total_bases / 1e9, HUMAN_SHARDS, len(batches)))
+        else:
+            wl = "synthetic D. melanogaster %.0f Mb @%.0fx per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1%% errors" % (args.genome_mb, args.coverage)
+        if not routed:
+            par = "single GPU"
+        else:
+            if cdist is not None:
+                how = "%s exchanged by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h) in %d chunks per batch overlapping the tile kernel" % (
+                    "window lists + the sketch hashes they need" if args.dist_exchange == "segments" else "whole sketches + window lists", n_chunks)
+                if host_comm:
+                    how = how.replace("by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h)", "by the same layer (mdbg_dist.h) through HOST memory over gloo")
+            else:
+                how = ("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if replicate else "all-to-all of k-min-mer records"
+            par = "reads sharded by record x%d, table partitioned by key; %s%s" % (world, how, "" if host_comm else " over RCCL")
+            if host_comm:
+                par += "; DRY RUN (--comm host): %d ranks on %d GPU(s), not RCCL, not a result" % (world, min(world, n_dev))
         out = {"metric": "Gbases/s ingested to k-min-mer graph", "value": value, "unit": "Gbases/s", "n_gpus": n_ranks, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if human else "weak", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
-               "config": {"workload": ("synthetic human 3 Gb @52x over 8 GPUs (BASELINE.json configs[3]): %.0f Mb of genome and %.1f Gbases of ~15 kb HiFi-shaped reads per GPU, 0.1%% errors"
-                                       % (args.genome_mb, n_bases / 1e9)) if world > 1 else
-                                      "synthetic D. melanogaster %.0f Mb @%.0fx per GPU (BASELINE.json configs[2]): ~15 kb HiFi-shaped reads, 0.1%% errors" % (args.genome_mb, args.coverage),
-                          "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund, "reads_per_gpu": reads_per_gpu,
-                          "bases_per_gpu": n_bases, "input_format": args.input,
-                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": ("reads sharded by record x%d, table partitioned by key; %s over RCCL" % (world, ("%s exchanged by grouped ncclSend/ncclRecv inside libmdbg_hip.so (mdbg_dist.h) in %d chunks overlapping the tile kernel" % ("window lists + the sketch hashes they need" if args.dist_exchange == "segments" else "whole sketches + window lists", n_chunks)) if cdist is not None else (("sketches exchanged by send/recv pairs in %d chunks overlapping the tile kernel" % n_chunks) if args.dist_mode == "replicate" else "all-to-all of k-min-mer records"))) if routed else "single GPU"},
-               "roofline": roof, "roofline_ascii": roof_ascii, "cpu_baseline": cpu,
+               "config": {"workload": wl, "workload_key": args.workload, "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund,
+                          "genome_mb": args.genome_mb, "coverage": args.coverage, "reads_per_gpu": reads_per_gpu,
+                          "bases_per_gpu": n_bases, "batches_per_step": len(batches), "total_bases": total_bases, "input_format": args.input,
+                          "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": par,
+                          "comm": None if not routed else ("host-staged over gloo: DRY RUN, not RCCL" if host_comm else "rccl")},
+               "roofline": roof, "roofline_ascii": roof_ascii, "ascii_in": ascii_in, "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
                          "checked_against_recorded_counts": want is not None,
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent},
-               "exchange": exchange, "no_exchange_anchor": anchor, "edges_after_timed_region": edges}
+               "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": n1_same_workload(args) if (human and world > 1) else None,
+               "edges_after_timed_region": edges}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     if cdist is not None:

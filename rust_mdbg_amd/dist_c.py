@@ -42,10 +42,90 @@ def rccl_comm(rank, world, dist=None):
     return comm, L
 
 
-class DistMdbg:
-    """mdbg_dist over RCCL: one per process / GPU"""
+class Xfer(C.Structure):            # mdbg_xfer
+    _fields_ = [("peer", C.c_uint32), ("d_ptr", C.c_void_p), ("bytes", C.c_uint64)]
 
-    def __init__(self, k, l, density, min_abundance, rank, world, dist=None, device=-1, reads_already_hpc=False):
+
+class HostStagedComm:
+    """An mdbg_comm whose transfers are staged through HOST memory and carried by a torch.distributed process group of CPU tensors (gloo):
+    device -> host copy, send / recv between the processes, host -> device copy.  It is the transport for DRY RUNS of the multi-process path
+    where there is no GPU per rank (several ranks share one device, where RCCL refuses to start) — every line of the multi-GPU layer above
+    the communicator runs exactly as under RCCL, the bytes just take the slow road.  NOT the RCCL path; `bench.py --comm host` labels its line so."""
+    AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64))
+    EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Xfer), C.c_uint32, C.POINTER(Xfer), C.c_uint32)
+    AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
+
+    def __init__(self, dist, rank, world, group=None):
+        import numpy as np
+        import torch
+        self.rank, self.world = rank, world
+        hip = C.CDLL("libamdhip64.so")        # (the copy torch loaded: same SONAME)
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        D2H, H2D = 2, 1
+
+        def allgather(_, send, n, recv):
+            try:
+                mine = torch.from_numpy(np.array([send[i] for i in range(n)], dtype=np.uint64).view(np.int64))
+                out = [torch.zeros(n, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(out, mine, group=group)
+                flat = np.concatenate([o.numpy() for o in out]).view(np.uint64) if n else np.zeros(0, np.uint64)
+                for i in range(world * n):
+                    recv[i] = int(flat[i])
+                return 0
+            except Exception:
+                return -4
+
+        def exchange(_, sends, ns, recvs, nr):
+            try:
+                ops, bufs, seq_s, seq_r = [], [], {}, {}
+                for i in range(nr):                       # receives first: every peer's sends then find their match whatever the order of arrival
+                    p, nbytes = int(recvs[i].peer), int(recvs[i].bytes)
+                    t = torch.empty(nbytes, dtype=torch.uint8)
+                    tag = seq_r.get(p, 0); seq_r[p] = tag + 1      # transfers between a pair are matched in the order they are listed
+                    ops.append(dist.irecv(t, src=p, group=group, tag=tag))
+                    bufs.append((t, recvs[i].d_ptr, nbytes))
+                for i in range(ns):
+                    p, nbytes = int(sends[i].peer), int(sends[i].bytes)
+                    t = torch.empty(nbytes, dtype=torch.uint8)
+                    if hip.hipMemcpy(t.data_ptr(), sends[i].d_ptr, nbytes, D2H) != 0:
+                        return -4
+                    tag = seq_s.get(p, 0); seq_s[p] = tag + 1
+                    ops.append(dist.isend(t, dst=p, group=group, tag=tag))
+                for o in ops:
+                    o.wait()
+                for t, d_ptr, nbytes in bufs:
+                    if hip.hipMemcpy(d_ptr, t.data_ptr(), nbytes, H2D) != 0:
+                        return -4
+                return 0
+            except Exception:
+                return -4
+
+        def allreduce(_, d_buf, n):
+            try:
+                a = torch.zeros(int(n), dtype=torch.int64)
+                if n and hip.hipMemcpy(a.data_ptr(), d_buf, n * 8, D2H) != 0:
+                    return -4
+                dist.all_reduce(a, group=group)            # (two's complement: the sum of int64 is the sum of u64 modulo 2^64)
+                if n and hip.hipMemcpy(d_buf, a.data_ptr(), n * 8, H2D) != 0:
+                    return -4
+                return 0
+            except Exception:
+                return -4
+
+        self.fns = (self.AG(allgather), self.EX(exchange), self.AR(allreduce))      # kept alive as long as the mdbg_dist
+        cm = Comm()
+        cm.self = None
+        cm.rank, cm.world = rank, world
+        cm.allgather_u64 = C.cast(self.fns[0], C.c_void_p)
+        cm.exchange = C.cast(self.fns[1], C.c_void_p)
+        cm.allreduce_sum_u64 = C.cast(self.fns[2], C.c_void_p)
+        self.table = cm
+
+
+class DistMdbg:
+    """mdbg_dist: one per process / GPU.  transport "rccl" (default): the library's own RCCL calls; "host": HostStagedComm over `dist` (dry runs)"""
+
+    def __init__(self, k, l, density, min_abundance, rank, world, dist=None, device=-1, reads_already_hpc=False, transport="rccl"):
         self.L = api.load_library()
         L = self.L
         L.mdbg_comm_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Comm)]
@@ -61,9 +141,14 @@ class DistMdbg:
         L.mdbg_dist_set_exchange.argtypes = [C.c_void_p, C.c_uint32]
         L.mdbg_dist_destroy.argtypes = [C.c_void_p]
         L.mdbg_dist_traffic.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        self.comm, self.rccl = rccl_comm(rank, world, dist)
-        vt = Comm()
-        self._chk(L.mdbg_comm_rccl(self.comm, rank, world, C.byref(vt)))
+        self.comm = self.rccl = self.host_comm = None
+        if transport == "host":
+            self.host_comm = HostStagedComm(dist, rank, world)
+            vt = self.host_comm.table
+        else:
+            self.comm, self.rccl = rccl_comm(rank, world, dist)
+            vt = Comm()
+            self._chk(L.mdbg_comm_rccl(self.comm, rank, world, C.byref(vt)))
         P = api.Params(k=k, l=l, density=density, min_abundance=min_abundance, reads_already_hpc=int(reads_already_hpc), device=device, flags=0,
                        table_capacity_hint=0)
         err = C.c_int()
@@ -111,4 +196,5 @@ class DistMdbg:
         if self.h:
             self.L.mdbg_dist_destroy(self.h)
             self.h = None
-            self.rccl.ncclCommDestroy(self.comm)
+            if self.rccl is not None:
+                self.rccl.ncclCommDestroy(self.comm)

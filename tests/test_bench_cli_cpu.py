@@ -22,6 +22,13 @@ def test_bench_world_size_must_match_gpus_flag():
     assert r.returncode != 0 and "--gpus 1 but the launcher started 2 rank(s)" in r.stderr and r.stdout.strip() == ""
 
 
+def test_bench_human_workload_needs_a_divisor_of_its_shards():
+    """--workload human is the same eight shards at every N: a rank count that does not divide them is refused before anything runs"""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "--gpus must divide 8" in r.stderr and r.stdout.strip() == ""
+
+
 def test_nccl_unique_id_travels_whole():
     """the 128-byte ncclUniqueId is binary: a NUL byte inside must not shorten what rank 0 broadcasts (rust_mdbg_amd/dist_c.py)"""
     from rust_mdbg_amd.dist_c import UniqueId

@@ -1,0 +1,43 @@
+"""bench.py's N>1 path executed for real before an 8-GPU node ever sees it: two OS processes, the library's multi-GPU layer (include/mdbg_dist.h),
+the exchange staged through host memory over gloo (--comm host) because two ranks share this box's one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _bench(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_dry_run_matches_one_rank():
+    small = ["--workload", "human", "--genome-mb", "40", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"]
+    one = _bench("--gpus", "1", *small)
+    two = _bench("--gpus", "2", "--comm", "host", *small)
+    assert one["n_gpus"] == 1 and one["config"]["batches_per_step"] == 8 and one["scaling"] == "strong"
+    assert two["n_gpus"] == 2 and two["config"]["batches_per_step"] == 4 and two["scaling"] == "strong"
+    assert two["config"]["total_bases"] == one["config"]["total_bases"] and 2 * two["config"]["bases_per_gpu"] != 0
+    # the same data set, the same graph: the partitions add up to the node count one context finds
+    assert two["graph"]["partitions_add_up"] is True and two["graph"]["nodes"] == one["graph"]["nodes"] > 1000
+    assert two["exchange"]["bytes_in_busiest_rank_per_step"] > 0 and "not RCCL" in two["exchange"]["transport"]
+    assert two["no_exchange_anchor"] and two["no_exchange_anchor"]["value"] > 0
+    assert "DRY RUN" in two["config"]["parallelism"] and "not RCCL" in two["config"]["comm"]
+    assert two["roofline"]["kernel"] == "sketch_bs_kernel<14>" and one["roofline"]["launches_per_step"] == 8
+
+
+@pytest.mark.gpu
+def test_bench_default_line_carries_the_ascii_leg():
+    j = _bench("--gpus", "1", "--genome-mb", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0")
+    a = j["ascii_in"]
+    assert j["config"]["workload_key"] == "fly" and a["ms_per_step"] > 0 and a["pack_ms"] > 0 and 0 < a["value_pack_then_packed"] < j["value"]
+    assert "valu_util" not in j["roofline"]
