@@ -94,7 +94,7 @@ def test_config3_size_properties():
             assert np.array_equal(one[f], three[f]), f
         del words
         import json
-        want = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w["reads_per_gpu"] == n_reads and w["l"] == l][0]
+        want = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w.get("reads_per_gpu") == n_reads and w["l"] == l][0]
         assert nb == want["bases_per_gpu"]
         assert {"minimizers": st3["n_minimizers"], "windows": st3["n_windows"], "distinct": st3["n_distinct"], "nodes": three["n_nodes"]} == want["graph"]
         assert (st["n_minimizers"], st["n_windows"], st["n_distinct"]) == (st3["n_minimizers"], st3["n_windows"], st3["n_distinct"])
