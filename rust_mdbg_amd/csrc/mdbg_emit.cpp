@@ -699,8 +699,11 @@ mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threa
     if (!r || threads <= 1 || r->lz) return r;
     // gzip: the inflate runs ahead of the parser on its own thread; BGZF blocks are inflated by the remaining threads (an ordinary gzip file is one stream)
     if (r->gzin) {
-        r->gz_ahead = true; r->gzin->core.threads = std::min(48, std::max(1, threads - 1));      // (beyond a few dozen the serial parts of a round dominate)
-        r->gw_mode = true; r->threads = threads;
+        // the thread budget is SPLIT: the read-ahead worker + inflate threads on one side (BGZF blocks; an ordinary stream is decoded by one thread, see
+        // gz_inflate.h), the parser threads of a window on the other — together `threads`, not twice that
+        const int inflate = std::min(48, std::max(1, threads / 2));                            // (beyond a few dozen the serial parts of a round dominate)
+        r->gz_ahead = true; r->gzin->core.threads = inflate;
+        r->gw_mode = true; r->threads = std::max(1, threads - inflate);
         r->gzin->set_depth(8, 16u << 20);                                        // up to 128 MB of text inflated while the previous window is parsed
         r->gw_cap = 1u << 20; r->gw = (u8*)malloc(r->gw_cap);
         if (!r->gw) { mdbg_reader_close(r); if (err) *err = MDBG_E_NOMEM; return nullptr; }

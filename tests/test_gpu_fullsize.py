@@ -142,7 +142,7 @@ def test_batch_larger_than_2_33_bases_equals_split_batches():
         m.ingest_device(db, do, n_reads, nb, 0)
         one = m.finalize()
         st = m.stats()
-        assert st["n_tiles"] == -(-nb // st["tile_bases"]) > 262144 and 1 <= st["n_sketch_tile_launches"] <= 4
+        assert st["n_tiles"] == -(-nb // st["tile_bases"]) > 262144 and st["n_sketch_tile_launches"] == 1      # (one launch per batch at every BASELINE configuration: the slabs of 277 k tiles take 1.2 of the 6 GB a launch may use)
         offs = m.to_host(do, (n_reads + 1) * 8, np.uint64)
         half = n_reads // 2
         cut = int(offs[half]) // 16 * 16                      # the device bases pointer must stay 16-byte aligned

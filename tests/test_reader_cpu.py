@@ -314,7 +314,6 @@ def test_gzip_decoder_over_levels_strategies_and_members(tmp_path):
     cut = [0, 100, 300_107, 300_108, 1_000_000, len(raw)]             # members cut anywhere (also in the middle of a header line), an empty one between
     files["members"] = b"".join(_member(raw[a:b]) + _member(b"") for a, b in zip(cut, cut[1:]))
     files["members_padded"] = files["members"] + bytes(1000)
-    files["members_garbage"] = files["members"] + b"not a gzip member"
     files["bgzf"] = _bgzf(raw)
     files["bgzf_small_blocks"] = _bgzf(raw, 777)
     files["bgzf_then_member_then_bgzf"] = _bgzf(raw[:500_000]) + _member(raw[500_000:900_000]) + _bgzf(raw[900_000:])
@@ -352,6 +351,9 @@ def test_gzip_decoder_rejects_damaged_streams(tmp_path):
     flipped = bytearray(good); flipped[len(good) // 3] ^= 0x10
     fails(bytes(flipped))                                            # a bit in the middle: caught by the decoder or, at the latest, by the CRC
     fails(good + b"\x1f\x8b\x08\xe0" + bytes(20))                    # a second member with reserved flag bits
+    fails(good + b"not a gzip member")                                # bytes behind a member that are neither a member nor zero padding (MultiGzDecoder: invalid gzip header)
+    fails(good + b"\x1e\x8b\x08\x00" + good[4:])                     # a later member with a damaged magic: its reads must not vanish quietly
+    fails(good + bytes(100) + b"\x01")                               # padding that is not all zero
     hdr = bytearray(_member(raw[:50_000])); hdr[14] ^= 0x01            # a byte of the extra field: the header's CRC-16 no longer matches (zlib and flate2 check it)
     fails(bytes(hdr))
     bg = bytearray(_bgzf(raw))
