@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="layout of the reads in HBM during the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--plain", action="store_true", help="only the warm-up and the timed steps (no ASCII legs, no edge stage, no CPU leg): for profiler runs, where every launch should be one of the timed kind")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
                     help="multi-GPU mode: exchange of sketch hashes + key-partitioned table (default inside a node: 3.5x faster per rank and fewer bytes than records up to ~10 ranks, DESIGN.md 3.4), or all-to-all of k-min-mer records by key range (the north star's wording)")
@@ -468,7 +469,7 @@ def main():
                                 "not by HBM (valu_lane_ops_per_base%s); the same kernel on the b_in = 1.0 accounting is in roofline_ascii"
                                 % ("; traffic = %.2fx the algorithmic bytes" % (roof["traffic"] / roof["algorithmic_bytes_per_launch"]) if roof["traffic"] else ""))
         roof_ascii = ascii_in = None
-        if packed and not routed and not human:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
+        if packed and not routed and not human and not args.plain:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
             for _ in range(2):
                 m.reset(0)
                 m.sketch_device(d_bases, d_off0, reads_per_gpu, n_bases, rank * reads_per_gpu)
@@ -492,13 +493,13 @@ def main():
                                 "(ASCII -> 2-bit planes) alone; value_pack_then_packed = bases / (pack_ms + ms_per_step of the timed region)"}
             local_step()      # the table the edge stage and the baseline below refer to
         edges = None
-        if not routed and not human:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
+        if not routed and not human and not args.plain:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
             m.graph_edges_device(0.01)
             t1 = time.perf_counter()
             e = m.graph_edges_device(0.01)
             edges = {"ms": (time.perf_counter() - t1) * 1e3, "n_edges": int(e.n), "presimp_removed": int(e.presimp_removed)}
         cpu = None
-        if args.cpu_seconds > 0 and world == 1:          # rank 0 at N=1 only: at N>1 the other ranks would wait for it
+        if args.cpu_seconds > 0 and world == 1 and not args.plain:          # rank 0 at N=1 only: at N>1 the other ranks would wait for it
             # (human: d_bases / d_off0 hold the ASCII of the last shard generated — a sample of the same data set)
             cpu = cpu_baseline(m, d_bases, d_off0, shard_reads, batches[-1][3], args)
         graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
@@ -528,7 +529,7 @@ def main():
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": wl, "workload_key": args.workload, "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund,
                           "genome_mb": args.genome_mb, "coverage": args.coverage, "reads_per_gpu": reads_per_gpu,
-                          "bases_per_gpu": n_bases, "batches_per_step": len(batches), "total_bases": total_bases, "input_format": args.input,
+                          "bases_per_gpu": n_bases, "batches_per_step": len(batches), "total_bases": total_bases, "input_format": args.input, "plain": bool(args.plain),
                           "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": par,
                           "comm": None if not routed else ("host-staged over gloo: DRY RUN, not RCCL" if host_comm else "rccl")},
                "roofline": roof, "roofline_ascii": roof_ascii, "ascii_in": ascii_in, "cpu_baseline": cpu,

@@ -72,6 +72,8 @@ def by_input(d):
     if not isinstance(f, list) or not isinstance(w, list) or len(f) != len(w) or not f:
         return None
     hbm = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w)]
+    if json.load(open(d + "/bench.json"))["config"].get("plain"):      # round 4: profiler runs are --plain (every launch is of the timed kind); the ASCII side comes from its own set
+        return {fmt: sum(hbm) / len(hbm)}
     if fmt != "packed" or len(hbm) < 4:
         return {fmt: sum(hbm) / len(hbm)}
     pk = hbm[:-3] + hbm[-1:]
@@ -96,7 +98,7 @@ def sq_summary(d, out):
     cfg = bench["config"]
     tile = [k for k in agg if k.startswith("sketch_bs_kernel")]
     res = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes) -- python bench.py --steps 1 --warmup 1 --cpu-seconds 0; per launch; "
-                   "launch order of a packed bench run: warmup + steps on packed input, two on ASCII (roofline_ascii), one more on packed input",
+                   "bench.py --plain: every launch is one of the timed kind (warm-up + steps)",
            "config": {f: cfg[f] for f in ("k", "l", "density", "minabund", "input_format", "bases_per_gpu")}, "kernels": {}}
     for k in agg:
         if not (k.startswith("sketch_bs") or k.startswith("insert_windows") or k.startswith("fin_") or k.startswith("gather")):
@@ -109,9 +111,8 @@ def sq_summary(d, out):
         res["derived"] = {
             "valu_lane_ops_per_base": first("SQ_INSTS_VALU") * 64.0 / nb,
             "valu_instr_per_simd_cycle": first("SQ_INSTS_VALU") / (first("SQ_BUSY_CU_CYCLES") * 4.0),
-            "valu_util": first("SQ_ACTIVE_INST_VALU") * 4.0 / (first("SQ_BUSY_CU_CYCLES") * 4.0),
-            "valu_util_definition": "SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SQ_BUSY_CU_CYCLES * 4 SIMDs); gfx950 issues the simple integer ops in 2 cycles but "
-                                    "counts a quad-cycle per instruction, so a saturated VALU reads above 1",
+            # (rounds 2-3 also derived a "valu_util" from SQ_ACTIVE_INST_VALU, which counts a quad-cycle per instruction whatever it costs and so read 1.03: dropped.
+            #  VALU cycles estimated from the instruction mix and the measured issue rates, profiles/r01_g_valu_rates.txt: ~77 % of the kernel's SIMD cycles)
             "wave_time_split": {"active": first("SQ_ACTIVE_INST_ANY") / first("SQ_WAVE_CYCLES"), "parked_waitcnt_barrier": first("SQ_WAIT_ANY") / first("SQ_WAVE_CYCLES"),
                                 "issue_stall": first("SQ_WAIT_INST_ANY") / first("SQ_WAVE_CYCLES")},
             "salu_per_valu": first("SQ_INSTS_SALU") / first("SQ_INSTS_VALU"), "lds_per_valu": first("SQ_INSTS_LDS") / first("SQ_INSTS_VALU")}
