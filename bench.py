@@ -37,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+MULTIK = [10, 15, 20, 25, 30, 35, 40]      # utils/multik:69-78 (k from 10 to 40 in steps of 5)
 HUMAN_SHARDS = 8            # --workload human: the data set is held as the eight shards of BASELINE.json configs[3]
 
 
@@ -56,6 +57,9 @@ def parse():
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="layout of the reads in HBM during the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--multik", action="store_true",
+                    help="BASELINE.json configs[4]: a step = sketch ONCE (l=12 d=0.003), then the graph of every k in 10,15,..,40 from the resident sketches (mdbg_reset(new_k): the table is "
+                         "cleared and refilled, nothing is sketched or — at N>1, where the ranks hold whole sketches — exchanged again); value counts every k's graph: bases x 7 / time")
     ap.add_argument("--plain", action="store_true", help="only the warm-up and the timed steps (no ASCII legs, no edge stage, no CPU leg): for profiler runs, where every launch should be one of the timed kind")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
@@ -86,6 +90,12 @@ def parse():
         ap.error("--workload human is held as %d shards: --gpus must divide %d" % (HUMAN_SHARDS, HUMAN_SHARDS))
     if human and (a.input != "packed" or a.dist_impl != "c"):
         ap.error("--workload human: packed input and the C layer only")
+    if a.multik:
+        if not human or a.dist_impl != "c":
+            ap.error("--multik runs on the human workload (configs[4]) and the C layer")
+        if a.l is None: a.l = 12
+        a.k = MULTIK[0]
+        a.dist_exchange = "whole"              # the multik mode of the multi-GPU layer: every rank keeps every sketch entire, so a new k needs no new exchange (mdbg_dist_set_exchange)
     if a.genome_mb is None: a.genome_mb = 3000.0 if human else 140.0
     if a.coverage is None: a.coverage = 52.0 if human else 50.0
     if a.l is None: a.l = 14 if human else 12
@@ -102,11 +112,13 @@ def expected_graph(args, world, shard_reads, total_bases):
         return None
     for w in ref["workloads"]:
         if (w.get("workload", "fly"), w["k"], w["l"], w["density"], w["minabund"], w["genome_mb"], w["coverage"]) != \
-           (args.workload, args.k, args.l, args.density, args.minabund, args.genome_mb, args.coverage):
+           (args.workload + ("-multik" if args.multik else ""), args.k, args.l, args.density, args.minabund, args.genome_mb, args.coverage):
             continue
         if args.workload == "human":
             if w["total_bases"] != total_bases:
                 continue
+            if args.multik:
+                return {"nodes_per_k": w["graph"]["nodes_per_k"]}      # (global counts: the same at every N)
             return dict(w["graph"]) if world == 1 else {"nodes": w["graph"]["nodes"]}
         if (w["n_gpus"], w["reads_per_gpu"], w["bases_per_gpu"]) == (world, shard_reads, total_bases):
             return w["graph"]
@@ -342,7 +354,29 @@ def main():
                 m.ingest_device(b_in, b_off, b_reads, b_bases, b_first)
         return m.finalize_device().n
 
+    per_k = []                                        # --multik: (k, global nodes) of the last sweep
+    sweep_stats = {}                                  # --multik: the context's stats right after the sweep's ingest (every mdbg_reset restarts the timers)
+
     def step():
+        if args.multik:
+            ctx = cdist if cdist is not None else m
+            ctx.reset(0)
+            ctx.reset(MULTIK[0])                      # (the sweep before left the context at the last k; nothing is resident: only k changes)
+            for (b_in, b_off, b_reads, b_bases, b_first) in batches:
+                (ctx.ingest_packed_device if packed else ctx.ingest_device)(b_in, b_off, b_reads, b_bases, b_first)
+            sweep_stats.clear()
+            sweep_stats.update(api_stats_of(cdist) if cdist is not None else m.stats())
+            per_k.clear()
+            for k in MULTIK:
+                if k != MULTIK[0]:
+                    ctx.reset(k)                      # clears the table and inserts the windows of the new k from the resident sketches
+                if cdist is not None:
+                    nd, _, ng = cdist.finalize()
+                    cdist.last_local = int(nd.n)
+                else:
+                    ng = int(m.finalize_device().n)
+                per_k.append((k, int(ng)))
+            return per_k[-1][1]
         if cdist is not None:
             cdist.reset(0)
             for (b_in, b_off, b_reads, b_bases, b_first) in batches:
@@ -379,7 +413,7 @@ def main():
     n_nodes = 0
     for _ in range(args.steps):
         n_nodes = step()
-        sti = api_stats_of(cdist) if cdist is not None else m.stats()
+        sti = sweep_stats if args.multik else (api_stats_of(cdist) if cdist is not None else m.stats())
         for f in tile_acc:
             tile_acc[f] += sti[f]
     fence()
@@ -404,7 +438,7 @@ def main():
                     "nodes_busiest_rank_over_mean": (float(tmax[1]) * world / float(tsum[1])) if int(tsum[1]) else None,
                     "transport": "host-staged over gloo (--comm host: DRY RUN, not RCCL)" if host_comm else "RCCL (grouped ncclSend / ncclRecv inside libmdbg_hip.so)"}
     anchor = None
-    if cdist is not None:    # outside the timed region: what the same ranks do WITHOUT the exchange — every rank pushes its own shards through one local context
+    if cdist is not None and not args.multik:    # outside the timed region: what the same ranks do WITHOUT the exchange — every rank pushes its own shards through one local context
         # (table not partitioned).  N x this rate is the ceiling on this node for this split of the data.
         t_loc = -1.0
         try:
@@ -430,6 +464,9 @@ def main():
         for f in ("n_minimizers", "n_windows", "n_distinct", "table_capacity", "n_slow_tiles", "n_tiles", "ms_sketch", "ms_sketch_tile", "ms_insert", "ms_finalize",
                   "n_sketch_tile_launches", "n_sketch_tile_bases", "n_bases"):
             st[f] = m_stats[f]
+    if args.multik:          # the sketch side of the line comes from the sweep's ingest, the table side from its last k
+        for f in ("ms_sketch", "ms_sketch_tile", "n_sketch_tile_launches", "n_sketch_tile_bases", "n_tiles", "n_slow_tiles"):
+            st[f] = sweep_stats[f]
     if routed and cdist is None and engine.tm is not m:
         st2 = engine.tm.stats()
         st["n_distinct"], st["table_capacity"] = st2["n_distinct"], st2["table_capacity"]
@@ -440,7 +477,7 @@ def main():
         print("[dist profile, ms per step] " + ", ".join("%s=%.2f" % (k, v / n) for k, v in runner.times.items()), file=sys.stderr)
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        value = total_bases * args.steps / dt / 1e9
+        value = total_bases * args.steps * (len(MULTIK) if args.multik else 1) / dt / 1e9
         mins_per_base = st["n_minimizers"] / max(1, st["n_bases"])
 
         def roofline(stt, b_in, fmt):
@@ -504,9 +541,14 @@ def main():
             cpu = cpu_baseline(m, d_bases, d_off0, shard_reads, batches[-1][3], args)
         graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
         want = expected_graph(args, world, shard_reads, total_bases)
+        if args.multik:
+            graph["nodes_per_k"] = [list(x) for x in per_k]
         if want is not None and not os.environ.get("MDBG_STOP_PHASE") and any(graph[f] != want[f] for f in want):
             raise SystemExit("bench.py: the graph of this run %r differs from the recorded one %r (tests/golden/bench_counts.json): no line printed" % (graph, want))
-        if human:
+        if human and args.multik:
+            wl = ("multik sweep k = %s on synthetic human %.0f Mb @%.0fx (BASELINE.json configs[4]): %.1f Gbases, l=%d d=%g, sketched ONCE per step, then one graph per k from the "
+                  "resident sketches; value = bases x %d / time" % (",".join(map(str, MULTIK)), args.genome_mb, args.coverage, total_bases / 1e9, args.l, args.density, len(MULTIK)))
+        elif human:
             wl = ("synthetic human %.0f Mb @%.0fx (BASELINE.json configs[3]): %.1f Gbases of ~15 kb HiFi-shaped reads, 0.1%% errors, held as %d shards; the SAME data set at "
                   "every N: %d batch(es) per rank and step" % (args.genome_mb, args.coverage, total_bases / 1e9, HUMAN_SHARDS, len(batches)))
         else:
@@ -527,7 +569,7 @@ def main():
         out = {"metric": "Gbases/s ingested to k-min-mer graph", "value": value, "unit": "Gbases/s", "n_gpus": n_ranks, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if human else "weak", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
-               "config": {"workload": wl, "workload_key": args.workload, "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund,
+               "config": {"workload": wl, "workload_key": args.workload + ("-multik" if args.multik else ""), "multik": MULTIK if args.multik else None, "k": args.k, "l": args.l, "density": args.density, "minabund": args.minabund,
                           "genome_mb": args.genome_mb, "coverage": args.coverage, "reads_per_gpu": reads_per_gpu,
                           "bases_per_gpu": n_bases, "batches_per_step": len(batches), "total_bases": total_bases, "input_format": args.input, "plain": bool(args.plain),
                           "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": par,
@@ -537,7 +579,7 @@ def main():
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
                          "checked_against_recorded_counts": want is not None,
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
-                         "partitions_add_up": consistent},
+                         "partitions_add_up": consistent, "nodes_per_k": per_k if args.multik else None},
                "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": n1_same_workload(args) if (human and world > 1) else None,
                "edges_after_timed_region": edges}
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -41,3 +41,16 @@ def test_bench_default_line_carries_the_ascii_leg():
     a = j["ascii_in"]
     assert j["config"]["workload_key"] == "fly" and a["ms_per_step"] > 0 and a["pack_ms"] > 0 and 0 < a["value_pack_then_packed"] < j["value"]
     assert "valu_util" not in j["roofline"]
+
+
+@pytest.mark.gpu
+def test_bench_multik_sweep_one_rank_and_two_ranks_agree():
+    """configs[4]: sketched once, one graph per k from the resident sketches; at N>1 the ranks keep whole sketches, so no k needs a new exchange"""
+    small = ["--workload", "human", "--multik", "--genome-mb", "40", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0"]
+    one = _bench("--gpus", "1", *small)
+    two = _bench("--gpus", "2", "--comm", "host", *small)
+    ks = [10, 15, 20, 25, 30, 35, 40]
+    assert [k for k, _ in one["graph"]["nodes_per_k"]] == ks and one["config"]["l"] == 12 and one["config"]["multik"] == ks
+    assert one["graph"]["nodes_per_k"] == two["graph"]["nodes_per_k"] and all(n > 500 for _, n in one["graph"]["nodes_per_k"])
+    assert two["exchange"]["mode"] == "whole" and two["graph"]["partitions_add_up"] is True
+    assert one["roofline"]["launches_per_step"] == 8          # one sketch per batch and sweep: nothing is sketched again for the later k
