@@ -83,8 +83,9 @@ int mdbg_dist_set_pipeline(mdbg_dist* d, uint32_t chunks);
  *   steps, so a rank's windows come in runs and a run of r windows needs r + k - 1 hashes: a few hashes per window, and a volume per rank
  *   that does not grow with the number of ranks.  The foreign sketches are then resident only where this k needs them:
  *   mdbg_dist_reset(d, new_k != k) returns MDBG_E_STATE.
- * MDBG_EXCHANGE_WHOLE: every rank receives every sketch entire (8 bytes per minimizer and peer: what round 2 did); needed for re-windowing
- *   the resident global sketch at another k without a new exchange. */
+ * MDBG_EXCHANGE_WHOLE: every rank receives every sketch entire (8 bytes per minimizer and peer: what round 2 did).  THE MODE OF A MULTI-K SWEEP
+ *   (utils/multik: k = 10, 15, .. 40 on the same reads): the resident global sketch is re-windowed at every k without a new exchange — one
+ *   exchange of 1.3 GB into a rank (8 ranks, 7-Gbase shards) instead of one of 0.3 GB per k under segments.  bench.py --multik selects it. */
 enum { MDBG_EXCHANGE_SEGMENTS = 0, MDBG_EXCHANGE_WHOLE = 1 };
 int mdbg_dist_set_exchange(mdbg_dist* d, uint32_t mode);
 
