@@ -60,7 +60,7 @@ def test_block_cache_keeps_and_releases():
     from oracle import oracle as O
     bases, offs = O.concat_reads(reads)
     for _ in range(2):                         # the second context finds the first one's blocks
-        with R.Mdbg(21, 12, 0.01, 2) as m:
+        with R.Mdbg(21, 12, 0.01, 1) as m:          # (random reads share nothing: min_abundance 1)
             m.ingest(bases, offs, 0)
             n = int(m.finalize()["n_nodes"])
     freed = R.api.release_cached_memory()
