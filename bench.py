@@ -19,7 +19,8 @@ staged through host memory and carried by gloo (rust_mdbg_amd/dist_c.py HostStag
 At N>1 the line also carries `no_exchange_anchor`: the same ranks, each pushing its own shards through one local context right after the timed region
 (no exchange, table not partitioned), and `n1_same_workload`: the committed N=1 line of the same workload.
 The reads sit in HBM in the north star's layout, packed 2 bits per base (--input ascii: one byte per base, fly only); at N=1 the line also carries
-`ascii_in`: the same steps fed ASCII, and the time of the device packer, so that the GPU and the CPU leg can be read from the same starting bytes.
+`ascii_in`: the same steps fed ASCII, and the time of the device packer, so that the GPU and the CPU leg can be read from the same starting bytes,
+and `scale_anchor_n1`: the human data set of the N>1 lines streamed through this one GPU after the timed region — the N=1 point of the 1 -> 8 curve in the same record as the headline.
 
 Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (sketch_bs_kernel) as fed in the timed region and
 is measured live with HIP events on the stream the kernel is launched on; `roofline_ascii` is the same kernel fed ASCII
@@ -60,6 +61,7 @@ def parse():
     ap.add_argument("--multik", action="store_true",
                     help="BASELINE.json configs[4]: a step = sketch ONCE (l=12 d=0.003), then the graph of every k in 10,15,..,40 from the resident sketches (mdbg_reset(new_k): the table is "
                          "cleared and refilled, nothing is sketched or — at N>1, where the ranks hold whole sketches — exchanged again); value counts every k's graph: bases x 7 / time")
+    ap.add_argument("--no-scale-anchor", action="store_true", help="default N=1 run: skip the human data set's pass through this GPU after the timed region (scale_anchor_n1)")
     ap.add_argument("--plain", action="store_true", help="only the warm-up and the timed steps (no ASCII legs, no edge stage, no CPU leg): for profiler runs, where every launch should be one of the timed kind")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
@@ -235,6 +237,54 @@ def api_stats_of(cdist):
     return {f: getattr(s, f) for f, _ in api.Stats._fields_ if f != "reserved"}
 
 
+def human_shards(m, torch, np, genome_mb, coverage, shard_ids):
+    """the shards `shard_ids` of the human data set, generated on the device one after the other and kept packed: -> (batches, tensors that own them, reads per shard)"""
+    genome_len = int(genome_mb * 1e6)
+    shard_reads = int(genome_mb * 1e6 * coverage / 15000.0) // HUMAN_SHARDS
+    keep, batches = [], []
+    for g in shard_ids:
+        d_bases, d_off0, nb = m.synth_reads_device(seed=1, genome_len=genome_len, n_reads=shard_reads, mean_len=15000, sd_len=1500,
+                                                   min_len=8000, max_len=25000, err_ppm=1000, first_read=g * shard_reads)
+        words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+        offs = torch.from_numpy(m.to_host(d_off0, (shard_reads + 1) * 8, np.uint64).view(np.int64).copy()).cuda()
+        torch.cuda.synchronize()
+        assert m.pack_device(d_bases, nb, words.data_ptr()) == 0      # synthetic reads are pure ACGT
+        m.sync()
+        keep += [words, offs]
+        batches.append((words.data_ptr(), offs.data_ptr(), shard_reads, nb, g * shard_reads))
+    return batches, keep, shard_reads, (d_bases, d_off0)
+
+
+def scale_anchor_n1(R, torch, np, device_index, minabund):
+    """The N=1 point of the 1 -> 8 curve measured in the DEFAULT N=1 run as well: the multi-GPU lines run BASELINE configs[3] (the same 156 Gbases at every N), the
+    default N=1 line configs[2] — so the human data set goes through this one GPU once more here, after the timed region (about 3 s), and the curve's anchor sits in
+    the same driver record as the headline."""
+    k, l, d, gm, cov = 35, 14, 0.003, 3000.0, 52.0
+    with R.Mdbg(k, l, d, minabund, device=device_index) as mh:
+        batches, keep, shard_reads, _ = human_shards(mh, torch, np, gm, cov, range(HUMAN_SHARDS))
+
+        def one():
+            mh.reset(0)
+            for (b_in, b_off, b_reads, b_bases, b_first) in batches:
+                mh.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first)
+            return int(mh.finalize_device().n)
+        one()                                     # sizes the store and the table
+        mh.sync()
+        t1 = time.perf_counter()
+        steps = 3
+        for _ in range(steps):
+            nodes = one()
+        mh.sync()
+        ms = (time.perf_counter() - t1) / steps * 1e3
+        st = mh.stats()
+        total = sum(b[3] for b in batches)
+        del keep
+    return {"what": "BASELINE.json configs[3] (synthetic human 3 Gb @52x, k=35 l=14 d=0.003): the workload of the N>1 lines of this script, streamed through THIS one GPU as "
+                    "%d batches per step (= bench.py --gpus 1 --workload human), after the timed region" % HUMAN_SHARDS,
+            "value": total / ms / 1e6, "unit": "Gbases/s", "ms_per_step": ms, "steps": steps, "total_bases": total,
+            "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": nodes}}
+
+
 def main():
     args = parse()
     # stdout carries exactly one JSON line: native libraries (RCCL prints a version banner) write to file descriptor 1
@@ -282,20 +332,8 @@ def main():
     d_bases = d_off0 = None                           # ASCII of the (last generated) batch: owned by the context
     pack_ms = None
     if human:
-        genome_len = int(args.genome_mb * 1e6)
-        shard_reads = int(args.genome_mb * 1e6 * args.coverage / 15000.0) // HUMAN_SHARDS
         per_rank = HUMAN_SHARDS // world
-        for j in range(per_rank):
-            g = rank * per_rank + j
-            d_bases, d_off0, nb = m.synth_reads_device(seed=1, genome_len=genome_len, n_reads=shard_reads, mean_len=15000, sd_len=1500,
-                                                       min_len=8000, max_len=25000, err_ppm=1000, first_read=g * shard_reads)
-            words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
-            offs = torch.from_numpy(m.to_host(d_off0, (shard_reads + 1) * 8, np.uint64).view(np.int64).copy()).cuda()
-            torch.cuda.synchronize()
-            assert m.pack_device(d_bases, nb, words.data_ptr()) == 0      # synthetic reads are pure ACGT
-            m.sync()
-            keep += [words, offs]
-            batches.append((words.data_ptr(), offs.data_ptr(), shard_reads, nb, g * shard_reads))
+        batches, keep, shard_reads, (d_bases, d_off0) = human_shards(m, torch, np, args.genome_mb, args.coverage, range(rank * per_rank, (rank + 1) * per_rank))
         reads_per_gpu = shard_reads * per_rank
     else:
         genome_len = int(args.genome_mb * 1e6) * world            # weak scaling: coverage constant, genome grows with N
@@ -539,6 +577,13 @@ def main():
         if args.cpu_seconds > 0 and world == 1 and not args.plain:          # rank 0 at N=1 only: at N>1 the other ranks would wait for it
             # (human: d_bases / d_off0 hold the ASCII of the last shard generated — a sample of the same data set)
             cpu = cpu_baseline(m, d_bases, d_off0, shard_reads, batches[-1][3], args)
+        anchor1 = None
+        if world == 1 and not routed and not human and not args.plain and not args.no_scale_anchor and (args.genome_mb, args.coverage, args.l, args.density) == (140.0, 50.0, 12, 0.002):
+            anchor1 = scale_anchor_n1(R, torch, np, device_index, args.minabund)
+            w3 = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w.get("workload") == "human" and w["total_bases"] == anchor1["total_bases"]]
+            anchor1["checked_against_recorded_counts"] = bool(w3)
+            if w3 and args.minabund == 2 and any(anchor1["graph"][f] != w3[0]["graph"][f] for f in w3[0]["graph"]):
+                raise SystemExit("bench.py: the graph of the scale anchor %r differs from the recorded one %r: no line printed" % (anchor1["graph"], w3[0]["graph"]))
         graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
         want = expected_graph(args, world, shard_reads, total_bases)
         if args.multik:
@@ -580,7 +625,7 @@ def main():
                          "checked_against_recorded_counts": want is not None,
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent, "nodes_per_k": per_k if args.multik else None},
-               "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": n1_same_workload(args) if (human and world > 1) else None,
+               "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": n1_same_workload(args) if (human and world > 1) else None, "scale_anchor_n1": anchor1,
                "edges_after_timed_region": edges}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
