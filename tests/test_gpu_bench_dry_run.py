@@ -54,3 +54,13 @@ def test_bench_multik_sweep_one_rank_and_two_ranks_agree():
     assert one["graph"]["nodes_per_k"] == two["graph"]["nodes_per_k"] and all(n > 500 for _, n in one["graph"]["nodes_per_k"])
     assert two["exchange"]["mode"] == "whole" and two["graph"]["partitions_add_up"] is True
     assert one["roofline"]["launches_per_step"] == 8          # one sketch per batch and sweep: nothing is sketched again for the later k
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_through_the_rccl_transport():
+    """the nearest this pool gets to the driver's N>1 run: torch's nccl process group, the library's RCCL communicator (one rank), the multi-GPU layer, the human workload"""
+    small = ["--workload", "human", "--genome-mb", "40", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"]
+    one = _bench("--gpus", "1", *small)
+    rccl = _bench("--gpus", "1", "--force-dist", *small)
+    assert rccl["config"]["comm"] == "rccl" and "RCCL" in rccl["exchange"]["transport"] and rccl["graph"]["partitions_add_up"] is True
+    assert rccl["graph"]["nodes"] == one["graph"]["nodes"] and rccl["config"]["batches_per_step"] == 8 and rccl["no_exchange_anchor"]["value"] > 0
