@@ -363,4 +363,5 @@ inline void bs_make_table(bs_u64* tab /* 2 << 2*GS */) {
         tab[2 * idx] = f; tab[2 * idx + 1] = r;
     }
 }
-constexpr int BS_GS = 3;             // group size of the exact tables: 64 entries x 16 B = 1 KB of LDS
+constexpr int BS_GS = 3;             // group size of the exact tables: 64 entries x 16 B = 1 KB of LDS.  (4: three lookups instead of four for l = 12, but 4 KB — the
+                                     // tile kernel lost 10 %: 26.9 KB per workgroup no longer run six to a CU, profiles/r04_l_micro_ab.txt)

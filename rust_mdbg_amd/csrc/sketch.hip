@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kerne
     static_assert(TPW == 1 || NW == 1, "several tiles per workgroup: wave tiles only (no workgroup barrier inside a tile)");
     static_assert(SCHEME == 0 || (NW == 4 && TPW == 1), "the syncmer scheme runs on the 256-lane tiles");
     __shared__ TileLdsS<SCHEME, NW> S_all[TPW];
-    __shared__ u64 S_t3[T3_WORDS];
+    __shared__ __attribute__((aligned(16))) u64 S_t3[T3_WORDS];
     __shared__ u32 sync_tmp[SCHEME ? 16 : 1];       // scan scratch of the generic syncmer machine (its ring covers S)
     const u32 Lr = SCHEME ? a.l : (u32)L;           // l
     const int tslot = TPW == 1 ? 0 : (int)(threadIdx.x / TT);
@@ -526,8 +526,8 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kerne
     static_assert((2 * (DPAD + RW + 4)) % 4 == 0, "the dense stream is a whole number of 16-byte words");
     for (int i = tid; i < 2 * (DPAD + RW + 4) / 4; i += TT) ((uint4*)S.dense)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (SCHEME == 0) {                                // (TPW > 1: every wave writes the whole table — the same values — so none waits for another)
-        static_assert(T3_WORDS % 64 == 0 && T3_WORDS <= 4 * 64, "the table is copied by the lanes of one wave");
-        for (int i = tid; i < T3_WORDS; i += TT) S_t3[i] = a.t4[i];
+        static_assert(T3_WORDS % 128 == 0, "the table is copied 16 bytes per lane");
+        for (int i = tid; i < T3_WORDS / 2; i += TT) ((uint4*)S_t3)[i] = ((const uint4*)a.t4)[i];
     } else {                                          // 8 bits -> 16 bits, bit i to bit 2 i: the exact phase interleaves the code planes with it
         u32 v = 0;
         for (int i = 0; i < 8; ++i) v |= ((u32)tid >> i & 1u) << (2 * i);
@@ -645,11 +645,13 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kerne
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const u32 n = n_kept[i];
-        if (n) {
+        {   // no branches: an empty word ORs zeros, a word that does not straddle ORs zeros into the next one (the stream has spare words behind its end).
+            // With `if (n)` / `if (s + n > 32)` around the two atomics the tile kernel was 2 % slower (profiles/r04_l_micro_ab.txt): the second is taken by
+            // ~70 % of the lanes, so every wave ran both sides anyway and paid the exec-mask bookkeeping four times per lane.
             const u32 wi = off >> 5, s = off & 31;
             unsigned long long* dst = (unsigned long long*)(S.dense + 2 * (DPAD + wi));
             atomicOr(dst, (unsigned long long)(x0[i] >> s) | ((unsigned long long)(x1[i] >> s) << 32));
-            if (s + n > 32) atomicOr(dst + 1, (unsigned long long)bs_alignbit(x0[i], 0u, s) | ((unsigned long long)bs_alignbit(x1[i], 0u, s) << 32));
+            atomicOr(dst + 1, (unsigned long long)bs_alignbit(x0[i], 0u, s) | ((unsigned long long)bs_alignbit(x1[i], 0u, s) << 32));
         }
         off += n;
     }
@@ -688,23 +690,24 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kerne
         for (u32 st = wv_s; st < n_steps; st += TT / 64) {
             const int D = (int)(63 * st) + lane - 1;                  // lane 0 recomputes the word before the step's first
             const u32* dw = S.dense + 2 * (DPAD + (D < RW + 3 ? D : RW + 3));     // words past the stream are zero; their results are dropped
+            // the planes of the word in front live in the lane in front.  They come through the LDS crossbar (ds_bpermute: no memory
+            // access, and not a VALU slot — the kernel is bound by VALU issue; round 2 used 14 v_mov_dpp wave_shr:1 per word here)
             const uint2 c = *(const uint2*)dw, p = *(const uint2*)(dw - 2);
             uint2 q = make_uint2(0u, 0u);
             if (L + BS_B - 2 >= 32) q = *(const uint2*)(dw - 4);
-            // the planes of the word in front live in the lane in front.  They come through the LDS crossbar (ds_bpermute: no memory
-            // access, and not a VALU slot — the kernel is bound by VALU issue; round 2 used 14 v_mov_dpp wave_shr:1 per word here)
             u32 W[BS_B], Wp[BS_B], inv;
             bs_strand_planes<L, true>(c.x, c.y, p.x, p.y, q.x, q.y, W, inv);
 #pragma unroll
             for (int i = 0; i < BS_B - 1; ++i) Wp[i] = (u32)__builtin_amdgcn_ds_bpermute(nb_addr, (int)W[i]);
-            Wp[BS_B - 1] = 0;                                         // forward: plane BS_B-1 is already at the common delay
+            Wp[BS_B - 1] = 0;
             u32 cand = zero_test ? bs_strand_compare<true, true>(W, Wp, inv, bmask) : bs_strand_compare<true, false>(W, Wp, inv, bmask);
             bs_strand_planes<L, false>(c.x, c.y, p.x, p.y, q.x, q.y, W, inv);
-            Wp[0] = 0;                                                // reverse: plane 0 is
+            Wp[0] = 0;
 #pragma unroll
             for (int i = 1; i < BS_B; ++i) Wp[i] = (u32)__builtin_amdgcn_ds_bpermute(nb_addr, (int)W[i]);
             cand |= zero_test ? bs_strand_compare<false, true>(W, Wp, inv, bmask) : bs_strand_compare<false, false>(W, Wp, inv, bmask);
-            // only the step that holds the first owned position and the one that holds the last need the range mask (wave-uniform test)
+            // only the step that holds the first owned position and the one that holds the last need the range mask (wave-uniform test).
+            // (Two copies of the loop, one per kind of comparison, so that no step branches on zero_test: no difference, profiles/r04_l_micro_ab.txt.)
             const int Dw0 = (int)(63 * st) - 1;
             if (32 * Dw0 < x_lo || 32 * (Dw0 + 64) > x_hi) cand &= range_mask((int64_t)x_lo - 32 * (int64_t)D, (int64_t)x_hi - 32 * (int64_t)D);
             if (lane && (u32)D < n_out) S.c.cand[D] = cand;
