@@ -831,8 +831,14 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kerne
         const uint4 cw = *(const uint4*)(S.c.cand + WPT * tid);
         const u32 w5[5] = {cw.x, cw.y, cw.z, cw.w, tid == TT - 1 ? S.c.cand[RW] : 0u};       // the last thread also takes word RW
         const u32 c = bs_popc(cw.x) + bs_popc(cw.y) + bs_popc(cw.z) + bs_popc(cw.w) + bs_popc(w5[4]);
+        // one LDS fetch-add per WAVE: the lanes' counts are scanned with DPP and the last lane reserves the wave's slots (a fetch-add per thread with
+        // candidates — about half of them, all on one address — was 0.3 - 1.7 % slower in three of three pairs, profiles/r04_l_micro_ab.txt)
+        const u32 inc_c = wave_incl_scan(c);
+        u32 wbase = 0;
+        if (lane == 63) wbase = lds_fetch_add(&S.misc[17], inc_c);
+        wbase = (u32)__builtin_amdgcn_readlane((int)wbase, 63);
         if (c) {
-            u32 slot = lds_fetch_add(&S.misc[17], c);
+            u32 slot = wbase + inc_c - c;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 u32 w = w5[i];
