@@ -1299,6 +1299,12 @@ __global__ __launch_bounds__(256) void zero_regions_kernel(ZeroList z) {
     for (int r = 0; r < 6; ++r) for (u64 i = i0; i < z.n[r]; i += stride) z.p[r][i] = 0;
     if (i0 == 0 && z.set_p) *z.set_p = z.set_v;
 }
+__global__ __launch_bounds__(256) void fill_u64_kernel(u64* __restrict__ p, u64 n, u64 v) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_u64(u64* p, u64 n, u64 v, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)std::min<u64>(1024, (n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
 void launch_zero_regions(const ZeroList& z, hipStream_t s) {
     u64 mx = 1;
     for (int r = 0; r < 6; ++r) mx = z.n[r] > mx ? z.n[r] : mx;

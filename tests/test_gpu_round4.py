@@ -65,3 +65,23 @@ def test_block_cache_keeps_and_releases():
             n = int(m.finalize()["n_nodes"])
     freed = R.api.release_cached_memory()
     assert n > 0 and freed >= (8 << 20) and R.api.release_cached_memory() == 0
+
+
+@pytest.mark.gpu
+def test_nothing_leans_on_zero_filled_allocations():
+    """MDBG_POISON hands every device block out filled with 0xA5.  A batch of empty reads only has no tile, so no gather wrote its reads' offsets: they were what the
+    allocation held — zeros from a fresh hipMalloc, garbage in a process that had freed memory before (found by scratch/fuzz_nodes_edges.py, seeds 70346 / 70670)."""
+    child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import test_gpu_fuzz as F\n"
+             "for s in (70346, 70670, 3, 11): F.test_fuzz_sketch_and_nodes(s)\n"
+             "import numpy as np, rust_mdbg_amd as R\n"
+             "from oracle import oracle as O\n"
+             "with R.Mdbg(5, 10, 0.05, 1) as m:\n"
+             "    b, o = O.concat_reads([b'', b'', b''])\n"
+             "    sk = m.sketch(b, o); assert list(sk['off']) == [0, 0, 0, 0], sk['off']\n"
+             "    m.ingest_reads([b'ACGTTGCA' * 40], 0); m.ingest_reads([b'', b''], 1); m.ingest_reads([b'ACGTTGCA' * 40], 3)\n"
+             "    g = O.Graph(5, 10, 0.05, 1); bb, oo = O.concat_reads([b'ACGTTGCA' * 40, b'', b'', b'ACGTTGCA' * 40]); assert g.ingest(bb, oo) == 0\n"
+             "    got, exp = m.finalize(), g.finalize(with_edges=False)\n"
+             "    assert got['n_nodes'] == exp['n_nodes'] and np.array_equal(got['keys'], exp['keys']) and np.array_equal(got['abundance'], exp['abundance'])\n"
+             "print('POISON_OK')\n") % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=dict(os.environ, MDBG_POISON="1"), timeout=900)
+    assert r.returncode == 0 and "POISON_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
