@@ -197,13 +197,14 @@ template <int NW> struct __attribute__((aligned(16))) TileLds {
 };
 constexpr int T3_WORDS = 2 << (2 * BS_GS);    // exact evaluation: 3-base groups {F, R}, one table per WORKGROUP (every wave writes the same values into it)
 template <int SCHEME, int NW> struct TileLdsS : TileLds<NW> {};
-// syncmers: + a bitmap over DENSE positions (a read starts here), padded to 32 KB: the generic machine of a flagged tile keeps its ring
-// of s-mer hashes (32 x 256 words) on top of the whole structure, which is dead by then
+// syncmers: + a bitmap over DENSE positions (a read starts here).  The generic machine of a flagged tile keeps its ring of s-mer hashes (32 x 128 words: it runs on
+// half of the tile's threads) on top of the structure, which is dead by then — with a ring for all 256 threads the structure had to be padded to 32 KB and only four
+// workgroups fitted a CU
 template <int NW> struct TileLdsS<1, NW> : TileLds<NW> {
     u32 dstart[TG<NW>::RW + 8];
-    u32 pad_to_ring[(32 * TG<NW>::TT * 4 - sizeof(TileLds<NW>) - (TG<NW>::RW + 8) * 4) / 4];
 };
-static_assert(sizeof(TileLdsS<1, 4>) == 32 * TG<4>::TT * 4, "the ring of the generic syncmer machine covers the tile state exactly");
+constexpr int SYNC_SLOW_THREADS = 128;       // threads of a tile that run the generic syncmer machine: their ring (32 x 128 words = 16 KB) lies on top of the tile state, dead by then
+static_assert(sizeof(TileLdsS<1, 4>) >= 32 * SYNC_SLOW_THREADS * 4, "the ring of the generic syncmer machine fits the tile state");
 // FMT_ASCII stages the half planes of its 16-base chunks (2 * RW words, phase 1 only) in memory that is idle then: the part of the dense
 // stream behind the read-start bitmap plus the keep masks (the stream part is zeroed again before phase 2 writes it)
 template <int NW> struct StageAt {
@@ -355,8 +356,8 @@ __device__ inline u32 nt4_code(u8 c) {                         // src/read.rs:23
 
 // dq: per-thread ring of the last <= 32 s-mer hashes (s <= 16: 32 bits), column = thread; sc_tmp: 8 words of scan scratch + 1 flag
 template <bool HPC, class Src>
-__device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[TG<4>::TT], u32* sc_tmp) {
-    constexpr int TT = TG<4>::TT, TILE_STRIDE = TG<4>::STRIDE;      // (the syncmer scheme runs on the 256-lane tiles)
+__device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[SYNC_SLOW_THREADS], u32* sc_tmp) {
+    constexpr int TT = SYNC_SLOW_THREADS, TILE_STRIDE = TG<4>::STRIDE;      // (the syncmer scheme runs on the 256-lane tiles; this machine on the first TT of their threads)
     constexpr u32 SEG = (TILE_STRIDE + TT - 1) / TT;           // raw positions per thread
     u32& any_over = sc_tmp[8];
     const int tid = threadIdx.x;
@@ -369,6 +370,7 @@ __device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, co
     u64 own_lo = t_lo + (u64)tid * SEG, own_hi = own_lo + SEG;      // the tile owns the l-mers whose LAST base (its run start) lies in [t_lo, t_hi)
     if (own_lo < first_base) own_lo = first_base;
     if (own_hi > t_hi) own_hi = t_hi;
+    if (tid >= TT) own_lo = own_hi = t_hi;                           // (the other threads only take part in the scan and the barriers)
     if (tid == 0) any_over = 0;
     __syncthreads();
 
@@ -469,7 +471,7 @@ struct CandOut { u64 hash; u32 pos, read; };
 // WMAX (syncmers): the window w = l - s + 1 itself (1 .. 32): the register window of s-mer hashes and its loops are unrolled over exactly w entries
 // with static register indices
 template <int L, int SCHEME = 0, int WMAX = 1, int NW = 4, int TPW = 1>
-__global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kernel(SketchArgs a) {
+__global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kernel(SketchArgs a) {
     typedef TG<NW> G;
     constexpr int TT = G::TT, RW = G::RW, HW = G::HW, QCAP = G::QCAP, RS_CAP = G::RS_CAP, STAGE_AT = StageAt<NW>::AT;
     static_assert(TPW == 1 || NW == 1, "several tiles per workgroup: wave tiles only (no workgroup barrier inside a tile)");
@@ -666,8 +668,8 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 4 : 6) void sketch_bs_kerne
             if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
             else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) slow_tile<true>(a, src, gt, slab, S); else slow_tile<false>(a, src, gt, slab, S); }
         } else {
-            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); }
-            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[TG<4>::TT])&S, sync_tmp); }
+            if (a.fmt == FMT_ASCII) { AsciiSrc src{a.bases}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[SYNC_SLOW_THREADS])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[SYNC_SLOW_THREADS])&S, sync_tmp); }
+            else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[SYNC_SLOW_THREADS])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[SYNC_SLOW_THREADS])&S, sync_tmp); }
         }
     };
     if (S.misc[8] || (!true_start && Hh < Lr)) { tile_sync<NW>(); run_slow_tile(); return; }
