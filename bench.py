@@ -619,7 +619,9 @@ def main():
                           "bases_per_gpu": n_bases, "batches_per_step": len(batches), "total_bases": total_bases, "input_format": args.input, "plain": bool(args.plain),
                           "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": par,
                           "comm": None if not routed else ("host-staged over gloo: DRY RUN, not RCCL" if host_comm else "rccl")},
-               "roofline": roof, "roofline_ascii": roof_ascii, "ascii_in": ascii_in, "cpu_baseline": cpu,
+               "roofline": roof, "roofline_ascii": roof_ascii, "ascii_in": ascii_in,
+               "value_ascii_in": ascii_in["value"] if ascii_in else None, "ms_per_step_ascii_in": ascii_in["ms_per_step"] if ascii_in else None, "pack_ms": pack_ms,
+               "cpu_baseline": cpu,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
                          "checked_against_recorded_counts": want is not None,
