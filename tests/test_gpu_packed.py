@@ -27,7 +27,7 @@ def test_packed_sketch_random_reads(l, d, hpc):
     reads += [b"", b"A", b"ACGT" * 2, b"", b"C" * 500, rand_reads(5, 1, 200000, 200000)[0], b""]
     sk, st, exp = packed_sketch(reads, l, d, hpc)
     # (the 500-base homopolymer read may sit in front of a tile boundary; wave tiles — MDBG_TILE=1x4 — look back 128 bases and have four times the boundaries)
-    assert exp["err"] == 0 and st["n_slow_tiles"] <= (1 if st["tile_bases"] > 20000 else 8)
+    assert exp["err"] == 0 and st["n_slow_tiles"] <= (1 if st["tile_bases"] > 20000 else 16)
     for f in ("hashes", "pos", "off"):
         assert np.array_equal(sk[f], exp[f]), f
 
