@@ -579,11 +579,15 @@ def main():
             cpu = cpu_baseline(m, d_bases, d_off0, shard_reads, batches[-1][3], args)
         anchor1 = None
         if world == 1 and not routed and not human and not args.plain and not args.no_scale_anchor and (args.genome_mb, args.coverage, args.l, args.density) == (140.0, 50.0, 12, 0.002):
-            anchor1 = scale_anchor_n1(R, torch, np, device_index, args.minabund)
-            w3 = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w.get("workload") == "human" and w["total_bases"] == anchor1["total_bases"]]
-            anchor1["checked_against_recorded_counts"] = bool(w3)
-            if w3 and args.minabund == 2 and any(anchor1["graph"][f] != w3[0]["graph"][f] for f in w3[0]["graph"]):
-                raise SystemExit("bench.py: the graph of the scale anchor %r differs from the recorded one %r: no line printed" % (anchor1["graph"], w3[0]["graph"]))
+            try:
+                anchor1 = scale_anchor_n1(R, torch, np, device_index, args.minabund)
+            except Exception as ex:      # (a side measurement: the headline above it must not be lost to it — e.g. a device shared with somebody else's 200 GB)
+                anchor1 = {"error": repr(ex)[:300]}
+            if "graph" in anchor1:
+                w3 = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w.get("workload") == "human" and w["total_bases"] == anchor1["total_bases"]]
+                anchor1["checked_against_recorded_counts"] = bool(w3)
+                if w3 and args.minabund == 2 and any(anchor1["graph"][f] != w3[0]["graph"][f] for f in w3[0]["graph"]):
+                    raise SystemExit("bench.py: the graph of the scale anchor %r differs from the recorded one %r: no line printed" % (anchor1["graph"], w3[0]["graph"]))
         graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
         want = expected_graph(args, world, shard_reads, total_bases)
         if args.multik:
