@@ -199,6 +199,33 @@ def sq_counters(args):
     return None
 
 
+def issue_roofline(args, roof, n_cus):
+    """The tile kernel's instruction-issue ceiling next to its HBM one: VALU-pipe cycles the launch NEEDS (instruction counts from the SQ counters,
+    split into full-rate and half-rate instructions by the ISA of the hot path, each at its measured issue cost: profiles/isa_issue.py ->
+    profiles/r*_isa_issue.json) over the SIMD cycles it GETS (4 SIMDs x CUs x the live launch duration x 2.4 GHz)."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_issue.json")), reverse=True):
+        try:
+            j = json.load(open(p))
+            c = j["config"]
+            if (c["l"], c["density"], c["input_format"]) != (args.l, args.density, args.input):
+                continue
+            bases = roof["algorithmic_bytes_per_launch"] / roof["algorithmic_bytes_per_base"]
+            need = j["valu_issue_cycles_per_base"] * bases
+            have = 4.0 * n_cus * roof["avg_launch_ms"] * 1e-3 * 2.4e9
+            allinst = j["all_instructions_per_launch"] / c["bases_per_launch"] * bases
+            return {"valu_pipe": need / have, "valu_issue_cycles_needed": need, "simd_cycles_available": have, "clock_ghz": 2.4, "simds": 4 * n_cus,
+                    "valu_instructions_per_launch": j["valu_instructions_per_base"] * bases, "half_rate_share": j["half_rate_share"],
+                    "issue_cycles_full_rate": j["c_full"], "issue_cycles_half_rate": j["c_half"], "avg_issue_cycles_per_valu": j["avg_issue_cycles_per_valu"],
+                    "all_instructions_per_simd_cycle": allinst / have,
+                    "reads_as": "share of the SIMDs' cycles the launch's VALU instructions occupy at their measured issue cost; 1.0 = nothing but fewer or cheaper "
+                                "instructions can make the kernel faster",
+                    "source": os.path.relpath(p, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     """Times the CPU oracle on a bounded prefix of the same reads, one worker per host core."""
     import numpy as np
@@ -220,7 +247,10 @@ def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     t = time.perf_counter()
     solid, wins = O.count_threaded(b1, offs[:r1 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
     dt = time.perf_counter() - t
+    # whole: the sample IS the workload of one step, so its node and window counts are the oracle's answer for the configuration the headline is
+    # measured on (src/main.rs:926-932 prints the same counters) — main() compares them with the GPU's and prints no line when they differ
     return {"value": float(offs[r1]) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "nodes": int(solid), "windows": int(wins), "whole_workload": bool(r1 == n_reads and int(offs[r1]) == int(n_bases)), "matches_gpu": None,
             "sample": "first %d reads (%.3f Gbases) of the same synthetic workload, %d threads, %.1f s; reads in RAM -> filtered node count; "
                       "the port sketches on all threads, deals the canonical k-min-mers into one bucket per thread by key hash and counts "
                       "every bucket on its own thread (no shared map, no serial merge)"
@@ -536,6 +566,7 @@ def main():
             roof["launches_per_step"] = tile_acc["n_sketch_tile_launches"] / max(1, args.steps); roof["launches_timed"] = tile_acc["n_sketch_tile_launches"]
         if roof:
             roof["traffic"], roof["traffic_source"] = pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args)
+            roof["issue"] = issue_roofline(args, roof, torch.cuda.get_device_properties(device_index).multi_processor_count) if packed else None
             sq = sq_counters(args)
             if sq:
                 roof.update(valu_lane_ops_per_base=sq.get("valu_lane_ops_per_base"), wave_time_split=sq.get("wave_time_split"), sq_source=sq.get("source"))
@@ -589,6 +620,12 @@ def main():
                 if w3 and args.minabund == 2 and any(anchor1["graph"][f] != w3[0]["graph"][f] for f in w3[0]["graph"]):
                     raise SystemExit("bench.py: the graph of the scale anchor %r differs from the recorded one %r: no line printed" % (anchor1["graph"], w3[0]["graph"]))
         graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
+        if cpu is not None and cpu.get("whole_workload") and not human and not routed and not args.multik and not os.environ.get("MDBG_STOP_PHASE"):
+            # the oracle has just counted the very reads the timed steps ingested: a full-size parity check of the headline configuration in every run
+            cpu["matches_gpu"] = bool(cpu["nodes"] == graph["nodes"] and cpu["windows"] == graph["windows"])
+            if not cpu["matches_gpu"]:
+                raise SystemExit("bench.py: the oracle counts %d nodes / %d windows on the whole workload, the GPU %d / %d: no line printed"
+                                 % (cpu["nodes"], cpu["windows"], graph["nodes"], graph["windows"]))
         want = expected_graph(args, world, shard_reads, total_bases)
         if args.multik:
             graph["nodes_per_k"] = [list(x) for x in per_k]

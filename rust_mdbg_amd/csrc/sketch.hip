@@ -470,6 +470,14 @@ struct CandOut { u64 hash; u32 pos, read; };
 // comes from the arguments (no bit-sliced filter: phase 3 is the window-minimum machine over the dense stream).
 // WMAX (syncmers): the window w = l - s + 1 itself (1 .. 32): the register window of s-mer hashes and its loops are unrolled over exactly w entries
 // with static register indices
+// MDBG_ISA_PROBE (profiles/isa_issue.py only, never the product build): the run-time conditions that are constant on the benchmark's workload
+// (packed input, interior tile, homopolymer compression, no exception, sparse density) become compile-time constants, so that the ISA of the
+// probe build IS the hot path and its static instruction counts x trip counts can be compared with the SQ counters
+#ifdef MDBG_ISA_PROBE
+#define MDBG_HOT(cond, value) (value)
+#else
+#define MDBG_HOT(cond, value) (cond)
+#endif
 template <int L, int SCHEME = 0, int WMAX = 1, int NW = 4, int TPW = 1>
 __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kernel(SketchArgs a) {
     typedef TG<NW> G;
@@ -485,15 +493,19 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     TileLdsS<SCHEME, NW>& S = S_all[tslot];
     const int64_t nb = (int64_t)a.n_bases;
     const int64_t n_pairs = (nb + 31) >> 5;
-    const bool hpc = a.hpc != 0;
+    const bool hpc = MDBG_HOT(a.hpc != 0, true);
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     const u32 wg = blockIdx.x * TPW + (u32)tslot, gt = a.tile0 + wg;       // the launch's wg-th tile
     if (TPW > 1 && gt >= a.tile_end) return;          // (a whole wave; nothing below waits for it)
     Rec* const slab = a.slab + (size_t)wg * a.slab_cap;
+#ifdef MDBG_ISA_PROBE
+#define MDBG_STAMP(i) asm volatile("s_nop 0 ; MDBG_PHASE_MARK " #i ::: "memory")      // a line the ISA tool can find
+#else
 #define MDBG_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(size_t)gt * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#endif
     MDBG_STAMP(0);
     const int64_t raw0 = (int64_t)gt * G::STRIDE - G::HALO;      // first staged raw position (negative for tile 0)
-    const bool interior = raw0 >= 0 && raw0 + RW * 32 <= nb;
+    const bool interior = MDBG_HOT(raw0 >= 0 && raw0 + RW * 32 <= nb, true);
     const TileRec* const rec = a.recs + gt;
     // (the record is read with vector loads — the compiler cannot prove it read-only —, so what is the same in every lane is moved to scalar
     // registers by hand: the conditions below then branch on SCC instead of travelling through the phases as lane masks)
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     constexpr int CPT = RW * 2 / TT;                  // FMT_ASCII: 16-base chunks per thread
     uint4 av[CPT]; uint2 pr[WPT];
     const int64_t pi0 = raw0 / 32 + (int64_t)WPT * tid;       // FMT_PLANES: my first word pair (raw0 is a multiple of 32, also when negative)
-    if (a.fmt == FMT_ASCII) {
+    if (MDBG_HOT(a.fmt == FMT_ASCII, false)) {
         if (interior) {
             const u32x4* src = (const u32x4*)(a.bases + raw0);
 #pragma unroll
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     }
     if (tid == 0) { S.misc[8] = a.force_slow | ((a.tile_flags && a.tile_flags[gt]) ? 1u : 0u); S.misc[9] = 0; S.misc[11] = 0; S.misc[17] = 0; S.misc[18] = 0; S.misc[19] = 0; S.misc[20] = 0; }
     tile_sync<NW>();
-    if (rh_ - rl < (u32)TREC_N) {                       // the usual case: the read starts come with the tile's record
+    if (MDBG_HOT(rh_ - rl < (u32)TREC_N, true)) {                       // the usual case: the read starts come with the tile's record
         if ((u32)tid <= rh_ - rl) {
             const int64_t rel = tid == 0 ? rec->start0 : (int64_t)rec->rel[tid - 1];
             if (tid == 0) S.rs0 = rel; else S.rs_rel[tid] = (int32_t)rel;
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         if (rel >= 0 && rel < RW * 32) atomicOr(&S.dense[rel >> 5], 0x80000000u >> (rel & 31));
     }
     u32* const stage = S.dense + STAGE_AT;
-    if (a.fmt == FMT_ASCII) {
+    if (MDBG_HOT(a.fmt == FMT_ASCII, false)) {
         u32 bad_any = 0;
         if (interior) {
 #pragma unroll
@@ -591,13 +603,13 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         tile_sync<NW>();
     }
     MDBG_STAMP(1);
-    if (a.stop_phase == 1) { if (tid == 0) a.n_valid[gt] = x0[0] == 0x12345u; return; }
+    if (MDBG_HOT(a.stop_phase == 1, false)) { if (tid == 0) a.n_valid[gt] = x0[0] == 0x12345u; return; }
 
     // ---- phase 2: keep masks, compaction, dense stream ----------------------------------------------------------------
     u32 kw[WPT], n_kept[WPT], mine = 0;
     {
         const int64_t lo = first_base - raw0, hi = nb - raw0;        // existing positions, tile-relative
-        if (interior && lo <= 0 && hpc) {
+        if (MDBG_HOT(interior && lo <= 0 && hpc, true)) {
             // the usual tile (every staged position exists, homopolymer compression on) on a path of its own: decided once, in scalar registers —
             // folded into the general loop below the compiler carried both conditions through every word as lane masks
             const uint4 st = *(const uint4*)(S.dense + WPT * tid);          // read-start bits of my four words
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     }
     tile_sync<NW>();
     MDBG_STAMP(2);
-    if (a.stop_phase == 2) { if (tid == 0) a.n_valid[gt] = 0; return; }
+    if (MDBG_HOT(a.stop_phase == 2, false)) { if (tid == 0) a.n_valid[gt] = 0; return; }
     const u32 Hh = S.misc[11];
     const bool true_start = raw0 <= first_base;       // the stream begins inside this tile: nothing to look back at
     auto run_slow_tile = [&]() {
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
             else { PlaneSrc src{a.planes, a.exc_pos, a.exc_val, a.tile_flags && a.tile_flags[gt] ? a.n_exc : 0u}; if (hpc) sync_slow_tile<true>(a, src, gt, slab, (u32(*)[SYNC_SLOW_THREADS])&S, sync_tmp); else sync_slow_tile<false>(a, src, gt, slab, (u32(*)[SYNC_SLOW_THREADS])&S, sync_tmp); }
         }
     };
-    if (S.misc[8] || (!true_start && Hh < Lr)) { tile_sync<NW>(); run_slow_tile(); return; }
+    if (MDBG_HOT(S.misc[8] || (!true_start && Hh < Lr), false)) { tile_sync<NW>(); run_slow_tile(); return; }
 
     // ---- phase 3: bit-sliced filter over the dense stream -> candidate bitmap + (unordered) candidate list ---------------
     // candidate plane coordinate x = e + BS_B - 1; owned END positions e in [max(Hh, L-1), H)
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
 #pragma unroll
         for (int i = 0; i < BS_B; ++i) bmask[i] = ((a.btop >> (BS_B - 1 - i)) & 1u) ? 0xFFFFFFFFu : 0u;
         const u32 n_steps = (n_out + 62) / 63;
-        const bool zero_test = a.btop == 0;                          // density < 2^-BS_B: "all evaluated hash bits are zero"
+        const bool zero_test = MDBG_HOT(a.btop == 0, true);                          // density < 2^-BS_B: "all evaluated hash bits are zero"
         const u32 wv_s = (u32)__builtin_amdgcn_readfirstlane(wv);    // the step index lives in scalar registers
         const int nb_addr = 4 * ((lane + 63) & 63);                  // ds_bpermute address of the lane in front
         // first / last candidate-plane position that is owned: words wholly inside [x_lo, x_hi) need no mask
@@ -854,7 +866,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     }
     tile_sync<NW>();
     MDBG_STAMP(3);
-    if (a.stop_phase == 3) { if (tid == 0) a.n_valid[gt] = 0; return; }
+    if (MDBG_HOT(a.stop_phase == 3, false)) { if (tid == 0) a.n_valid[gt] = 0; return; }
 
     // ---- phase 4: exact evaluation, ranks, records -------------------------------------------------------------------
     auto count_words = [&]() -> u32 {                                 // cpre[] <- exclusive counts of the bitmap per word; returns the total
@@ -909,7 +921,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         const u32 sd = e - (Lr - 1);
         const int64_t rel_start = dense_to_raw(sd);
         u32 r; int64_t q0, q1;                                         // the read holding the first base; q0: its start, q1: the next read's, tile-relative
-        if (n_rs <= RS_CAP) {
+        if (MDBG_HOT(n_rs <= RS_CAP, true)) {
             u32 i = 0;
             while (i + 1 < n_rs && (int64_t)S.rs_rel[i + 1] <= rel_start) ++i;
             r = rl + i; q0 = i ? (int64_t)S.rs_rel[i] : S.rs0; q1 = i + 1 < n_rs ? (int64_t)S.rs_rel[i + 1] : (int64_t)RW * 32;
@@ -984,7 +996,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     };
 
     const u32 n_cand = S.misc[17];
-    if (n_cand <= QCAP) {
+    if (MDBG_HOT(n_cand <= QCAP, true)) {
         // every candidate sits in the (unordered) list of phase 3
         const u32 nv = n_cand ? process_list(n_cand) : 0;
         if (tid == 0) { put_count(a, gt, nv, true); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; } }

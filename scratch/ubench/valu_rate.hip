@@ -6,6 +6,7 @@
 #include <vector>
 #include <string>
 #include <cstdlib>
+#include <cstring>
 
 #ifndef NCHAIN
 #define NCHAIN 8
@@ -106,7 +107,9 @@ int main() {
     const int iters = 200;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("CUs %d clock %.0f MHz\n", cus, clk / 1e6);
+    const char* only = getenv("ONLY");
     for (auto& k : ks) {
+        if (only && !strstr(only, k.name)) continue;
         hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d, 1u, 10);
         hipDeviceSynchronize();
         hipEventRecord(e0);

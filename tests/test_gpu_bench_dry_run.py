@@ -44,6 +44,16 @@ def test_bench_default_line_carries_the_ascii_leg():
 
 
 @pytest.mark.gpu
+def test_bench_cpu_leg_checks_the_whole_workload_against_the_oracle():
+    """when the CPU sample is the whole workload (a small genome here; configs[2] in the driver's run) the line carries the oracle's node and
+    window counts of that very workload and has been refused unless the GPU's are the same (src/main.rs:926-932 prints the same counters)"""
+    j = _bench("--gpus", "1", "--genome-mb", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "60", "--no-scale-anchor")
+    c = j["cpu_baseline"]
+    assert c["whole_workload"] is True and c["matches_gpu"] is True
+    assert c["nodes"] == j["graph"]["nodes"] > 1000 and c["windows"] == j["graph"]["windows"] > 1000
+
+
+@pytest.mark.gpu
 def test_bench_multik_sweep_one_rank_and_two_ranks_agree():
     """configs[4]: sketched once, one graph per k from the resident sketches; at N>1 the ranks keep whole sketches, so no k needs a new exchange"""
     small = ["--workload", "human", "--multik", "--genome-mb", "40", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0"]
