@@ -205,10 +205,15 @@ int mdbg_get_stats(mdbg_ctx* ctx, mdbg_stats* out);
 const char* mdbg_strerror(int err);
 const char* mdbg_last_error(mdbg_ctx* ctx); /* detail of the last failure on ctx ("" if none) */
 uint32_t mdbg_abi_version(void);
+/* how the library was compiled: bit 0 = the wave-tile kernels of the round-4 experiment are in it (-DMDBG_WAVE_TILES; the default build has ONE tile shape
+ * and ignores MDBG_TILE) */
+uint32_t mdbg_build_flags(void);
 /* Device memory that contexts of this process have released is kept by the library for the next allocation (a hipMalloc that follows large
- * frees takes seconds on this stack); at most MDBG_CACHE_MB megabytes (environment; default a third of the device, 0 = keep nothing).
- * This hands all of it back to the runtime and returns the number of bytes released.  Never needed for correctness: an allocation that
- * runs out of memory empties the cache itself before it fails. */
+ * frees takes seconds on this stack); at most MDBG_CACHE_MB megabytes per device (environment; default a third of each device, 0 = keep nothing).
+ * This hands all of it back to the runtime and returns the number of bytes released.  Never needed for the correctness of THIS library's calls: one of
+ * its allocations that runs out of memory empties the cache itself before it fails.  Another allocator in the same process (torch's caching allocator,
+ * RCCL, the host's own hipMalloc) does not know about the cached blocks and can run out of memory against them: such a host calls this after it has
+ * destroyed its contexts (or before a large allocation of its own), or caps the cache with MDBG_CACHE_MB. */
 uint64_t mdbg_release_cached_memory(void);
 
 /* ---- device-resident stage entry points (used by the multi-GPU driver and the benchmark) -------------

@@ -76,7 +76,7 @@ class SynthParams(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
-EXPORTS = ["mdbg_abi_version", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
+EXPORTS = ["mdbg_abi_version", "mdbg_build_flags", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
@@ -109,6 +109,7 @@ def load_library():
     L = C.CDLL(p)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.mdbg_abi_version.restype = u32
+    L.mdbg_build_flags.restype = u32
     L.mdbg_release_cached_memory.restype = u64
     L.mdbg_create.restype = vp
     L.mdbg_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_int)]

@@ -1,14 +1,17 @@
 // gz_inflate.h — gzip input for the host reader (include/mdbg_emit.h: mdbg_reader_*), without zlib's inflate.
 //
-// What it replaces: the reference reads ".gz" input through flate2's MultiGzDecoder on one thread (src/main.rs:170-177: concatenated
-// members, CRC checked); zlib's gzread did the same here at ~0.2 GB/s of text per thread, which made the inflate the bound of any run
+// What it replaces: the reference reads ".gz" input through flate2's read::GzDecoder on one thread (src/main.rs:34,173: it decodes the FIRST
+// member, checks its CRC and silently ignores whatever follows — so a bgzip'ed or concatenated file loses every read behind its first member there).
+// This reader decodes EVERY member (what `zcat` prints; a deliberate superset); zlib's gzread did the same here at ~0.2 GB/s of text per thread, which made the inflate the bound of any run
 // that starts from a compressed file.  This decoder (RFC 1951 / 1952, written against the RFCs) keeps a 64-bit bit buffer that is
 // refilled without a branch, resolves a literal / length code with ONE lookup in an 11-bit table (longer codes: a second lookup in a
 // subtable), copies matches eight bytes at a time, and checks bounds once per iteration instead of once per byte (a careful per-byte
 // loop takes over near the ends of the input and of the output window).  The CRC-32 of every member is verified (carry-less multiply
 // where the CPU has it).  BGZF files (bgzip: every member is an independent block of at most 64 KiB that carries its compressed size
-// in an extra field) are inflated by several threads at once; so is an ORDINARY gzip stream of some size, which has no such entry
-// points: pieces of it are entered at block headers found by search and decoded without their history (SpecChunk / GzIn::produce_spec).
+// in an extra field) are inflated by several threads at once.  An ORDINARY gzip stream has no such entry points and stays on one thread: rounds 3 - 4 carried
+// a speculative several-thread decoder for it (pieces entered at block headers found by search, decoded without their history: the pugz / rapidgzip scheme);
+// on the GPU box's host it delivered 520 - 550 MB/s of text with 4 - 32 threads against 633 MB/s on ONE (profiles/r04_a_host_reader_gz.txt), it was switched
+// off, and round 5 removed it (git history: gz_inflate.h of round 4).  bgzip is the parallel format.
 //
 // The compressed file is mapped, so the decoder never runs out of input in the middle of a symbol; output is produced in chunks into
 // a window that keeps the last 32 KiB as history.  Untrusted input: every table index is masked, every distance is checked against the
@@ -49,7 +52,6 @@ template <class T> struct NoInit : std::allocator<T> {
     template <class U, class... A> void construct(U* p, A&&... a) { if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...); }
 };
 typedef std::vector<u8, NoInit<u8>> Bytes;
-typedef std::vector<u16, NoInit<u16>> Syms;
 
 // ---- CRC-32 (IEEE 802.3, reflected; RFC 1952 section 8) -----------------------------------------------------------------------
 struct CrcTables {
@@ -141,22 +143,6 @@ inline u32 e_extra(u32 e) { return e >> 24 & 31; }
 constexpr int LIT_BITS = 11, DIST_BITS = 8;
 constexpr int LIT_TAB = (1 << LIT_BITS) + 288 * 16, DIST_TAB = (1 << DIST_BITS) + 32 * 128;
 
-// does a dynamic-Huffman block that is not the stream's last one start at this bit?  (13 header bits, then a COMPLETE code for the code lengths: about one
-// position in a few hundred passes; used by the search for entry points into a stream, see SpecChunk)
-inline bool plausible_dynamic_header(const u8* in, size_t n, size_t bit) {
-    const size_t byte = bit >> 3;
-    if (byte + 16 > n) return false;
-    u64 w0, w1; memcpy(&w0, in + byte, 8); memcpy(&w1, in + byte + 8, 8);
-    const unsigned sh = (unsigned)(bit & 7);
-    const unsigned __int128 v = ((unsigned __int128)w1 << 64 | w0) >> sh;          // >= 120 bits from `bit` on
-    const u32 h = (u32)v;
-    if ((h & 7) != 4) return false;                                             // not the final block, dynamic Huffman codes
-    if ((h >> 3 & 31) > 29 || (h >> 8 & 31) > 29) return false;
-    const u32 hclen = (h >> 13 & 15) + 4;
-    u32 kraft = 0;
-    for (u32 i = 0; i < hclen; ++i) { const u32 l = (u32)(v >> (17 + 3 * i)) & 7; if (l) kraft += 128u >> l; }
-    return kraft == 128;
-}
 struct Inflater {
     // input (whole stream in memory)
     const u8* in = nullptr; size_t in_n = 0, ip = 0;
@@ -169,10 +155,7 @@ struct Inflater {
     u32 lit[LIT_TAB], dist[DIST_TAB];
     const char* err = nullptr;
 
-    size_t stop_bit = ~(size_t)0; bool stopped = false;      // run / run_spec return in front of the first header of a dynamic block at or behind this bit of the stream
-    void start(const u8* p, size_t n, size_t at) { in = p; in_n = n; ip = at; bb = 0; bc = 0; st = HEADER; last = false; stored_left = 0; pend_len = pend_dist = 0; pend_lit = pend_nlit = 0; err = nullptr; stop_bit = ~(size_t)0; stopped = false; }
-    // ... at a bit position (a block header in the middle of a stream)
-    void start_bits(const u8* p, size_t n, size_t bit) { start(p, n, bit >> 3); if (ip < in_n) { bb = (u64)in[ip] >> (bit & 7); bc = 8 - (u32)(bit & 7); ++ip; } }
+    void start(const u8* p, size_t n, size_t at) { in = p; in_n = n; ip = at; bb = 0; bc = 0; st = HEADER; last = false; stored_left = 0; pend_len = pend_dist = 0; pend_lit = pend_nlit = 0; err = nullptr; }
     size_t bitpos() const { return ip * 8 - bc; }               // of the next unread bit (bytes the fast path holds above bc are not counted in ip)
     bool fail(const char* m) { err = m; return false; }
 
@@ -353,7 +336,6 @@ struct Inflater {
             }
             if (st == END) { op_io = op; return true; }
             if (st == HEADER) {
-                if (bitpos() >= stop_bit && plausible_dynamic_header(in, in_n, bitpos())) { stopped = true; op_io = op; return true; }      // (only where the search of the next piece can find it)
                 if (!block_header()) return false;
                 continue;
             }
@@ -459,124 +441,6 @@ struct Inflater {
         }
     }
 
-    // The same stream decoded WITHOUT its history (a block found in the middle of a gzip file, see SpecChunk): 16-bit symbols, a byte or
-    // 256 + i for "byte i of the 32 KiB in front of this piece" — copies carry such markers along.  One table entry at a time.  Returns
-    // true when: the room is nearly used up (op > out_end - 512: call again with more), the final block has ended (st == END), the stop bit
-    // was reached in front of a block header (stopped), or the last 32 KiB hold no marker (*clean: the caller goes on with run() on bytes).
-    // last_marker = index behind the last marker written (in / out).
-    GZ_CLONES
-    bool run_spec(u16* out, size_t& op_io, size_t out_end, size_t& last_marker, bool& clean) {
-        size_t op = op_io;
-        constexpr u32 LM = (1u << LIT_BITS) - 1, DM = (1u << DIST_BITS) - 1;
-        clean = false;
-        for (;;) {
-            if (st == END) { op_io = op; return true; }
-            if (op >= 32768 && op - last_marker >= 32768) { clean = true; op_io = op; return true; }
-            if (st == HEADER) {
-                if (bitpos() >= stop_bit && plausible_dynamic_header(in, in_n, bitpos())) { stopped = true; op_io = op; return true; }      // (only where the search of the next piece can find it)
-                if (!block_header()) return false;
-                continue;
-            }
-            if (op + 512 > out_end) { op_io = op; return true; }
-            if (st == STORED) {
-                const size_t n = std::min<size_t>(std::min<size_t>(stored_left, out_end - op), in_n - ip);
-                for (size_t k = 0; k < n; ++k) out[op + k] = in[ip + k];
-                op += n; ip += n; stored_left -= (u32)n;
-                if (stored_left) { if (ip >= in_n) return fail("truncated stored block"); op_io = op; return true; }
-                st = last ? END : HEADER;
-                continue;
-            }
-            bool eob = false;
-            // fast loop (as in run(), on 16-bit symbols): away from the end of the input, room for three literals and the longest match
-            if (in_n >= 32) {
-                const size_t in_fast = in_n - 32;
-                u64 b = bb; u32 c = bc; size_t i = ip;
-#define GZ_REFILL() do { u64 w_; memcpy(&w_, in + i, 8); b |= w_ << c; i += (63 - c) >> 3; c |= 56; } while (0)
-#define GZ_LOOKUP(e) do { e = lit[b & LM]; if ((e & 0xF0) == (K_SUB << 4)) { b >>= LIT_BITS; c -= LIT_BITS; e = lit[e_value(e) + (b & ((1u << e_extra(e)) - 1))]; } b >>= e & 15; c -= e & 15; } while (0)
-#define GZ_PUT(e) do { out[op] = (u16)(e >> 8 & 0xFF); out[op + 1] = (u16)(e >> 16 & 0xFF); out[op + 2] = (u16)(e >> 24); op += e >> 4 & 3; } while (0)
-                while (i <= in_fast && op + 512 <= out_end && !(op >= 32768 && op - last_marker >= 32768)) {
-                    GZ_REFILL();
-                    u32 e;
-                    GZ_LOOKUP(e);
-                    if (e & LITF) {
-                        GZ_PUT(e);
-                        GZ_LOOKUP(e);
-                        if (e & LITF) {
-                            GZ_PUT(e);
-                            GZ_LOOKUP(e);
-                            if (e & LITF) { GZ_PUT(e); continue; }
-                        }
-                        GZ_REFILL();
-                    }
-                    const u32 kind = e >> 4 & 7;
-                    if (kind != K_BASE) { if (kind == K_EOB) { eob = true; break; } bb = b; bc = c; ip = i; return fail("invalid literal / length code"); }
-                    const u32 xb = e_extra(e);
-                    const u32 len = e_value(e) + (u32)(b & ((1u << xb) - 1));
-                    b >>= xb; c -= xb;
-                    u32 d = dist[b & DM];
-                    if ((d & 0xF0) == (K_SUB << 4)) { b >>= DIST_BITS; c -= DIST_BITS; d = dist[e_value(d) + (b & ((1u << e_extra(d)) - 1))]; }
-                    b >>= d & 15; c -= d & 15;
-                    if ((d >> 4 & 15) != K_BASE) { bb = b; bc = c; ip = i; return fail("invalid distance code"); }
-                    const u32 db = e_extra(d);
-                    const size_t dd = e_value(d) + (size_t)(b & ((1u << db) - 1));
-                    b >>= db; c -= db;
-                    if (dd > op + 32768) { bb = b; bc = c; ip = i; return fail("distance reaches in front of the data"); }
-                    if (dd <= op && dd >= 4) {                          // inside the piece: four symbols at a time (up to three too many: room is there); a marker among them marks the whole match
-                        u16* dst = out + op; const u16* src = dst - dd;
-                        u64 any = 0;
-                        for (u32 k = 0; k < len; k += 4) { u64 w; memcpy(&w, src + k, 8); memcpy(dst + k, &w, 8); any |= w; }
-                        op += len;
-                        if (any & 0xFF00FF00FF00FF00ull) last_marker = op;
-                    } else {
-                        for (u32 k = 0; k < len; ++k, ++op) {
-                            if (dd <= op) { const u16 v = out[op - dd]; out[op] = v; if (v >= 256) last_marker = op + 1; }
-                            else { out[op] = (u16)(256 + 32768 - (dd - op)); last_marker = op + 1; }
-                        }
-                    }
-                }
-#undef GZ_REFILL
-#undef GZ_LOOKUP
-#undef GZ_PUT
-                bb = b; bc = c; ip = i;
-            }
-            normalize();
-            while (!eob && op + 512 <= out_end) {
-                if (op >= 32768 && op - last_marker >= 32768) break;
-                if (ip + 40 <= in_n) break;                             // (the fast loop goes on: it only left for room or for a clean window)
-                need(32);
-                u32 e = lit[bb & LM];
-                u32 used = 0;
-                if ((e & 0xF0) == (K_SUB << 4)) { used = LIT_BITS; e = lit[e_value(e) + ((bb >> LIT_BITS) & ((1u << e_extra(e)) - 1))]; }
-                used += e & 15;
-                const u32 kind = e_kind(e);
-                if (kind == K_BAD || kind == K_SUB) return fail(used > bc ? "truncated deflate stream" : "invalid literal / length code");
-                if (used > bc) return fail("truncated deflate stream");
-                take(used);
-                if (kind == K_LIT) { u32 n = e >> 4 & 3, v = e >> 8; while (n--) { out[op++] = (u16)(v & 0xFF); v >>= 8; } continue; }
-                if (kind == K_EOB) { eob = true; break; }
-                const u32 xb = e_extra(e);
-                if (!need(xb)) return fail("truncated deflate stream");
-                const u32 len = e_value(e) + take(xb);
-                need(32);
-                u32 d = dist[bb & DM];
-                used = 0;
-                if ((d & 0xF0) == (K_SUB << 4)) { used = DIST_BITS; d = dist[e_value(d) + ((bb >> DIST_BITS) & ((1u << e_extra(d)) - 1))]; }
-                used += d & 15;
-                if ((d >> 4 & 15) != K_BASE) return fail(used > bc ? "truncated deflate stream" : "invalid distance code");
-                if (used > bc) return fail("truncated deflate stream");
-                take(used);
-                const u32 db = e_extra(d);
-                if (!need(db)) return fail("truncated deflate stream");
-                const size_t dd = e_value(d) + take(db);
-                if (dd > op + 32768) return fail("distance reaches in front of the data");
-                for (u32 k = 0; k < len; ++k, ++op) {
-                    if (dd <= op) { const u16 v = out[op - dd]; out[op] = v; if (v >= 256) last_marker = op + 1; }
-                    else { out[op] = (u16)(256 + 32768 - (dd - op)); last_marker = op + 1; }
-                }
-            }
-            if (eob) st = last ? END : HEADER;
-        }
-    }
 };
 
 // ---- gzip members over a mapped file ----------------------------------------------------------------------------------------------
@@ -611,54 +475,6 @@ inline bool parse_header(const u8* p, size_t n, size_t at, Member& m) {
     return true;
 }
 
-// ---- an ordinary gzip stream on several threads ---------------------------------------------------------------------------------------
-// One deflate stream has no entry points, but it has block headers, and a dynamic block's header is recognisable: a piece of the file is
-// searched bit by bit for something that parses as one (13 header bits, then a COMPLETE code for the code lengths: one position in a few
-// hundred survives that, the table build and the decoding of the blocks behind it weed out the rest), and the stream is decoded from
-// there without its history: references into the unknown 32 KiB become markers (Inflater::run_spec) until 32 KiB without one have gone by,
-// from where the ordinary byte decoder takes over.  Pieces are accepted IN ORDER and only if the piece in front — decoded exactly — ended at
-// the very bit this one started at, so what the search guessed never decides what comes out; markers are then replaced from the 32 KiB in
-// front.  (The scheme of pugz / rapidgzip, written from the idea.)
-struct SpecChunk {
-    size_t start_bit = 0, end_bit = 0; bool found = false, hit_end = false, gave_up = false;
-    size_t sym_cap = 32u << 20, byte_cap = 256u << 20;        // a piece that needs more is left to the sequential decoder (very compressible data): set by the caller
-    Syms sym; size_t nsym = 0;                        // decoded without history: bytes and markers
-    Bytes bytes; size_t nbytes = 0;
-    Bytes res;                                        // sym[0, nsym) as bytes, once the 32 KiB in front are known (GzIn::produce_spec)         // ... and from where no marker can be referred to any more: [0, 32768) repeats the end of sym
-    // the first block at or behind from_bit (searched up to limit_bit) from which the stream decodes up to the first block boundary at or behind stop_bit
-    void decode(const u8* in, size_t n, size_t from_bit, size_t limit_bit, size_t stop_bit, Inflater& f) {
-        found = false; gave_up = false;
-        for (size_t pos = from_bit; pos < limit_bit && !gave_up; ++pos) {
-            if (!plausible_dynamic_header(in, n, pos)) continue;
-            if (attempt(in, n, pos, stop_bit, f)) { found = true; start_bit = pos; return; }
-        }
-    }
-    bool attempt(const u8* in, size_t n, size_t pos, size_t stop_bit, Inflater& f) {
-        f.start_bits(in, n, pos); f.stop_bit = stop_bit;
-        hit_end = false; nsym = nbytes = 0;
-        if (sym.size() < (1u << 18)) sym.resize(1u << 18);
-        size_t last_marker = 0; bool clean = false;
-        for (;;) {
-            if (!f.run_spec(sym.data(), nsym, sym.size(), last_marker, clean)) return false;
-            if (f.st == Inflater::END) { hit_end = true; end_bit = f.bitpos(); return true; }
-            if (f.stopped) { end_bit = f.bitpos(); return true; }
-            if (clean) break;
-            if (sym.size() >= sym_cap) { gave_up = true; return false; }        // markers all the way: not worth it (the sequential decoder takes the piece)
-            sym.resize(sym.size() * 2);
-        }
-        if (bytes.size() < (4u << 20)) bytes.resize(4u << 20);
-        for (size_t i = 0; i < 32768; ++i) bytes[i] = (u8)sym[nsym - 32768 + i];
-        nbytes = 32768;
-        for (;;) {
-            if (!f.run(bytes.data(), 0, nbytes, bytes.size() - 16)) return false;
-            if (f.st == Inflater::END && !f.pend_len && !f.pend_nlit) { hit_end = true; end_bit = f.bitpos(); return true; }
-            if (f.stopped) { end_bit = f.bitpos(); return true; }
-            if (bytes.size() >= byte_cap) { gave_up = true; return false; }
-            bytes.resize(bytes.size() * 2);
-        }
-    }
-};
-
 // Streaming reader of a mapped gzip file: read() like gzread.  With threads > 1 and a BGZF file, groups of blocks are inflated in parallel.
 struct GzIn {
     const u8* in = nullptr; size_t n = 0, at = 0;                      // mapped file; at = next member header (between members)
@@ -677,13 +493,13 @@ struct GzIn {
         is_bgzf = parse_header(in, n, 0, m) && m.bgzf;
         inf = new Inflater();
         win.resize(HIST + CHUNK + 64);
-        if (const char* e = getenv("MDBG_GZ_PIECE")) { const long v = atol(e); if (v >= 1024) SPEC_C = (size_t)v; }      // small pieces: the piecewise path on small test files
     }
     bool fail(const char* m) { bad = true; err = m; return false; }
 
     // next member at `at`, or the end of the data.  Behind a complete member only zero bytes (block padding of tapes and some archivers) end the data
-    // quietly; anything else that is not a member is an error, as with the reference's MultiGzDecoder (flate2: "invalid gzip header", src/main.rs:170-177)
-    // — zlib's gzread would stop there without a word and the reads behind a damaged magic would be lost with MDBG_OK.
+    // quietly; anything else that is not a member is an error.  This is deliberately STRICTER than the reference: its flate2 read::GzDecoder
+    // (src/main.rs:34,173) stops after the first member and never looks at the rest, and zlib's gzread would stop at the damage without a word —
+    // either way the reads behind a damaged magic would be lost with MDBG_OK.  (flate2's MultiGzDecoder reports "invalid gzip header" here.)
     bool begin_member() {
         Member m;
         if (at >= n) { done = true; return false; }
@@ -696,14 +512,6 @@ struct GzIn {
         inf->start(in, n, m.data);
         in_member = true; crc = 0; produced = 0;
         lo = wr;                                                       // a member has no history
-        cur_bit = m.data * 8;
-        // An ordinary stream on several threads (produce_spec) is OFF unless MDBG_GZ_SPEC is set: measured on the GPU box's host (256 cores,
-        // profiles/r04_a_host_reader_gz.txt) it delivers 520 - 550 MB/s of text with 4 - 32 threads against 633 MB/s on ONE — the pieces decoded without
-        // history cost twice their sequential time and the marker replacement and the serial acceptance eat the rest.  BGZF is the parallel format.
-        const bool spec_env = getenv("MDBG_GZ_SPEC") != nullptr || getenv("MDBG_GZ_PIECE") != nullptr;      // (per member: cheap, and the test hook may be set late)
-        spec_on = spec_env && threads >= SPEC_MIN_THREADS && !m.bgzf && n - m.data >= 4 * SPEC_C;
-        st_member_rounds = 0;
-        if (spec_on && spec_skip) { --spec_skip; spec_on = false; }    // (a file of many small members: their pieces would be searched in vain)
         return true;
     }
     bool end_member() {
@@ -725,24 +533,11 @@ struct GzIn {
         lo = 0; rd = wr = keep;
     }
     bool produce() {
-        if (rd != wr || seg_i < segs.size()) return true;
-        if (!segs.empty()) {                                            // a round's segments have been read: their end is the history now
-            segs.clear(); seg_i = 0;
-            memcpy(win.data(), tail.data(), tail.size());
-            lo = 0; rd = wr = tail.size();
-        }
-        if (wr > HIST || (spec_on && in_member)) slide();
-        if (spec_on && in_member) {
-            const int r = produce_spec();
-            if (r < 0) return false;
-            if (r == 1) return true;
-            if (r == 2) return produce();                               // the member ended without a byte
-            spec_on = false;                                            // r == 0: the sequential decoder goes on at cur_bit, the history is in place
-            inf->start_bits(in, n, cur_bit);
-        }
+        if (rd != wr) return true;
+        if (wr > HIST) slide();
         if (is_bgzf && threads > 1 && !in_member) return produce_bgzf();
         for (;;) {
-            if (!in_member) { if (!begin_member()) return false; if (spec_on) return produce(); }
+            if (!in_member && !begin_member()) return false;
             size_t op = wr;
             if (!inf->run(win.data(), lo, op, HIST + CHUNK)) return fail(inf->err);
             if (op > wr) { crc = crc32(crc, win.data() + wr, op - wr); produced += op - wr; }
@@ -752,116 +547,6 @@ struct GzIn {
             if (got) return true;
             if (in_member) return fail("deflate stream made no progress");      // (chunk room is never zero here)
         }
-    }
-    // One round of an ordinary stream on `threads` threads (SpecChunk): pieces of SPEC_C compressed bytes; the first is decoded exactly into the
-    // window (behind the history), the others without history into buffers of their own; then the pieces are accepted in order, each only if
-    // the one in front ended at the bit it started at, and copied behind each other with their markers replaced.
-    // 1: bytes produced; 2: none, but the member has ended; 0: not worth a round (or the last one found nothing): sequential from cur_bit; -1: error
-    size_t SPEC_C = 1u << 20;                                          // smallest piece (compressed bytes); pieces grow with what is left, up to 8x (MDBG_GZ_PIECE: test hook)
-    static constexpr int SPEC_MIN_THREADS = 3;                          // (a piece decoded without history costs about twice its sequential time)
-    bool spec_on = false, spec_quit = false; size_t cur_bit = 0;
-    u64 st_rounds = 0, st_pieces = 0, st_offered = 0;                   // rounds, pieces accepted / started (statistics)
-    struct Seg { const u8* p; size_t n; };
-    std::vector<Seg> segs; size_t seg_i = 0, seg_rd = 0;               // output of a round behind win[rd, wr): the pieces' own buffers, in order
-    Bytes tail;                                                         // its last 32 KiB
-    u32 st_member_rounds = 0, spec_skip = 0;                            // rounds of this member so far; members to read sequentially before the next try
-    std::vector<SpecChunk> chunks;
-    int produce_spec() {
-        const size_t cur_byte = cur_bit >> 3;
-        const int T = threads;
-        if (spec_quit || n < cur_byte + 3 * SPEC_C + 8) { spec_quit = false; return 0; }
-        // the first piece is decoded exactly and fast: it gets a share and a half
-        const size_t left = n - 8 - cur_byte;
-        const size_t C = std::min<size_t>(8 * SPEC_C, std::max<size_t>(SPEC_C, left / (2 * (size_t)T + 1)));
-        if ((int)chunks.size() < T) chunks.resize((size_t)T);
-        for (SpecChunk& c : chunks) { c.byte_cap = 16 * C; c.sym_cap = 4 * C; }      // 16x expansion at most (FASTQ: ~4x); what is more compressible than that is read sequentially
-        while ((int)pool.size() < T) pool.push_back(new Inflater());
-        auto lim = [&](int k) { return std::min(cur_byte + (k ? C / 2 + (size_t)k * C : 0), n - 8) * 8; };
-        const size_t h = wr;                                            // history in win[0, h)
-        size_t op0 = h; size_t end0 = 0; bool hit_end0 = false; const char* err0 = nullptr; u32 crc0 = 0;
-        auto first = [&]() {
-            Inflater& f = *pool[0];
-            f.start_bits(in, n, cur_bit); f.stop_bit = lim(1);
-            for (;;) {
-                if (win.size() < op0 + (1u << 20)) win.resize(std::max(win.size() * 2, op0 + (4u << 20)));
-                if (!f.run(win.data(), 0, op0, win.size() - 16)) { err0 = f.err; return; }
-                if (f.st == Inflater::END && !f.pend_len && !f.pend_nlit) { hit_end0 = true; break; }
-                if (f.stopped) break;
-                if (op0 - h > 24 * C) f.stop_bit = 0;              // very compressible data: stop at the next block (the other pieces will not fit: sequential from there)
-            }
-            end0 = f.bitpos();
-            crc0 = crc32(0, win.data() + h, op0 - h);
-        };
-        {
-            std::vector<std::thread> th;
-            for (int k = 1; k < T; ++k) th.emplace_back([&, k]() { chunks[(size_t)k].decode(in, n, lim(k), lim(k + 1), lim(k + 1), *pool[(size_t)k]); });
-            first();
-            for (auto& x : th) x.join();
-        }
-        if (err0) { fail(err0); return -1; }
-        // which pieces follow each other.  Their bytes are NOT copied behind the first piece: read() takes them where they are (segs) — only the symbols of a
-        // piece's first part are turned into bytes (res), with the 32 KiB in front of the piece
-        struct Place { size_t len; const u8* window; u32 crc; };
-        std::vector<Place> place((size_t)T);
-        size_t end = end0, w = op0, total = op0 - h; bool ended = hit_end0; int accepted = 1;
-        for (int k = 1; k < T && !ended; ++k) {
-            SpecChunk& c = chunks[(size_t)k];
-            if (!c.found || c.start_bit != end) break;
-            // the 32 KiB in front of the piece: the end of the first piece (in the window) or the marker-free end of the piece before
-            const u8* window = nullptr;
-            if (k == 1) { if (w >= 32768) window = win.data() + w - 32768; }
-            else { const SpecChunk& p = chunks[(size_t)k - 1]; if (p.nbytes >= 65536) window = p.bytes.data() + p.nbytes - 32768; }
-            if (!window && c.nsym) break;                               // rare (a piece of markers only, or a member's first 32 KiB): the next round starts here
-            const size_t more = c.nsym + (c.nbytes > 32768 ? c.nbytes - 32768 : 0);
-            place[(size_t)k] = Place{more, window, 0};
-            total += more; end = c.end_bit; ended = c.hit_end; ++accepted;
-        }
-        auto settle = [&](int k) {                                      // markers replaced, CRC of the piece
-            SpecChunk& c = chunks[(size_t)k]; Place& pl = place[(size_t)k];
-            if (c.res.size() < c.nsym) c.res.resize(c.nsym + c.nsym / 8);
-            u8* o = c.res.data();
-            for (size_t i = 0; i < c.nsym; ++i) { const u16 v = c.sym[i]; o[i] = v < 256 ? (u8)v : pl.window[v - 256]; }
-            pl.crc = crc32(0, o, c.nsym);
-            if (c.nbytes > 32768) pl.crc = crc32(pl.crc, c.bytes.data() + 32768, c.nbytes - 32768);
-        };
-        if (accepted > 1) {
-            std::vector<std::thread> th;
-            for (int k = 2; k < accepted; ++k) th.emplace_back(settle, k);
-            settle(1);
-            for (auto& x : th) x.join();
-        }
-        segs.clear(); seg_i = 0; seg_rd = 0;
-        for (int k = 1; k < accepted; ++k) {
-            const SpecChunk& c = chunks[(size_t)k];
-            if (c.nsym) segs.push_back(Seg{c.res.data(), c.nsym});
-            if (c.nbytes > 32768) segs.push_back(Seg{c.bytes.data() + 32768, c.nbytes - 32768});
-        }
-        // the last 32 KiB of the round (history of what follows), gathered from the back: put in front of the window when the segments have been read
-        tail.clear();
-        if (!segs.empty()) {
-            size_t need = HIST; std::vector<Seg> back;
-            for (size_t i = segs.size(); i-- > 0 && need;) { const size_t t = std::min(need, segs[i].n); back.push_back(Seg{segs[i].p + segs[i].n - t, t}); need -= t; }
-            if (need) { const size_t t = std::min(need, w); back.push_back(Seg{win.data() + w - t, t}); }      // (history + first piece, as far as it goes)
-            for (size_t i = back.size(); i-- > 0;) tail.insert(tail.end(), back[i].p, back[i].p + back[i].n);
-        }
-        crc = (u32)::crc32_combine(crc, crc0, (z_off_t)(op0 - h));
-        for (int k = 1; k < accepted; ++k) crc = (u32)::crc32_combine(crc, place[(size_t)k].crc, (z_off_t)place[(size_t)k].len);
-        produced += total;
-        cur_bit = end;
-        rd = h; wr = w;
-        ++st_rounds; st_pieces += (u64)accepted; st_offered += (u64)T;
-        const u32 rounds_before = st_member_rounds++;
-        if (ended) {
-            const size_t q = (end + 7) >> 3;
-            if (q + 8 > n) { fail("truncated gzip trailer"); return -1; }
-            const u32 want_crc = in[q] | (u32)in[q + 1] << 8 | (u32)in[q + 2] << 16 | (u32)in[q + 3] << 24;
-            const u32 want_len = in[q + 4] | (u32)in[q + 5] << 8 | (u32)in[q + 6] << 16 | (u32)in[q + 7] << 24;
-            if (want_crc != crc) { fail("gzip CRC mismatch"); return -1; }
-            if (want_len != (u32)produced) { fail("gzip length mismatch"); return -1; }
-            at = q + 8; in_member = false; spec_on = false;
-            if (accepted == 1 && rounds_before == 0) spec_skip = 64;    // the whole member was inside the first piece: the next ones sequentially
-        } else if (accepted == 1) spec_quit = true;                     // nothing found behind the first piece (stored data?): the rest of the member sequentially
-        return total ? 1 : ended ? 2 : 0;
     }
     // BGZF: the next blocks (about CHUNK bytes of text per thread), every one inflated on its own into its place
     std::vector<Inflater*> pool;
@@ -921,11 +606,6 @@ struct GzIn {
             if (rd != wr) {
                 const size_t take = std::min(want - got, wr - rd);
                 memcpy(dst + got, win.data() + rd, take); rd += take; got += take;
-            } else if (seg_i < segs.size()) {
-                const Seg& sg = segs[seg_i];
-                const size_t take = std::min(want - got, sg.n - seg_rd);
-                memcpy(dst + got, sg.p + seg_rd, take); seg_rd += take; got += take;
-                if (seg_rd == sg.n) { ++seg_i; seg_rd = 0; }
             } else if (done || bad || !produce()) break;
         }
         return bad ? -1 : (int)got;

@@ -321,8 +321,12 @@ __device__ void slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab
 // window (or a read start) has been seen, from there on its state is the reference's; the selected window ends go to the candidate
 // bitmap, and the exact phase of the density scheme (exact hash of the canonical 2-bit l-mer, raw coordinates, ranks, records) takes over.
 // Tiles with bytes outside ACGT, or whose look-back window does not let every thread converge, run sync_slow_tile: the same machine
-// byte by byte through the input accessor, one thread per 127 raw positions, looking back 96, 384, ... positions, at most to the read start.
-constexpr int SYNC_KEEP = 8;                        // records a thread of the generic machine keeps between the count and the write (more: it runs a second time)
+// byte by byte through the input accessor, on SYNC_SLOW_THREADS = 128 of the tile's threads, one per 254 raw positions (SEG), looking back 96, 384, ...
+// positions, at most to the read start.
+constexpr int SYNC_KEEP = 8;                        // records a thread of the generic machine keeps between the count and the write (more: it runs a second time).  A thread's
+                                                    // segment is 254 positions since the machine moved to 128 threads: ~3 records at l=12 s=4 d=0.05, so the second run stays the exception
+                                                    // for the sparse settings; dense ones (d >= 0.3) take it on most flagged tiles — flagged tiles are the rare ones (N, foreign bytes), and
+                                                    // 16 records would cost 32 more VGPRs in the function that sets the kernel's register count
 __device__ inline u64 sync_hash(u64 key, u64 mask) {          // src/read.rs:43-52
     key = (~key + (key << 21)) & mask;
     key = key ^ key >> 24;
@@ -354,7 +358,8 @@ __device__ inline u32 nt4_code(u8 c) {                         // src/read.rs:23
     }
 }
 
-// dq: per-thread ring of the last <= 32 s-mer hashes (s <= 16: 32 bits), column = thread; sc_tmp: 8 words of scan scratch + 1 flag
+// dq: ring of the last <= 32 s-mer hashes (s <= 16: 32 bits) of each of the SYNC_SLOW_THREADS threads that run the machine, dq[slot][thread] (32 x 128 words = 16 KB,
+// on top of the tile state, which is dead by then); sc_tmp: 8 words of scan scratch + 1 flag
 template <bool HPC, class Src>
 __device__ __attribute__((noinline)) void sync_slow_tile(const SketchArgs& a, const Src& src, u32 gt, Rec* slab, u32 (*dq)[SYNC_SLOW_THREADS], u32* sc_tmp) {
     constexpr int TT = SYNC_SLOW_THREADS, TILE_STRIDE = TG<4>::STRIDE;      // (the syncmer scheme runs on the 256-lane tiles; this machine on the first TT of their threads)
@@ -1202,7 +1207,11 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs g) {
     u32 lr = LAST_IN_SLAB;
     if (g.last_read && b0) lr = g.last_read[g.tile0 + b0 - 1];
     u32 slots = ns ? ns : nv;                                         // slab slots to look at (ns != 0: some hold rejected candidates)
-    if (slots > g.slab_cap) slots = 0;                                // the tile's records did not fit: skipped (the host runs the batch again)
+    // a tile whose records did not fit its slab is skipped, and the later tiles of the same wave then write at output indices that are short by its records: the store of a
+    // launch with an overflowing tile is NOT valid.  That is the contract, not an accident: the tile kernel of the same launch has raised over_max for that tile, and
+    // sketch_device_impl reads it before it commits anything (attempt loop: larger slabs, the whole batch again); nothing reads the store in between.  gather_kernel
+    // skips such a tile the same way (tests/test_gpu_round5.py forces the overflow on both).
+    if (slots > g.slab_cap) slots = 0;
     const u32 inc = wave_incl_scan(slots);                            // inclusive prefix over the wave's tiles (lanes >= T: the total)
     const u32 S = (u32)__builtin_amdgcn_readlane((int)inc, 63);
     const u32 nv_all = (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(nv), 63);
@@ -1343,11 +1352,15 @@ void launch_tile_flags(const u64* exc_pos, u32 n_exc, u32 n_tiles, u8* flags, co
 // (profiles/r04_b_tile_shapes_ab.txt): the kernel follows its VALU instruction count, and a wave tile spends more of them per base (four
 // filter steps of 63 words for 193 dense words, a placement pass per 24 instead of 97 survivors, twice the look-back share).
 // The switch is read once; the syncmer scheme only exists on the 256-lane tiles.
+// Since round 5 the wave-tile kernels are only compiled with -DMDBG_WAVE_TILES (scratch/build_variant.sh wave_tiles -DMDBG_WAVE_TILES; mdbg_build_flags() bit 0):
+// the default library carries ONE tile shape, MDBG_TILE is ignored by it.
 TileShape tile_shape_for(u32 scheme) {
-    static const char* const env = getenv("MDBG_TILE");
     u32 nw = 4, tpw = 1;
+#ifdef MDBG_WAVE_TILES
+    static const char* const env = getenv("MDBG_TILE");
     if (env && env[0] == '1' && env[1] == 'x' && env[2] == '4') { nw = 1; tpw = 4; }
     else if (env && env[0] == '1' && env[1] == 'x' && env[2] == '1') { nw = 1; tpw = 1; }
+#endif
     if (scheme == 1) { nw = 4; tpw = 1; }
     TileShape sh; sh.nw = nw; sh.tpw = tpw;
     sh.stride = nw == 4 ? (u32)TileGeo<4>::STRIDE : (u32)TileGeo<1>::STRIDE; sh.halo = nw == 4 ? (u32)TileGeo<4>::HALO_BASES : (u32)TileGeo<1>::HALO_BASES;
@@ -1361,9 +1374,12 @@ void launch_alphabet_rule(const SketchArgs& a, unsigned long long* which, hipStr
 }
 
 template <int L> static void launch_bs(const SketchArgs& a, u32 n_tiles, const TileShape& sh, hipStream_t s) {
-    if (sh.nw == 4) hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 4, 1>), dim3(n_tiles), dim3(256), 0, s, a);
-    else if (sh.tpw == 1) hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 1, 1>), dim3(n_tiles), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 1, 4>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, a);
+#ifdef MDBG_WAVE_TILES
+    if (sh.nw == 1 && sh.tpw == 1) { hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 1, 1>), dim3(n_tiles), dim3(64), 0, s, a); return; }
+    if (sh.nw == 1) { hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 1, 4>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, a); return; }
+#endif
+    (void)sh;
+    hipLaunchKernelGGL((sketch_bs_kernel<L, 0, 1, 4, 1>), dim3(n_tiles), dim3(256), 0, s, a);
 }
 // one launch covers the whole batch (launch boundaries would only re-synchronise the workgroups' phases); n_tiles = tiles to run from a.tile0
 void launch_sketch(SketchArgs a, u32 n_tiles, const TileShape& sh, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {

@@ -37,7 +37,6 @@ with tempfile.TemporaryDirectory() as d:
             z = _bgzf(data[:h], 5000) + gzip.compress(data[h:], 6)
         p = plain + ".gz"
         open(p, "wb").write(z)
-        os.environ["MDBG_GZ_PIECE"] = str(rnd.choice([1 << 20, 2000, 9000, 40000]))      # small pieces: the several-thread path of an ordinary stream on these small files
         for _ in range(4):
             threads = rnd.choice([1, 2, 3, 5, 8, 16])
             mb = rnd.choice([1, 500, 4000, 30000, 200000, 1 << 30])

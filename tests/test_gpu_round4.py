@@ -45,6 +45,9 @@ print("TILE_OK")
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,stride", [("1x4", 8064), ("1x1", 8064), ("4", 32512)])
 def test_tile_geometries_give_the_oracles_table(shape, stride):
+    from rust_mdbg_amd import api
+    if shape != "4" and not (api.load_library().mdbg_build_flags() & 1):
+        pytest.skip("the wave-tile kernels are compiled only with -DMDBG_WAVE_TILES since round 5 (scratch/build_variant.sh wave_tiles -DMDBG_WAVE_TILES)")
     env = dict(os.environ, MDBG_TILE=shape)
     r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, stride)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "TILE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -1,0 +1,64 @@
+"""Round-5 additions checked on the GPU."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+# the gather of SMALL tiles (gather_multi_kernel: one wave takes several tiles) is chosen whenever a tile expects fewer than 128 records — with the product's 256-lane
+# tiles that is any density below ~0.002 —, and until round 5 only the wave-tile experiment exercised it.  Child process: the hooks are read once per process.
+CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import rust_mdbg_amd as R
+from oracle import oracle as O
+rng = np.random.default_rng(%d)
+def rnd(n):
+    return rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n).tobytes()
+# several reads per tile (3 - 9 kb), reads that span tiles (70 kb), empty reads, a read of one homopolymer (no minimizer: empty tiles behind it), tiny reads
+reads = []
+for i in range(260):
+    reads.append(rnd(int(rng.integers(3000, 9000))))
+    if i %% 37 == 0: reads.append(b"")
+    if i %% 53 == 0: reads.append(rnd(70000))
+    if i %% 97 == 0: reads.append(b"A" * 90000)
+    if i %% 11 == 0: reads.append(rnd(int(rng.integers(1, 30))))
+b, o = O.concat_reads(reads)
+for (l, d) in ((12, 0.0005), (14, 0.0002), (10, 0.0015)):
+    exp = O.sketch(b, o, l, d)
+    with R.Mdbg(5, l, d, 1) as m:
+        for rep in range(2):                         # the second pass starts with the slab size the first one learnt
+            sk = m.sketch(b, o)
+            assert np.array_equal(sk["hashes"], exp["hashes"]) and np.array_equal(sk["pos"], exp["pos"]) and np.array_equal(sk["off"], exp["off"]), (l, d, rep)
+    assert len(exp["hashes"]) > 300, len(exp["hashes"])
+print("GATHER_MULTI_OK", len(b))
+"""
+
+
+def _child(seed, **env):
+    e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, seed)], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0 and "GATHER_MULTI_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_small_tile_gather_at_low_density_equals_oracle():
+    _child(5)
+
+
+@pytest.mark.gpu
+def test_small_tile_gather_survives_slab_overflow_and_several_launches():
+    # MDBG_SLAB_CAP0=8: every tile with more than 8 minimizers overflows its slab on the first attempt (the gather of that attempt skips it and shifts the tiles behind
+    # it: its output is discarded), the batch runs again with slabs sized from the largest count seen; MDBG_SLAB_BUDGET_MB=1: ~8 launches per batch
+    _child(6, MDBG_SLAB_CAP0=8, MDBG_SLAB_BUDGET_MB=1)
+    _child(7, MDBG_SLAB_BUDGET_MB=1)
+    _child(8, MDBG_SLAB_CAP0=8)
+
+
+@pytest.mark.gpu
+def test_default_build_has_one_tile_shape():
+    from rust_mdbg_amd import api
+    assert api.load_library().mdbg_build_flags() & 1 == 0
