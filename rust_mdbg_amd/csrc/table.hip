@@ -84,6 +84,8 @@ struct TableArgs {
     const u64* own_thr;           // see OwnerSpec
     u32* probe_err;               // set when a probe sequence visited every slot: the table was sized from a wrong window count
     u64* own_inserted;            // sharded counter: owned windows actually inserted (checked against the senders' counts)
+    u8* claim;                    // non-null: claim[i] <- 1 when the window starting at minimizer index i CLAIMED its slot (created the key), else 0 — written for every
+                                  // index of the span, so the map needs no zeroing; finalize starts from it instead of marking every key's first sighting (fin_mark_kernel)
 };
 
 // Home slot of a key hash: range reduction by multiplication, so the capacity need not be a power of two.  It is fed
@@ -245,8 +247,8 @@ void launch_owner_thresholds(double bound, u32 k, u32 world, u64* thr, hipStream
 constexpr int OWN_SPAN = OWN_SPAN_V;
 __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
                                                                    const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
-                                                                   u32* __restrict__ cap_err, const u64* __restrict__ i1_dev) {
-    extern __shared__ u64 sh_keys[];           // [OWN_SPAN + k] keys, then u16 list[OWN_SPAN], then the counter
+                                                                   u32* __restrict__ cap_err, const u64* __restrict__ i1_dev, u64 n_lim) {
+    extern __shared__ u64 sh_keys[];           // [OWN_SPAN + k] keys, then u16 list[OWN_SPAN], then the counter, then u8 cl[OWN_SPAN]
     if (cap_err[1]) return;
     // i1_dev: launched behind the sketch of the same batch before the host knew how many minimizers it has (i1 = an upper bound the grid was
     // sized for): the count comes from the device, workgroups behind it have nothing to do
@@ -254,10 +256,12 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     const u32 k = T.ks.k;
     u16* const list = (u16*)(sh_keys + OWN_SPAN + k);
     u32* const n_own = (u32*)(list + OWN_SPAN);
+    u8* const cl = (u8*)(n_own + 4);             // [OWN_SPAN] claim bytes of the span (T.claim)
     const u64 b0 = i0 + (u64)blockIdx.x * OWN_SPAN;
     const u64 lim = b0 + OWN_SPAN + k - 1 < i1 ? b0 + OWN_SPAN + k - 1 : i1;
     for (u64 t = b0 + threadIdx.x; t < lim; t += 256) sh_keys[t - b0] = mh[t];
     if (threadIdx.x == 0) *n_own = 0;
+    if (T.claim) for (int u = threadIdx.x; u < OWN_SPAN / 8; u += 256) ((u64*)cl)[u] = 0;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < OWN_SPAN / 256; ++u) {
@@ -290,9 +294,15 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
         const u64 h = key_hash_window(w, k, rev);
         bool claimed;
         const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+        if (claimed && T.claim) cl[li] = 1;
         if (claimed || s == ~0ull) continue;
         atomicAdd(&T.tab[s].count, 1u);
         push_ordinal(T, s, ord);
+    }
+    if (T.claim) {                             // the span's claim bytes, 64 consecutive bytes per wave and store (a slice's last workgroup stops at its end: n_lim)
+        __syncthreads();
+        const u64 hi = i1 - b0 < (u64)OWN_SPAN ? i1 - b0 : (u64)OWN_SPAN;
+        for (u32 li = threadIdx.x; li < hi && li < n_lim - (u64)blockIdx.x * OWN_SPAN; li += 256) T.claim[b0 + li] = cl[li];
     }
 }
 
@@ -693,6 +703,8 @@ struct FinArgs {
     u64* o_row;                              // non-null: write node q at position q and its global row here (partitioned table)
     const u64* ath_override;                 // [Slot.pad - 1]: sighting whose metadata a node that wrapped its u16 abundance keeps (null: none)
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
+    u32 claims;                              // 1: by_first IS the insertion's claim map (TableArgs::claim) and dense index == store index: fin_mark only moves the marks of
+                                             // keys whose first sighting is not their claimer (keys seen once — most — need nothing)
     u8* by_first; u8* by_solid;              // the same as one BYTE per index (zeroed): fin_mark sets bytes with plain stores — 3.9 M device-scope atomics on the
                                              // bitmaps were most of its time —, bytes_to_bits_kernel packs them into the bitmaps
     const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
@@ -769,6 +781,14 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
             ++n_occ; solid[u] = F.A == 1 || (u16)count >= (u16)F.A; n_wrapped += count >= 65536u ? 1u : 0u;          // as slot_view
             // first sighting: the claimer's window or the smallest ordinal the others pushed.  Most keys are seen once (sequencing
             // errors), and the claimer's dense index follows from `rep` alone: no read map / offset lookups for them
+            if (F.claims) {
+                // the claimer's byte is set already (insert_windows_kernel); a key seen again may have an earlier sighting: move the mark there.  201 M scattered byte
+                // stores into a 721 MB map were 10 ms of the human table's finalize (1.3 TB/s); 183 M of those keys are seen once and cost nothing here
+                const u64 Dc = (u32)e[u].word;
+                D = Dc;
+                if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; F.by_first[D1] = 1; } }
+                if (solid[u]) F.by_solid[D] = 1;
+            } else {
             if (e[u].word & (1ull << 33)) { u64 i; const u64 ro = rep_ordinal(F, e[u].word); decode_ordinal(F, ro < e[u].m1 ? ro : e[u].m1, i, D); }   // routed record
             else {
                 D = dense_of_index(F, (u32)e[u].word);
@@ -776,6 +796,7 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
             }
             F.by_first[D] = 1;                       // (distinct keys have distinct first sightings: nobody else writes this byte)
             if (solid[u]) F.by_solid[D] = 1;
+            }
         }
         dense[u] = D;
         m[u] = __ballot(solid[u]);
@@ -1288,7 +1309,7 @@ void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, 
     (void)n_windows;
     const u64 n = n_starts ? n_starts : i1 - i0;          // n_starts: only the window starts [i0, i0 + n_starts) (a slice; i1 stays the end of the batch)
     hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((n + OWN_SPAN - 1) / OWN_SPAN)), dim3(256),
-                       (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err, i1_dev);
+                       (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16 + OWN_SPAN, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err, i1_dev, n);
 }
 // Several small regions zeroed (and one scalar set) by ONE launch: the steps between the big kernels would otherwise be chains of
 // 5-microsecond fill kernels (ten of them in front of the sketch, five in front of finalize).

@@ -62,3 +62,13 @@ def test_small_tile_gather_survives_slab_overflow_and_several_launches():
 def test_default_build_has_one_tile_shape():
     from rust_mdbg_amd import api
     assert api.load_library().mdbg_build_flags() & 1 == 0
+
+
+@pytest.mark.gpu
+def test_finalize_without_the_claim_map_gives_the_same_nodes():
+    """finalize starts from the insertion's claim map since round 5 (fin_mark only moves the marks of keys whose first sighting is not their claimer); MDBG_NO_CLAIMS
+    keeps the round-4 path (every key's first sighting marked at finalize) alive: the fuzz seeds give the oracle's nodes on it too"""
+    child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import test_gpu_fuzz as F\n"
+             "for s in (1, 2, 3, 5, 8, 13, 21): F.test_fuzz_sketch_and_nodes(s)\nprint('NO_CLAIMS_OK')\n" % (ROOT, ROOT))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=dict(os.environ, MDBG_NO_CLAIMS="1"), timeout=900)
+    assert r.returncode == 0 and "NO_CLAIMS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
