@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __rest
 // workgroup's span are ranked per owner in index order — lanes of a wave by ballots, the 32 (iteration, wave) groups by a prefix in LDS.
 __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
                                                                u32 k, u32 world, const u64* thr, u32 slot0, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list,
-                                                               const u8* __restrict__ owner_of) {
+                                                               const u8* __restrict__ owner_of, u32 direct_owner, u32* __restrict__ direct_dst) {
+    // direct_owner (< world): that owner's bucket is not part of `list` (its bases entry is unused): it goes to direct_dst, the place the rank keeps its own
+    // share of its own batch (api.inc, owner_lists_impl) — until round 5 the bucket was written to the list and copied there (368 MB per 19.5-Gbase batch at one rank)
     constexpr int NG = OWNL_SPAN / 64;
     __shared__ u32 grp[NG][OWNL_MAX_WORLD];
     for (int t = threadIdx.x; t < NG * (int)OWNL_MAX_WORLD; t += 256) ((u32*)grp)[t] = 0;
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __rest
         const u32 o = own[u];
         if (o == NONE) continue;
         const u64 i = b0 + u * 256 + threadIdx.x;
-        uint2* const e = (uint2*)list + (bases.b[o] + blk_off[(size_t)blockIdx.x * world + o] + grp[u * 4 + wv][o] + rank[u]);
+        const u64 at = blk_off[(size_t)blockIdx.x * world + o] + grp[u * 4 + wv][o] + rank[u];
+        uint2* const e = o == direct_owner ? (uint2*)direct_dst + at : (uint2*)list + (bases.b[o] + at);
         *e = make_uint2((u32)(i - i0), slot_of[u] - slot0);        // window start and its read, both relative to the batch
     }
 }
@@ -588,8 +591,9 @@ void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u
     const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k - 1) * sizeof(u64) : 0;
     if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), lds, s, mh, mread, roff, i0, i1, k, world, thr, blk_cnt, owner_of);
 }
-void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, const u8* owner_of, hipStream_t s) {
-    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, thr, slot0, blk_off, bases, list, owner_of);
+void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, const u8* owner_of, hipStream_t s,
+                             u32 direct_owner = 0xFFFFFFFFu, u32* direct_dst = nullptr) {
+    if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, thr, slot0, blk_off, bases, list, owner_of, direct_owner, direct_dst);
 }
 // list: n pairs (window start, read), seg: launch_list_segments of it
 void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, const u32* seg, u64 n, u32 slot0,

@@ -23,12 +23,24 @@ typedef u32 v32u __attribute__((ext_vector_type(32)));
 
 // chunk c of the lane's 32 machines: word NCH * i + c of machine i, both planes, transposed: V0[r] bit i = plane-0 bit of position r of that word
 __device__ __forceinline__ void load_chunk(const uint2* __restrict__ src, int c, v32u& V0, v32u& V1) {
-    u32 a0[32], a1[32];
+    // one plane at a time: 32 raw words in flight beside the resident state
+    const u32* s32 = (const u32*)(src + c);
+    {
+        u32 a[32];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { const uint2 q = src[NCH * i + c]; a0[i] = q.x; a1[i] = q.y; }
-    vt_transpose32(a0); vt_transpose32(a1);
+        for (int i = 0; i < 32; ++i) a[i] = s32[2 * NCH * i];
+        vt_transpose32(a);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { V0[i] = a0[i]; V1[i] = a1[i]; }
+        for (int i = 0; i < 32; ++i) V0[i] = a[i];
+    }
+    {
+        u32 a[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a[i] = s32[2 * NCH * i + 1];
+        vt_transpose32(a);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) V1[i] = a[i];
+    }
 }
 
 template <int L>
