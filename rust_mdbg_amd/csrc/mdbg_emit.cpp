@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -424,6 +427,33 @@ struct Lz4In {
 };
 
 // ---- host ingest -------------------------------------------------------------------------------------
+
+// A pool of worker threads that lives as long as its reader: run(f) executes f(0) .. f(n - 1), f(0) on the caller.  (std::thread per batch and stage: 64 threads x 3
+// stages x ~40 us of spawn + join per 256-Mbase batch was a third of the reader's time at 64 threads, profiles/r04_n_file_pipeline.json -> r05_file_pipeline.json.)
+struct WorkerPool {
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv_go, cv_done;
+    const std::function<void(int)>* job = nullptr; u64 epoch = 0; int pending = 0, n = 1; bool quit = false;
+    explicit WorkerPool(int n_) : n(std::max(1, n_)) {
+        for (int i = 1; i < n; ++i) th.emplace_back([this, i] {
+            u64 seen = 0;
+            for (;;) {
+                const std::function<void(int)>* f;
+                { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return quit || epoch != seen; }); if (quit) return; seen = epoch; f = job; }
+                (*f)(i);
+                { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+            }
+        });
+    }
+    void run(const std::function<void(int)>& f) {
+        if (n == 1) { f(0); return; }
+        { std::lock_guard<std::mutex> lk(mu); job = &f; pending = n - 1; ++epoch; }
+        cv_go.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~WorkerPool() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
+};
+
 struct mdbg_reader {
     gzFile f = nullptr; Lz4In* lz = nullptr; bool fasta = false, strip = false, eof = false, io_error = false;
     gz::GzAhead* gzin = nullptr; const u8* gz_map = nullptr; size_t gz_size = 0;   // a gzip file, mapped and inflated by gz_inflate.h (f stays null)
@@ -445,6 +475,12 @@ struct mdbg_reader {
     std::vector<u64> pexc_pos, pexc_pos2; std::vector<u8> pexc_val, pexc_val2;
     std::vector<u8> bases; std::vector<u64> offs;            // current batch
     std::vector<u8> pending; bool have_pending = false;      // a parsed record that did not fit the previous batch
+    // fast path of the parallel reader (round 5): records whose sequence is ONE line are located by a scan (no copy) and packed / copied straight from the mapped
+    // text by a pool of workers that lives as long as the reader (rounds 2 - 4: two copies per base and three thread spawns per batch)
+    struct FastRec { u64 off, len; };
+    std::vector<std::vector<FastRec>> fast_recs;
+    struct WorkerPool* pool = nullptr;
+    bool packed_done = false;                                 // the batch in offs has been packed by the fast path already (mdbg_reader_next_packed)
     bool fill() {                                             // more input; false at EOF
         if (eof || mem) return false;
         if (pos > 0) { memmove(buf.data(), buf.data() + pos, len - pos); len -= pos; pos = 0; }
@@ -577,6 +613,9 @@ size_t next_record_start(const u8* m, size_t n, size_t p, bool fasta) {
 }
 }  // namespace
 
+// the fast path (defined behind the packer): 1 = the batch is complete (offsets, and the ASCII copy or the packed words), 0 = a record of the window needs the
+// general parser (FASTA sequence over several lines, --reference stripping, stray lines), < 0 = error
+static int reader_fast_window(mdbg_reader* r, const std::vector<size_t>& cut, bool ascii_out);
 // ascii_out: the sequences are copied side by side into r->big; otherwise they stay in the per-thread pieces (mdbg_reader_next_packed
 // packs them from there) and only the offsets are laid out
 static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_out = true) {
@@ -592,6 +631,13 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_o
     for (int i = 1; i < T; ++i) {
         const size_t guess = r->map_cur + (size_t)((double)(end - r->map_cur) * i / T);
         cut[i] = std::min(end, std::max(cut[i - 1], next_record_start(m, end, guess, r->fasta)));
+    }
+    r->packed_done = false;
+    {
+        static const bool no_fast = getenv("MDBG_READER_NO_FAST") != nullptr;      // (A/B switch and test hook: the general parser on every window)
+        const int f = no_fast ? 0 : reader_fast_window(r, cut, ascii_out);
+        if (f < 0) return f;
+        if (f == 1) { r->map_cur = end; return MDBG_OK; }
     }
     r->piece_bases.resize(T); r->piece_lens.resize(T);
     struct PieceRef { std::vector<u8>& bases; std::vector<u64>& lens; };
@@ -719,7 +765,7 @@ mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threa
     void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (mp == MAP_FAILED) return r;
-    (void)madvise(mp, (size_t)st.st_size, MADV_SEQUENTIAL);
+    // (no MADV_SEQUENTIAL: the fast path reads every window twice — the scan, then the pack / copy — and that advice lets the kernel drop the pages in between)
     r->map = (const u8*)mp; r->map_size = (size_t)st.st_size; r->map_cur = 0; r->threads = threads;
     return r;
 }
@@ -748,7 +794,7 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
     return r->io_error ? MDBG_E_IO : MDBG_OK;                // a malformed / truncated compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); if (r->map && !r->gw_mode) munmap((void*)r->map, r->map_size); free(r->gw); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
+void mdbg_reader_close(mdbg_reader* r) { if (r) { delete r->pool; if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); if (r->map && !r->gw_mode) munmap((void*)r->map, r->map_size); free(r->gw); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
 
 }  // extern "C"
 
@@ -847,6 +893,93 @@ int reader_pack_pieces(mdbg_reader* r, u64 total) {
 }
 }  // namespace
 
+// ---- fast path of the parallel reader -------------------------------------------------------------------------------------------------------
+// Stage A (every worker on its piece of the window, which starts at a record start): the records' sequences are LOCATED — (offset in the text, length) —
+// without copying anything; a record whose sequence is not one line of the text sends the whole window to the general parser.  Stage B: the
+// offsets are laid out and every worker copies (ASCII batches) or packs (2-bit batches) the sequences of its own records straight from the text.
+namespace {
+// false: the piece holds something the general parser has to look at
+bool scan_piece(const u8* m, size_t a, size_t b, size_t file_end, bool fasta, bool strip, std::vector<mdbg_reader::FastRec>& recs, u64& n_bases) {
+    recs.clear(); n_bases = 0;
+    size_t p = a;
+    auto eol = [&](size_t from) -> size_t { const u8* nl = from < b ? (const u8*)memchr(m + from, '\n', b - from) : nullptr; return nl ? (size_t)(nl - m) : b; };
+    while (p < b) {
+        if (fasta) {
+            if (m[p] != '>') return false;                                  // a stray line in front of a header: the general parser skips it
+            const size_t he = eol(p);
+            if (he >= b) { recs.push_back({b, 0}); break; }                   // a header without a line behind it: an empty record
+            size_t s = he + 1, e = eol(s);
+            if (s < b && m[s] == '>') { recs.push_back({s, 0}); p = s; continue; }      // empty sequence
+            if (strip) return false;                                        // --reference: line terminators are taken out of the sequence (a copy)
+            const size_t next = e < b ? e + 1 : b;
+            if (next < b && m[next] != '>') return false;                   // the sequence goes on in the next line: interior terminators belong to it
+            if (e == b && b < file_end) return false;                       // (cannot happen: pieces end at record starts)
+            size_t ee = e; if (ee > s && m[ee - 1] == '\r') --ee;
+            recs.push_back({s, ee - s}); n_bases += ee - s;
+            p = next;
+        } else {
+            size_t he = eol(p);
+            if (he == p) { p = he + 1; continue; }                           // the general parser skips empty lines in front of a header
+            if (he >= b) break;                                              // a header and nothing else: no record (as the general parser: its sequence line is missing)
+            const size_t s = he + 1, e = eol(s);
+            size_t ee = e; if (ee > s && m[ee - 1] == '\r') --ee;
+            recs.push_back({s, ee - s}); n_bases += ee - s;
+            if (e >= b) break;
+            const size_t pe = eol(e + 1);                                    // '+'
+            if (pe >= b) break;
+            const size_t qe = eol(pe + 1);                                   // qualities
+            p = qe < b ? qe + 1 : b;
+        }
+    }
+    return true;
+}
+}  // namespace
+static int reader_fast_window(mdbg_reader* r, const std::vector<size_t>& cut, bool ascii_out) {
+    const int T = (int)cut.size() - 1;
+    const u8* m = r->map;
+    if (!r->pool || r->pool->n != T) { delete r->pool; r->pool = new WorkerPool(T); }
+    r->fast_recs.resize((size_t)T);
+    std::vector<u64> nb((size_t)T, 0); std::vector<u8> ok((size_t)T, 1);
+    static const bool timing = getenv("MDBG_READER_TIMING") != nullptr;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+    const double t0 = timing ? now() : 0;
+    const std::function<void(int)> scan = [&](int i) { ok[(size_t)i] = scan_piece(m, cut[(size_t)i], cut[(size_t)i + 1], cut[(size_t)T], r->fasta, r->strip, r->fast_recs[(size_t)i], nb[(size_t)i]) ? 1 : 0; };
+    r->pool->run(scan);
+    const double t1 = timing ? now() : 0;
+    for (int i = 0; i < T; ++i) if (!ok[(size_t)i]) return 0;
+    std::vector<u64> base0((size_t)T + 1, 0), read0((size_t)T + 1, 0);
+    for (int i = 0; i < T; ++i) { base0[(size_t)i + 1] = base0[(size_t)i] + nb[(size_t)i]; read0[(size_t)i + 1] = read0[(size_t)i] + r->fast_recs[(size_t)i].size(); }
+    const u64 total = base0[(size_t)T], reads = read0[(size_t)T];
+    r->offs.resize(reads + 1);
+    const u64 nw = (total + 31) / 32;
+    if (ascii_out) { if (total + 64 > r->big_cap) { free(r->big); r->big_cap = total + total / 8 + 4096; r->big = (u8*)malloc(r->big_cap); if (!r->big) { r->big_cap = 0; return MDBG_E_NOMEM; } } }
+    else if (nw + 8 > r->pw_cap) { free(r->pw); r->pw_cap = nw + nw / 8 + 64; r->pw = (u64*)malloc(r->pw_cap * 8); if (!r->pw) { r->pw_cap = 0; return MDBG_E_NOMEM; } }
+    const bool avx2 = __builtin_cpu_supports("avx2");
+    std::vector<ExcList> ex((size_t)T); std::vector<std::vector<Partial>> parts((size_t)T);
+    const std::function<void(int)> place = [&](int i) {
+        u64 o = base0[(size_t)i]; size_t j = read0[(size_t)i];
+        for (const mdbg_reader::FastRec& q : r->fast_recs[(size_t)i]) {
+            r->offs[j++] = o;
+            if (q.len) { if (ascii_out) memcpy(r->big + o, m + q.off, q.len); else pack_piece(m + q.off, o, o + q.len, r->pw, ex[(size_t)i], parts[(size_t)i], avx2); }
+            o += q.len;
+        }
+    };
+    const double t2 = timing ? now() : 0;
+    r->pool->run(place);
+    const double t3 = timing ? now() : 0;
+    r->offs[reads] = total;
+    if (!ascii_out) {
+        for (int i = 0; i < T; ++i) for (const Partial& q : parts[(size_t)i]) r->pw[q.word] = 0;       // words shared by records: clear, then OR the contributions
+        for (int i = 0; i < T; ++i) for (const Partial& q : parts[(size_t)i]) r->pw[q.word] |= (u64)q.lo | ((u64)q.hi << 32);
+        r->pexc_pos.clear(); r->pexc_val.clear();
+        for (int i = 0; i < T; ++i) { r->pexc_pos.insert(r->pexc_pos.end(), ex[(size_t)i].pos.begin(), ex[(size_t)i].pos.end()); r->pexc_val.insert(r->pexc_val.end(), ex[(size_t)i].val.begin(), ex[(size_t)i].val.end()); }
+        r->packed_done = true;
+    }
+    if (timing) fprintf(stderr, "[mdbg reader] window %.1f MB, %d threads: scan %.2f ms, layout %.2f, %s %.2f, merge %.2f\n", (double)(cut[(size_t)T] - cut[0]) / 1e6, T, t1 - t0, t2 - t1,
+                        ascii_out ? "copy" : "pack", t3 - t2, now() - t3);
+    return 1;
+}
+
 extern "C" {
 int mdbg_reader_next_packed(mdbg_reader* r, uint64_t max_bases, mdbg_packed_batch* out) {
     if (!r || !out) return MDBG_E_PARAM;
@@ -859,7 +992,7 @@ int mdbg_reader_next_packed(mdbg_reader* r, uint64_t max_bases, mdbg_packed_batc
         if (e) return e;
         if (r->offs.size() == 1) { r->pexc_pos.clear(); r->pexc_val.clear(); out->offsets = r->offs.data(); return MDBG_OK; }      // end of file (the pieces still hold the last batch)
         const u64 total = r->offs.back();
-        e = reader_pack_pieces(r, total); if (e) return e;
+        if (!r->packed_done) { e = reader_pack_pieces(r, total); if (e) return e; }
     } else {                                                   // streaming reader (.gz, .lz4, one thread): parse, then pack the ASCII batch
         const uint8_t* b; const uint64_t* o; uint64_t n;
         r->offs.swap(r->offs2);                                // the offsets handed out last stay intact during this call
