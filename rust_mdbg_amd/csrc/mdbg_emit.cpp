@@ -243,22 +243,39 @@ int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nd, const mdbg_edges
     if (!path || !nd) return MDBG_E_PARAM;
     FILE* f = fopen(path, "wb");
     if (!f) return MDBG_E_IO;
-    std::vector<char> buf((1u << 20) + 256);
-    char* p = buf.data(); char* const lim = buf.data() + (1u << 20);
-    bool ok = true;
-    auto flush = [&]() { if (p != buf.data()) { ok = ok && fwrite(buf.data(), 1, (size_t)(p - buf.data()), f) == (size_t)(p - buf.data()); p = buf.data(); } };
-    auto lit = [&](const char* s) { while (*s) *p++ = *s++; };
-    lit("H\tVN:Z:1.0\n");                                                                          // main.rs:1011
-    for (u64 i = 0; ok && i < nd->n; ++i) {                                                         // :1021  S\t{index}\t*\tLN:i:{seqlen}\tKC:i:{abundance}
-        lit("S\t"); p = put_u32(p, nd->index[i]); lit("\t*\tLN:i:"); p = put_u32(p, nd->seqlen[i]); lit("\tKC:i:"); p = put_u32(p, (u32)nd->abundance[i]); *p++ = '\n';
-        if (p >= lim) flush();
+    // The lines are formatted by a few threads, each a contiguous range of the S lines and of the L lines into a buffer of its own, and written in order
+    // (one thread: 31 ms per 465 k nodes + 910 k edges, a tenth of a file -> .gfa run at 25 Gbases/s).  Small graphs stay on the caller's thread.
+    const u64 n_s = nd->n, n_l = ed ? ed->n : 0;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int T = n_s + n_l < 200000 ? 1 : (int)std::min<u64>(8, std::max<unsigned>(1, hw));
+    std::vector<std::string> s_part((size_t)T), l_part((size_t)T);
+    auto fmt = [&](int t) {
+        const u64 s0 = n_s * (u64)t / (u64)T, s1 = n_s * (u64)(t + 1) / (u64)T, l0 = n_l * (u64)t / (u64)T, l1 = n_l * (u64)(t + 1) / (u64)T;
+        char tmp[96];
+        std::string& S = s_part[(size_t)t]; S.reserve((s1 - s0) * 40 + 64);
+        for (u64 i = s0; i < s1; ++i) {                                                             // main.rs:1021  S\t{index}\t*\tLN:i:{seqlen}\tKC:i:{abundance}
+            char* p = tmp;
+            *p++ = 'S'; *p++ = '\t'; p = put_u32(p, nd->index[i]); memcpy(p, "\t*\tLN:i:", 8); p += 8; p = put_u32(p, nd->seqlen[i]); memcpy(p, "\tKC:i:", 6); p += 6;
+            p = put_u32(p, (u32)nd->abundance[i]); *p++ = '\n';
+            S.append(tmp, (size_t)(p - tmp));
+        }
+        std::string& Lp = l_part[(size_t)t]; Lp.reserve((l1 - l0) * 40 + 64);
+        for (u64 i = l0; i < l1; ++i) {                                                             // main.rs:1095  L\t{n1}\t{o1}\t{n2}\t{o2}\t{overlap}M
+            char* p = tmp;
+            *p++ = 'L'; *p++ = '\t'; p = put_u32(p, ed->n1[i]); *p++ = '\t'; *p++ = (char)ed->o1[i]; *p++ = '\t'; p = put_u32(p, ed->n2[i]); *p++ = '\t'; *p++ = (char)ed->o2[i]; *p++ = '\t';
+            p = put_u32(p, ed->overlap[i]); *p++ = 'M'; *p++ = '\n';
+            Lp.append(tmp, (size_t)(p - tmp));
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(fmt, t);
+        fmt(0);
+        for (auto& x : th) x.join();
     }
-    if (ed) for (u64 i = 0; ok && i < ed->n; ++i) {                                                 // :1095  L\t{n1}\t{o1}\t{n2}\t{o2}\t{overlap}M
-        lit("L\t"); p = put_u32(p, ed->n1[i]); *p++ = '\t'; *p++ = (char)ed->o1[i]; *p++ = '\t'; p = put_u32(p, ed->n2[i]); *p++ = '\t'; *p++ = (char)ed->o2[i]; *p++ = '\t';
-        p = put_u32(p, ed->overlap[i]); *p++ = 'M'; *p++ = '\n';
-        if (p >= lim) flush();
-    }
-    flush();
+    bool ok = fwrite("H\tVN:Z:1.0\n", 1, 11, f) == 11;                                              // main.rs:1011
+    for (int t = 0; ok && t < T; ++t) ok = s_part[(size_t)t].empty() || fwrite(s_part[(size_t)t].data(), 1, s_part[(size_t)t].size(), f) == s_part[(size_t)t].size();
+    for (int t = 0; ok && t < T; ++t) ok = l_part[(size_t)t].empty() || fwrite(l_part[(size_t)t].data(), 1, l_part[(size_t)t].size(), f) == l_part[(size_t)t].size();
     ok = ok && !ferror(f);                     // a short write (disk full) must not pass for a complete graph
     ok = (fclose(f) == 0) && ok;
     return ok ? MDBG_OK : MDBG_E_IO;
@@ -481,6 +498,28 @@ struct mdbg_reader {
     std::vector<std::vector<FastRec>> fast_recs;
     struct WorkerPool* pool = nullptr;
     bool packed_done = false;                                 // the batch in offs has been packed by the fast path already (mdbg_reader_next_packed)
+    // A window of the mapped file is never looked at again once its batch has been copied / packed: its pages go back on a thread of their own while the next window is read
+    // (munmap of the whole 7-GB mapping at close was ~40 ms of a 0.28-s run)
+    size_t unmap_from = 0; std::thread unmap_th; std::mutex unmap_mu; std::condition_variable unmap_cv; std::vector<std::pair<size_t, size_t>> unmap_q; bool unmap_quit = false;
+    void unmap_upto(size_t end) {
+        if (!map || gw_mode) return;
+        const size_t page = 4096, to = end & ~(page - 1);
+        if (to < unmap_from + (64u << 20)) return;
+        if (!unmap_th.joinable()) unmap_th = std::thread([this] {
+            for (;;) {
+                std::pair<size_t, size_t> q;
+                { std::unique_lock<std::mutex> lk(unmap_mu); unmap_cv.wait(lk, [&] { return unmap_quit || !unmap_q.empty(); }); if (unmap_q.empty()) return; q = unmap_q.back(); unmap_q.pop_back(); }
+                munmap((void*)(map + q.first), q.second);
+            }
+        });
+        { std::lock_guard<std::mutex> lk(unmap_mu); unmap_q.emplace_back(unmap_from, to - unmap_from); }
+        unmap_cv.notify_one();
+        unmap_from = to;
+    }
+    void unmap_finish() {
+        if (unmap_th.joinable()) { { std::lock_guard<std::mutex> lk(unmap_mu); unmap_quit = true; } unmap_cv.notify_one(); unmap_th.join(); }
+        if (map && !gw_mode && map_size > unmap_from) munmap((void*)(map + unmap_from), map_size - unmap_from);
+    }
     bool fill() {                                             // more input; false at EOF
         if (eof || mem) return false;
         if (pos > 0) { memmove(buf.data(), buf.data() + pos, len - pos); len -= pos; pos = 0; }
@@ -637,7 +676,7 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_o
         static const bool no_fast = getenv("MDBG_READER_NO_FAST") != nullptr;      // (A/B switch and test hook: the general parser on every window)
         const int f = no_fast ? 0 : reader_fast_window(r, cut, ascii_out);
         if (f < 0) return f;
-        if (f == 1) { r->map_cur = end; return MDBG_OK; }
+        if (f == 1) { r->map_cur = end; r->unmap_upto(end); return MDBG_OK; }
     }
     r->piece_bases.resize(T); r->piece_lens.resize(T);
     struct PieceRef { std::vector<u8>& bases; std::vector<u64>& lens; };
@@ -673,6 +712,7 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_o
     }
     r->offs[reads] = total;
     r->map_cur = end;
+    r->unmap_upto(end);
     return MDBG_OK;
 }
 
@@ -794,7 +834,7 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
     return r->io_error ? MDBG_E_IO : MDBG_OK;                // a malformed / truncated compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { delete r->pool; if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); if (r->map && !r->gw_mode) munmap((void*)r->map, r->map_size); free(r->gw); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
+void mdbg_reader_close(mdbg_reader* r) { if (r) { delete r->pool; if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); r->unmap_finish(); free(r->gw); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
 
 }  // extern "C"
 

@@ -60,6 +60,23 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                     while not stop.is_set():      # the reader's buffers must outlive the last batch's ingest: wait until the consumer is done
                         time.sleep(0.005)
                     return
+                if r.parallel:
+                    # ASCII batches of the parallel reader are views into its two alternating buffers: no copy, at most two outstanding (as the packed ones);
+                    # until round 5 every batch was copied once more on this thread (7 GB of memcpy per 7 Gbases: most of the ASCII path's time)
+                    it = r.batches(batch_bases, copy=False)
+                    while True:
+                        while not free.acquire(timeout=0.2):
+                            if stop.is_set():
+                                return
+                        item = next(it, None)
+                        if item is None:
+                            break
+                        if not put((item[0], item[1].copy(), len(item[0]))):
+                            return
+                    put(None)
+                    while not stop.is_set():
+                        time.sleep(0.005)
+                    return
                 for bases, offs in r.batches(batch_bases):
                     if not put((bases, offs, len(bases))):
                         return
@@ -88,6 +105,7 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                     free.release()                      # this batch's buffers may be reused
                 else:
                     m.ingest(payload, offs, n_reads)    # ctypes releases the GIL: the reader thread parses the next batch meanwhile
+                    free.release()
                 n_reads += (len(payload["offsets"]) if packed else len(offs)) - 1
                 n_bases += nb
             tm["ingest"] = time.perf_counter() - t0

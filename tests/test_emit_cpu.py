@@ -221,3 +221,25 @@ def test_sequences_blocks_are_compressed(tmp_path):
         assert len(f[1][1:-1].split(", ")) == k and set(f[2]) <= set("ACGTN")
         idx.add(int(f[0]))
     assert len(idx) == 2000
+
+
+def test_large_gfa_written_by_several_threads_is_the_same_text(tmp_path):
+    """graphs of 200 k lines and more are formatted by several threads (round 5), each a range of the S lines and of the L lines: the file is the text one
+    thread writes (src/main.rs:1011,1021,1095), checked against Python's own formatting of a synthetic table"""
+    import ctypes as C
+    from rust_mdbg_amd.api import EdgeList
+    rng = np.random.default_rng(5)
+    n, m, k = 150_001, 210_007, 3
+    nodes = dict(keys=np.zeros((n, k), np.uint64), index=rng.permutation(n).astype(np.uint32), abundance=rng.integers(2, 65535, n).astype(np.uint16),
+                 seqlen=rng.integers(1, 4_000_000_000, n, dtype=np.uint64).astype(np.uint32), shift=np.zeros(2 * n, np.uint16), shift_full=np.zeros((n, 2), np.uint64),
+                 src_read=np.zeros(n, np.uint64), src_start=np.zeros(n, np.uint64), src_end=np.zeros(n, np.uint64), reversed=np.zeros(n, np.uint8))
+    n1 = rng.integers(0, n, m).astype(np.uint32); n2 = rng.integers(0, n, m).astype(np.uint32)
+    o1 = rng.choice(np.frombuffer(b"+-", np.uint8), m); o2 = rng.choice(np.frombuffer(b"+-", np.uint8), m)
+    ov = rng.integers(0, 100000, m).astype(np.uint32)
+    ed = EdgeList(n=m, n1=n1.ctypes.data_as(C.POINTER(C.c_uint32)), o1=o1.ctypes.data_as(C.POINTER(C.c_uint8)), n2=n2.ctypes.data_as(C.POINTER(C.c_uint32)),
+                  o2=o2.ctypes.data_as(C.POINTER(C.c_uint8)), overlap=ov.ctypes.data_as(C.POINTER(C.c_uint32)), presimp_removed=0)
+    p = str(tmp_path / "big.gfa")
+    E.Emitter().write_gfa(p, nodes, ed)
+    want = ["H\tVN:Z:1.0"] + ["S\t%d\t*\tLN:i:%d\tKC:i:%d" % (nodes["index"][i], nodes["seqlen"][i], nodes["abundance"][i]) for i in range(n)]
+    want += ["L\t%d\t%s\t%d\t%s\t%dM" % (n1[i], chr(o1[i]), n2[i], chr(o2[i]), ov[i]) for i in range(m)]
+    assert open(p).read() == "\n".join(want) + "\n"
