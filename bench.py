@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--minabund", type=int, default=2)
     ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="layout of the reads in HBM during the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--multik-exchange", choices=["whole", "segments"], default="whole", help="--multik at N > 1: what the ranks exchange (whole: once per sweep; segments: once per k)")
     ap.add_argument("--multik", action="store_true",
                     help="BASELINE.json configs[4]: a step = sketch ONCE (l=12 d=0.003), then the graph of every k in 10,15,..,40 from the resident sketches (mdbg_reset(new_k): the table is "
                          "cleared and refilled, nothing is sketched or — at N>1, where the ranks hold whole sketches — exchanged again); value counts every k's graph: bases x 7 / time")
@@ -97,7 +98,9 @@ def parse():
             ap.error("--multik runs on the human workload (configs[4]) and the C layer")
         if a.l is None: a.l = 12
         a.k = MULTIK[0]
-        a.dist_exchange = "whole"              # the multik mode of the multi-GPU layer: every rank keeps every sketch entire, so a new k needs no new exchange (mdbg_dist_set_exchange)
+        # the sweep's default at N > 1: every rank keeps every sketch entire, so a new k needs no new exchange (mdbg_dist_set_exchange); --multik-exchange segments: the
+        # default exchange, and mdbg_dist_reset(k) exchanges the rounds again for every k (seven smaller exchanges instead of one large one)
+        a.dist_exchange = a.multik_exchange
     if a.genome_mb is None: a.genome_mb = 3000.0 if human else 140.0
     if a.coverage is None: a.coverage = 52.0 if human else 50.0
     if a.l is None: a.l = 14 if human else 12

@@ -132,7 +132,8 @@ static void* rank_main(void* arg) {
     fetch(c, o->keys, nd.keys, nd.n * nd.k * 8); fetch(c, o->index, nd.index, nd.n * 4); fetch(c, o->abundance, nd.abundance, nd.n * 2);
     fetch(c, o->seqlen, nd.seqlen, nd.n * 4); fetch(c, o->src_read, nd.src_read, nd.n * 8); fetch(c, o->row, d_row, nd.n * 8);
     pthread_barrier_wait(&w->bar);
-    /* another k on the resident sketches: possible after a whole-sketch exchange, refused (nothing is changed) after segments, which hold only this k's windows */
+    /* another k on the resident sketches: after a whole-sketch exchange every hash is here; after segments (which hold only this k's windows) the library runs the
+       rounds' exchange again for the new k — collective either way */
     j->reset_rc = mdbg_dist_reset(d, j->P.k + 2);
     pthread_barrier_wait(&w->bar);
     mdbg_destroy(gen);

@@ -81,11 +81,13 @@ int mdbg_dist_set_pipeline(mdbg_dist* d, uint32_t chunks);
  * MDBG_EXCHANGE_SEGMENTS (default): per peer the list of the windows it owns (8 bytes each) and ONLY the hashes those windows need.  A
  *   k-min-mer is owned by the rank its smallest minimizer hash maps to; consecutive windows of a read share that hash for about (k + 1) / 2
  *   steps, so a rank's windows come in runs and a run of r windows needs r + k - 1 hashes: a few hashes per window, and a volume per rank
- *   that does not grow with the number of ranks.  The foreign sketches are then resident only where this k needs them:
- *   mdbg_dist_reset(d, new_k != k) returns MDBG_E_STATE.
+ *   that does not grow with the number of ranks.  The foreign sketches are then resident only where this k needs them: mdbg_dist_reset(d, new_k != k)
+ *   runs the rounds' exchange again for the new k (the reads are not sketched again; neither k's hashes are a subset of the other's — the owner of a window is
+ *   a function of the smallest of ITS k hashes).
  * MDBG_EXCHANGE_WHOLE: every rank receives every sketch entire (8 bytes per minimizer and peer: what round 2 did).  THE MODE OF A MULTI-K SWEEP
  *   (utils/multik: k = 10, 15, .. 40 on the same reads): the resident global sketch is re-windowed at every k without a new exchange — one
- *   exchange of 1.3 GB into a rank (8 ranks, 7-Gbase shards) instead of one of 0.3 GB per k under segments.  bench.py --multik selects it. */
+ *   exchange of 1.3 GB into a rank (8 ranks, 7-Gbase shards) instead of one of 0.3 GB per k under segments (seven k: 2.1 GB).  bench.py --multik selects it
+ *   (--multik-exchange segments: the other way). */
 enum { MDBG_EXCHANGE_SEGMENTS = 0, MDBG_EXCHANGE_WHOLE = 1 };
 int mdbg_dist_set_exchange(mdbg_dist* d, uint32_t mode);
 
@@ -100,8 +102,10 @@ int mdbg_dist_ingest_batch_packed_device(mdbg_dist* d, const mdbg_packed_batch* 
  * the global table (= rank in DbgEntry.index order), so concatenating the partitions of all ranks and ordering by d_row gives the
  * single-GPU table; out->index holds the GLOBAL DbgEntry.index; out->n_distinct and *n_nodes_global are totals over all ranks. */
 int mdbg_dist_finalize(mdbg_dist* d, mdbg_nodes* out, const uint64_t** d_row, uint64_t* n_nodes_global);
-/* new_k = 0: drop everything; else re-window the resident GLOBAL sketch with new_k (no exchange needed: every rank holds the hashes;
- * the positions the new nodes need are fetched at the next finalize) — MDBG_EXCHANGE_WHOLE only, see mdbg_dist_set_exchange. */
+/* new_k = 0: drop everything; else the node table of the same reads at another k.  COLLECTIVE.  MDBG_EXCHANGE_WHOLE: the resident GLOBAL sketch is re-windowed
+ * (no exchange: every rank holds every hash).  MDBG_EXCHANGE_SEGMENTS: every round is exchanged again for the new k from the sketches the ranks hold of their
+ * own reads — new window lists, new segments into the same regions of the store.  Either way nothing is sketched again, and the positions the new nodes need
+ * are fetched at the next finalize. */
 int mdbg_dist_reset(mdbg_dist* d, uint32_t new_k);
 
 /* Bytes this rank has received / sent through the communicator's `exchange` since mdbg_dist_create or the last mdbg_dist_reset(d, 0)

@@ -64,6 +64,12 @@ def test_bench_multik_sweep_one_rank_and_two_ranks_agree():
     assert one["graph"]["nodes_per_k"] == two["graph"]["nodes_per_k"] and all(n > 500 for _, n in one["graph"]["nodes_per_k"])
     assert two["exchange"]["mode"] == "whole" and two["graph"]["partitions_add_up"] is True
     assert one["roofline"]["launches_per_step"] == 8          # one sketch per batch and sweep: nothing is sketched again for the later k
+    # the same sweep under the DEFAULT exchange (segments): mdbg_dist_reset(k) exchanges the rounds again for every k (round 5; until then MDBG_E_STATE) — same graphs,
+    # still one sketch per batch, and the line says what the seven exchanges moved
+    seg = _bench("--gpus", "4", "--comm", "host", "--multik-exchange", "segments", *small)
+    assert seg["graph"]["nodes_per_k"] == one["graph"]["nodes_per_k"] and seg["exchange"]["mode"] == "segments" and seg["graph"]["partitions_add_up"] is True
+    assert seg["config"]["batches_per_step"] == 2 and seg["roofline"]["launches_per_step"] == 4          # two batches x two chunks per rank, sketched once per sweep
+    assert seg["exchange"]["bytes_in_busiest_rank_per_step"] > 0
 
 
 @pytest.mark.gpu

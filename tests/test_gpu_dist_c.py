@@ -45,8 +45,9 @@ def test_whole_sketch_exchange_gives_the_same_table_and_moves_more(exe, world, r
         assert r.returncode == 0, r.stdout + r.stderr
         assert "EQUAL to the single-context table" in r.stdout and ("whole-sketch exchange" if whole else "segment exchange") in r.stdout
         out[whole] = _bytes_in(r.stdout)
-        # re-windowing the resident sketches at another k: fine with whole sketches, MDBG_E_STATE (-6) when only this k's segments are resident
-        assert ("reset(k + 2): 0 " in r.stdout) if whole else ("reset(k + 2): -" in r.stdout and "ranks differ" not in r.stdout), r.stdout
+        # re-windowing the resident sketches at another k: the resident hashes do with whole sketches; under segments the rounds are exchanged again for the new k
+        # (round 5; until then MDBG_E_STATE) — tests/test_gpu_round5.py compares the tables
+        assert "reset(k + 2): 0 " in r.stdout and "ranks differ" not in r.stdout, r.stdout
     assert out[0] > 0 and out[1] > 0
     if world >= 8:
         assert out[0] < 0.6 * out[1], out

@@ -111,3 +111,91 @@ def test_owner_table_from_a_skewed_first_batch():
     ratio = max(sizes) / (sum(sizes) / W)
     print("nodes per rank %r, max / mean %.3f" % (sizes, ratio))
     assert ratio < 1.30, sizes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,chunks,k2", [(2, 1, 27), (4, 2, 15), (3, 3, 31)])
+def test_dist_reset_to_another_k_under_segments(W, chunks, k2):
+    """mdbg_dist_reset(new k) with the default exchange: the foreign sketches hold only the hashes of the old k's windows, so the library exchanges the rounds again
+    for the new k (new owner lists, new segments into the same store regions) without sketching anything again; the partitions put together equal ONE context that
+    was reset to the same k — both for a larger and for a smaller k (neither is a subset of the other: the owner is a function of the window's smallest hash)"""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import api, dist_c
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_dist_scale as S
+    from thread_comm import ThreadWorld
+    k, l, d, A, n_reads, rounds = 21, 12, 0.004, 2, 6000, 2
+    genome = 20_000_000
+    L = api.load_library()
+    L.mdbg_dist_create.restype = C.c_void_p
+    L.mdbg_dist_create.argtypes = [C.POINTER(api.Params), C.POINTER(dist_c.Comm), C.POINTER(C.c_int)]
+    L.mdbg_dist_ingest_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.mdbg_dist_finalize.argtypes = [C.c_void_p, C.POINTER(api.Nodes), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.mdbg_dist_set_pipeline.argtypes = [C.c_void_p, C.c_uint32]
+    L.mdbg_dist_reset.argtypes = [C.c_void_p, C.c_uint32]
+    L.mdbg_dist_traffic.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mdbg_dist_destroy.argtypes = [C.c_void_p]
+    world = ThreadWorld(W)
+    parts, traffic, errs = [None] * W, [None] * W, []
+
+    def first_of(rank, rd):
+        return (rd * W + rank) * n_reads
+
+    def body(rank):
+        try:
+            cm, keep = world.comm(rank)
+            P = api.Params(k=k, l=l, density=d, min_abundance=A, reads_already_hpc=0, device=0, flags=0, table_capacity_hint=0)
+            err = C.c_int()
+            h = L.mdbg_dist_create(C.byref(P), C.byref(cm), C.byref(err))
+            assert h, err.value
+            assert L.mdbg_dist_set_pipeline(h, chunks) == 0
+            with R.Mdbg(k, l, d, A, device=0) as gen:
+                for rd in range(rounds):
+                    idle = rd == rounds - 1 and rank == W - 1          # the last rank sits out the last round
+                    db, do, nb = gen.synth_reads_device(seed=5, genome_len=genome, n_reads=n_reads, first_read=first_of(rank, rd))
+                    assert L.mdbg_dist_ingest_batch_device(h, db, do, 0 if idle else n_reads, nb, first_of(rank, rd)) == 0
+                nd, row, ng = api.Nodes(), C.c_void_p(), C.c_uint64()
+                assert L.mdbg_dist_finalize(h, C.byref(nd), C.byref(row), C.byref(ng)) == 0
+                bi0 = C.c_uint64()
+                L.mdbg_dist_traffic(h, C.byref(bi0), None, None)
+                world.bar.wait()
+                e = L.mdbg_dist_reset(h, k2)
+                assert e == 0, e
+                assert L.mdbg_dist_finalize(h, C.byref(nd), C.byref(row), C.byref(ng)) == 0
+                bi1 = C.c_uint64()
+                L.mdbg_dist_traffic(h, C.byref(bi1), None, None)
+                n = int(nd.n)
+                cp = lambda p, cnt, dt: gen.to_host(C.cast(p, C.c_void_p).value, cnt * np.dtype(dt).itemsize, dt) if cnt else np.empty(0, dt)
+                parts[rank] = dict(n=n, ng=int(ng.value), n_distinct=int(nd.n_distinct), n_wrapped=int(nd.n_wrapped), row=cp(row, n, np.uint64),
+                                   keys=cp(nd.keys, n * k2, np.uint64).reshape(n, k2), index=cp(nd.index, n, np.uint32), abundance=cp(nd.abundance, n, np.uint16),
+                                   seqlen=cp(nd.seqlen, n, np.uint32), shift_full=cp(nd.shift_full, 2 * n, np.uint64).reshape(n, 2), src_read=cp(nd.src_read, n, np.uint64),
+                                   src_start=cp(nd.src_start, n, np.uint64), src_end=cp(nd.src_end, n, np.uint64))
+                traffic[rank] = (bi0.value, bi1.value - bi0.value)
+            world.bar.wait()
+            L.mdbg_dist_destroy(h)
+        except BaseException as ex:          # noqa: BLE001
+            errs.append(ex)
+            world.bar.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    with R.Mdbg(k, l, d, A, device=0) as one, R.Mdbg(k, l, d, A, device=0) as gen:
+        for rd in range(rounds):
+            for r in range(W):
+                if rd == rounds - 1 and r == W - 1:
+                    continue
+                db, do, nb = gen.synth_reads_device(seed=5, genome_len=genome, n_reads=n_reads, first_read=first_of(r, rd))
+                one.ingest_device(db, do, n_reads, nb, first_of(r, rd))
+        one.finalize()
+        one.reset(k2)
+        ref = one.finalize()
+    assert ref["n_nodes"] > 5000
+    S._assert_partitions_equal(parts, ref)
+    assert all(t[0] > 0 and t[1] > 0 for t in traffic), traffic          # the new k cost an exchange of its own
+    print("bytes received per rank, first k / new k:", traffic)
