@@ -788,10 +788,12 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
             if (F.claims) {
                 // the claimer's byte is set already (insert_windows_kernel); a key seen again may have an earlier sighting: move the mark there.  201 M scattered byte
                 // stores into a 721 MB map were 10 ms of the human table's finalize (1.3 TB/s); 183 M of those keys are seen once and cost nothing here
+                // ONE map in this mode: bit 0 = first sighting, bit 1 = the key is solid (no second map to zero: 2.2 ms per finalize of the human table); a byte only ever
+                // gains bits between two resets (abundances grow, and with the batches in ordinal order — the mode's condition — a first sighting never moves forward)
                 const u64 Dc = (u32)e[u].word;
                 D = Dc;
-                if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; F.by_first[D1] = 1; } }
-                if (solid[u]) F.by_solid[D] = 1;
+                if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; } }
+                if (D != Dc || solid[u]) F.by_first[D] = solid[u] ? 3 : 1;
             } else {
             if (e[u].word & (1ull << 33)) { u64 i; const u64 ro = rep_ordinal(F, e[u].word); decode_ordinal(F, ro < e[u].m1 ? ro : e[u].m1, i, D); }   // routed record
             else {
@@ -826,22 +828,23 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
             F.solid_list[j] = s0 + 1024ull * u; F.solid_dense[j] = dense[u];
         }
 }
-// bitmap word w <- bit i = (byte 64 w + i != 0), for both maps; one thread per word (four 16-byte loads per map)
+// bitmap word w <- bit i = (byte 64 w + i != 0), for both maps; one thread per word (four 16-byte loads per map).  by1 == null: ONE map whose bytes hold bit 0 = first
+// sighting, bit 1 = solid (the claim-map mode of fin_mark_kernel)
 __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const u8* __restrict__ by0, const u8* __restrict__ by1, u64 n_words, u64* __restrict__ bm0, u64* __restrict__ bm1) {
     const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
     if (w >= n_words) return;
-    auto pack = [](const u8* p) -> u64 {
+    auto pack = [](const u8* p, u32 shift) -> u64 {
         u64 out = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint4 v = ((const uint4*)p)[q];
             const u32 x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out |= (u64)((((x[j] & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (16 * q + 4 * j);      // bytes hold 0 or 1: four of them -> four bits, byte 0 lowest
+            for (int j = 0; j < 4; ++j) out |= (u64)(((((x[j] >> shift) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (16 * q + 4 * j);      // four bytes -> four bits, byte 0 lowest
         }
         return out;
     };
-    bm0[w] = pack(by0 + 64 * w); bm1[w] = pack(by1 + 64 * w);
+    bm0[w] = pack(by0 + 64 * w, 0); bm1[w] = by1 ? pack(by1 + 64 * w, 0) : pack(by0 + 64 * w, 1);
 }
 void launch_bytes_to_bits(const u8* by0, const u8* by1, u64 n_words, u64* bm0, u64* bm1, hipStream_t s) {
     if (n_words) hipLaunchKernelGGL(bytes_to_bits_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, by0, by1, n_words, bm0, bm1);
