@@ -80,8 +80,9 @@ def test_owner_table_from_a_skewed_first_batch():
     under a live table.  Here the first round is as unrepresentative as it gets: every rank's first batch comes from a 20-kb genome at 2,000x (a few hundred
     distinct window minima: a few hundred of the 65,536 bins hold everything), the second from a 60-Mb genome.  The table must stay EXACT whatever the balance;
     the balance itself is reported (nodes per rank, max / mean).  Measured on MI355X: 1.28 while bins the first round never saw were spread by a hash of their index,
-    1.21 since they go by the analytic quantiles of the window-minimum distribution (dist_api.inc, build_owner_table); what is left comes from the few hundred bins
-    the skewed round DID see, which are dealt out by its counts (a representative first round: 1.01 - 1.05, tests/test_gpu_dist_scale.py)."""
+    1.21 with the analytic quantiles of the window-minimum distribution for them, **1.03** since the bins' weights are a blend of the measurement and a model of a
+    uniform genome (the enumerated l-mer hashes under the bound and their chance of being a window's minimum), the measurement trusted by the share of the model's mass
+    it has seen (dist_api.inc, build_owner_table).  A representative first round: 1.01 - 1.05 as before (tests/test_gpu_dist_scale.py)."""
     import numpy as np
     import rust_mdbg_amd as R
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -110,7 +111,7 @@ def test_owner_table_from_a_skewed_first_batch():
     sizes = [p["n"] for p in parts]
     ratio = max(sizes) / (sum(sizes) / W)
     print("nodes per rank %r, max / mean %.3f" % (sizes, ratio))
-    assert ratio < 1.30, sizes
+    assert ratio < 1.10, sizes
 
 
 @pytest.mark.gpu
