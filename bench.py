@@ -502,7 +502,11 @@ def main():
         consistent = bool(loc == int(n_nodes))
     exchange = None
     if cdist is not None:    # what went over the links in the last step, and how even the partition is (mdbg_dist_traffic; outside the timed region)
-        b_in, b_out, n_q = cdist.traffic()
+        try:
+            b_in, b_out, n_q = cdist.traffic()
+        except Exception as ex:          # (a side measurement; every rank still joins the all-reduces below)
+            print("bench.py: mdbg_dist_traffic failed on rank %d: %r" % (rank, ex), file=sys.stderr)
+            b_in = b_out = n_q = 0
         tmax = allreduce([b_in, int(cdist.last_local)], torch.int64, dist.ReduceOp.MAX)
         tsum = allreduce([b_in, int(cdist.last_local)], torch.int64)
         exchange = {"mode": args.dist_exchange, "chunks_per_step": n_chunks * len(batches), "bytes_in_busiest_rank_per_step": int(tmax[0]), "bytes_in_mean_per_step": float(tsum[0]) / world,
@@ -513,6 +517,8 @@ def main():
         # (table not partitioned).  N x this rate is the ceiling on this node for this split of the data.
         t_loc = -1.0
         try:
+            if "no_exchange_anchor" in os.environ.get("MDBG_BENCH_FAIL_SIDE", "").split(","):
+                raise RuntimeError("forced by MDBG_BENCH_FAIL_SIDE")
             ts = []
             for _ in range(3):
                 torch.cuda.synchronize(); m.sync()
@@ -570,10 +576,23 @@ def main():
         roof = roofline(dict(st, **tile_acc), 0.25 if packed else 1.0, args.input)          # the kernel's average launch duration over all timed steps
         if roof:
             roof["launches_per_step"] = tile_acc["n_sketch_tile_launches"] / max(1, args.steps); roof["launches_timed"] = tile_acc["n_sketch_tile_launches"]
+        side_errors = {}
+
+        def side(name, fn, default=None):
+            """a side measurement (recorded profiles, passes after the timed region): a failure in one is reported in the line under side_errors, the headline is not
+            lost to it.  (A parity mismatch raises SystemExit, which passes through: no line is printed then.)"""
+            try:
+                if name in os.environ.get("MDBG_BENCH_FAIL_SIDE", "").split(","):      # (tests: every side measurement can be made to fail)
+                    raise RuntimeError("forced by MDBG_BENCH_FAIL_SIDE")
+                return fn()
+            except Exception as ex:
+                side_errors[name] = repr(ex)[:300]
+                print("bench.py: side measurement %s failed: %r" % (name, ex), file=sys.stderr)
+                return default
         if roof:
-            roof["traffic"], roof["traffic_source"] = pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args)
-            roof["issue"] = issue_roofline(args, roof, torch.cuda.get_device_properties(device_index).multi_processor_count) if packed else None
-            sq = sq_counters(args)
+            roof["traffic"], roof["traffic_source"] = side("pmc_traffic", lambda: pmc_traffic(st["n_sketch_tile_bases"] / st["n_sketch_tile_launches"], args), (None, None))
+            roof["issue"] = side("issue_roofline", lambda: issue_roofline(args, roof, torch.cuda.get_device_properties(device_index).multi_processor_count)) if packed else None
+            sq = side("sq_counters", lambda: sq_counters(args))
             if sq:
                 roof.update(valu_lane_ops_per_base=sq.get("valu_lane_ops_per_base"), wave_time_split=sq.get("wave_time_split"), sq_source=sq.get("source"))
             if packed:
@@ -581,14 +600,16 @@ def main():
                                 "not by HBM (valu_lane_ops_per_base%s); the same kernel on the b_in = 1.0 accounting is in roofline_ascii"
                                 % ("; traffic = %.2fx the algorithmic bytes" % (roof["traffic"] / roof["algorithmic_bytes_per_launch"]) if roof["traffic"] else ""))
         roof_ascii = ascii_in = None
-        if packed and not routed and not human and not args.plain:      # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
+
+        def ascii_leg():
+            # the same kernel fed one byte per base: the other accounting of SURVEY.md 8d, measured live
             for _ in range(2):
                 m.reset(0)
                 m.sketch_device(d_bases, d_off0, reads_per_gpu, n_bases, rank * reads_per_gpu)
             sta = m.stats()
-            roof_ascii = roofline(sta, 1.0, "ascii")
-            if roof_ascii:
-                roof_ascii["traffic"], roof_ascii["traffic_source"] = pmc_traffic(sta["n_sketch_tile_bases"] / sta["n_sketch_tile_launches"], args, "ascii")
+            ra = roofline(sta, 1.0, "ascii")
+            if ra:
+                ra["traffic"], ra["traffic_source"] = pmc_traffic(sta["n_sketch_tile_bases"] / sta["n_sketch_tile_launches"], args, "ascii")
             # the same STEPS fed ASCII (both legs start from ASCII, concatenated + offsets): the timed region above starts from the packed layout,
             # which the device packer produces in pack_ms
             local_step(ascii_in=True)
@@ -599,21 +620,26 @@ def main():
                 local_step(ascii_in=True)
             m.sync()
             ms_a = (time.perf_counter() - t1) / na * 1e3
-            ascii_in = {"ms_per_step": ms_a, "value": n_bases / ms_a / 1e6, "unit": "Gbases/s", "steps": na, "pack_ms": pack_ms,
+            return ra, {"ms_per_step": ms_a, "value": n_bases / ms_a / 1e6, "unit": "Gbases/s", "steps": na, "pack_ms": pack_ms,
                         "value_pack_then_packed": n_bases / (pack_ms + ms_step) / 1e6 if pack_ms else None,
                         "what": "the same steps with the reads resident as ASCII (one byte per base): the tile kernel converts on the fly; pack_ms = mdbg_pack_device "
                                 "(ASCII -> 2-bit planes) alone; value_pack_then_packed = bases / (pack_ms + ms_per_step of the timed region)"}
-            local_step()      # the table the edge stage and the baseline below refer to
-        edges = None
-        if not routed and not human and not args.plain:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
+        if packed and not routed and not human and not args.plain:
+            roof_ascii, ascii_in = side("ascii_in", ascii_leg, (None, None))
+            local_step()      # the table the edge stage and the baseline below refer to (not a side measurement: the counts below come from it)
+
+        def edge_leg():
             m.graph_edges_device(0.01)
             t1 = time.perf_counter()
             e = m.graph_edges_device(0.01)
-            edges = {"ms": (time.perf_counter() - t1) * 1e3, "n_edges": int(e.n), "presimp_removed": int(e.presimp_removed)}
+            return {"ms": (time.perf_counter() - t1) * 1e3, "n_edges": int(e.n), "presimp_removed": int(e.presimp_removed)}
+        edges = None
+        if not routed and not human and not args.plain:               # outside the timed region: the edge stage that follows the hot path (device-resident in, device-resident out)
+            edges = side("edges_after_timed_region", edge_leg)
         cpu = None
         if args.cpu_seconds > 0 and world == 1 and not args.plain:          # rank 0 at N=1 only: at N>1 the other ranks would wait for it
             # (human: d_bases / d_off0 hold the ASCII of the last shard generated — a sample of the same data set)
-            cpu = cpu_baseline(m, d_bases, d_off0, shard_reads, batches[-1][3], args)
+            cpu = side("cpu_baseline", lambda: cpu_baseline(m, d_bases, d_off0, shard_reads, batches[-1][3], args))
         anchor1 = None
         if world == 1 and not routed and not human and not args.plain and not args.no_scale_anchor and (args.genome_mb, args.coverage, args.l, args.density) == (140.0, 50.0, 12, 0.002):
             try:
@@ -674,8 +700,8 @@ def main():
                          "checked_against_recorded_counts": want is not None,
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent, "nodes_per_k": per_k if args.multik else None},
-               "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": n1_same_workload(args) if (human and world > 1) else None, "scale_anchor_n1": anchor1,
-               "edges_after_timed_region": edges}
+               "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": side("n1_same_workload", lambda: n1_same_workload(args)) if (human and world > 1) else None, "scale_anchor_n1": anchor1,
+               "edges_after_timed_region": edges, "side_errors": side_errors or None}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     if cdist is not None:

@@ -110,6 +110,8 @@ int main(int argc, char** argv) {
     const uint64_t batch_bases = 256u << 20;
     mdbg_reader* rd = mdbg_reader_open_mt(input, reference, threads, &err);
     if (!rd) die(NULL, "mdbg_reader_open", err);
+    /* the batch buffers come from the GPU library: page-locked by the first ingest call that sees them, so a batch crosses PCIe as one DMA */
+    { const int rc = mdbg_reader_set_allocator(rd, mdbg_host_alloc, mdbg_host_free); if (rc) die(NULL, "mdbg_reader_set_allocator", rc); }
     uint64_t n_reads = 0, n_bases = 0, first = 0;
     double t_wait = 0, t_gpu = 0;                                   /* --timing: where the ingest loop spends its time */
     if (threads > 1) {                                              /* any input: the streaming reader (.gz, .lz4) packs on the reader thread */
@@ -144,7 +146,8 @@ int main(int argc, char** argv) {
     const double t_ingest = now_s();
 
     mdbg_nodes nodes; mdbg_edge_list edges;
-    int rc = mdbg_finalize(ctx, &nodes);
+    /* without the .sequences pass the host prints three columns of the node table (the S lines): the minimizer lists stay on the device */
+    int rc = write_sequences ? mdbg_finalize(ctx, &nodes) : mdbg_finalize_gfa(ctx, &nodes);
     if (rc) die(ctx, "mdbg_finalize", rc);
     rc = mdbg_graph_edges(ctx, presimp, &edges);
     if (rc) die(ctx, "mdbg_graph_edges", rc);

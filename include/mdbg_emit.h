@@ -10,6 +10,7 @@
 #ifndef MDBG_EMIT_H
 #define MDBG_EMIT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "mdbg_hip.h"
@@ -71,6 +72,10 @@ int mdbg_reader_is_fasta(const mdbg_reader* r);
  * records goes to the parser threads, the rest is carried into the next window.  When the file is read in parallel, mdbg_reader_next alternates two buffers: a batch stays valid until the call
  * AFTER the next one, so that another thread can pack / copy batch i while batch i+1 is being parsed. */
 mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err);
+/* Where the batch buffers handed out by a parallel reader (mdbg_reader_open_mt on an uncompressed file: the ASCII bases of mdbg_reader_next, the packed words of
+ * mdbg_reader_next_packed of any reader) come from; default malloc / free.  With mdbg_host_alloc / mdbg_host_free of mdbg_hip.h the ingest calls page-lock them on
+ * first use and the copy to the device is one DMA.  Before the first batch (MDBG_E_STATE afterwards); both or neither (NULL, NULL = malloc / free). */
+int mdbg_reader_set_allocator(mdbg_reader* r, void* (*alloc_fn)(size_t), void (*free_fn)(void*));
 int mdbg_reader_is_parallel(const mdbg_reader* r);      /* 1: the file is mapped and parsed by several threads (two alternating batch buffers) */
 void mdbg_reader_close(mdbg_reader* r);
 

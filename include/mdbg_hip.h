@@ -35,6 +35,7 @@
 #ifndef MDBG_HIP_H
 #define MDBG_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -179,6 +180,10 @@ int mdbg_query_batch(mdbg_ctx* ctx, const uint8_t* bases, const uint64_t* offset
 int mdbg_finalize(mdbg_ctx* ctx, mdbg_nodes* out);
 /* Same node table, but every pointer in *out is DEVICE memory (no copy to the host). */
 int mdbg_finalize_device(mdbg_ctx* ctx, mdbg_nodes* out);
+/* The node table for a host that writes the .gfa and nothing else: it stays on the device (where mdbg_graph_edges reads it), and only what the S lines print
+ * comes to the host — out->index, out->seqlen, out->abundance (HOST arrays: 10 bytes per node instead of 8 k + 58); every other pointer of *out is NULL.
+ * mdbg_emit_write_gfa accepts such a table, the .sequences writer and mdbg_emit_edges do not (they need the minimizer lists: MDBG_E_PARAM). */
+int mdbg_finalize_gfa(mdbg_ctx* ctx, mdbg_nodes* out);
 /* Multi-k: keep every cached sketch and all allocations, clear the node table, and re-window the
  * resident sketches with new_k (new_k == 0: also drop the sketches = start over with the same parameters). */
 int mdbg_reset(mdbg_ctx* ctx, uint32_t new_k);
@@ -215,6 +220,17 @@ uint32_t mdbg_build_flags(void);
  * RCCL, the host's own hipMalloc) does not know about the cached blocks and can run out of memory against them: such a host calls this after it has
  * destroyed its contexts (or before a large allocation of its own), or caps the cache with MDBG_CACHE_MB. */
 uint64_t mdbg_release_cached_memory(void);
+/* Host memory for the batches handed to mdbg_ingest_batch / mdbg_ingest_batch_packed: ordinary page-aligned memory that the first ingest call given a pointer
+ * into it page-locks (hipHostRegister of the whole allocation, after the caller has written — i.e. faulted in — the batch: 0.011 ms per MB, against 0.24 ms per
+ * MB for hipHostMalloc), so that the copy to the device is one DMA (57 GB/s measured) instead of the runtime's staged copy from pageable memory (17 - 20 GB/s
+ * for freshly written batches).  A drop-in for malloc / free as far as the caller is concerned; memory from anywhere else is still accepted by the ingest calls
+ * and takes the staged path.  mdbg_host_free keeps a
+ * page-locked allocation for the next mdbg_host_alloc of about its size (unlocking and unmapping costs what locking did not: 10 ms per 73 MB), up to
+ * MDBG_HOST_CACHE_MB megabytes per process (environment; default 2048, 0 = give everything back at once); mdbg_release_cached_memory releases these too.  mdbg_reader_set_allocator (mdbg_emit.h) takes this pair.  mdbg_host_is_pinned: 1 once the
+ * allocation that holds p has been page-locked. */
+void* mdbg_host_alloc(size_t bytes);
+void mdbg_host_free(void* p);
+int mdbg_host_is_pinned(const void* p);
 
 /* ---- device-resident stage entry points (used by the multi-GPU driver and the benchmark) -------------
  * Sketch stage only, device buffers in, results appended to the context's resident sketch store. */

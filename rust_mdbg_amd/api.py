@@ -76,14 +76,14 @@ class SynthParams(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
-EXPORTS = ["mdbg_abi_version", "mdbg_build_flags", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
+EXPORTS = ["mdbg_abi_version", "mdbg_build_flags", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_finalize_gfa", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
            "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
            "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed", "mdbg_mark", "mdbg_rewind", "mdbg_set_lmer_filter",
-           "mdbg_release_cached_memory"]
+           "mdbg_release_cached_memory", "mdbg_host_alloc", "mdbg_host_free", "mdbg_host_is_pinned"]
 
 
 def lib_path():
@@ -111,6 +111,11 @@ def load_library():
     L.mdbg_abi_version.restype = u32
     L.mdbg_build_flags.restype = u32
     L.mdbg_release_cached_memory.restype = u64
+    L.mdbg_host_alloc.restype = vp
+    L.mdbg_host_alloc.argtypes = [C.c_size_t]
+    L.mdbg_host_free.restype = None
+    L.mdbg_host_free.argtypes = [vp]
+    L.mdbg_host_is_pinned.argtypes = [vp]
     L.mdbg_create.restype = vp
     L.mdbg_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_int)]
     L.mdbg_destroy.restype = None
@@ -128,6 +133,7 @@ def load_library():
     L.mdbg_sketch_only.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.POINTER(u64)]
     L.mdbg_finalize.argtypes = [vp, C.POINTER(Nodes)]
     L.mdbg_finalize_device.argtypes = [vp, C.POINTER(Nodes)]
+    L.mdbg_finalize_gfa.argtypes = [vp, C.POINTER(Nodes)]
     L.mdbg_reset.argtypes = [vp, u32]
     L.mdbg_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mdbg_strerror.restype = C.c_char_p
@@ -280,8 +286,16 @@ class Mdbg:
         self._chk(self.L.mdbg_sketch_only(self.h, bases.ctypes.data, offsets.ctypes.data, n, C.byref(ph), C.byref(pp), C.byref(po), C.byref(m)))
         return dict(hashes=_np(ph, m.value, np.uint64), pos=_np(pp, m.value, np.uint64), off=_np(po, n + 1, np.uint64))
 
-    def finalize(self):
+    def finalize(self, gfa_only=False):
+        """-> the node table as numpy arrays.  gfa_only: the table stays on the device (where mdbg_graph_edges reads it) and only what the S lines of a .gfa
+        print (index, length, abundance: 10 bytes per node instead of 8 k + 58) is copied to the host; the other entries are None"""
         nd = Nodes()
+        if gfa_only:
+            self._chk(self.L.mdbg_finalize_gfa(self.h, C.byref(nd)))
+            n = int(nd.n)
+            return dict(n_nodes=n, n_nodes_before=int(nd.n_distinct), n_wrapped=int(nd.n_wrapped), k=int(nd.k), keys=None, index=_np(nd.index, n, np.uint32),
+                        abundance=_np(nd.abundance, n, np.uint16), seqlen=_np(nd.seqlen, n, np.uint32), shift=None, shift_full=None, src_read=None, src_start=None,
+                        src_end=None, reversed=None)
         self._chk(self.L.mdbg_finalize(self.h, C.byref(nd)))
         n, k = nd.n, nd.k
         return dict(n_nodes=int(n), n_nodes_before=int(nd.n_distinct), n_wrapped=int(nd.n_wrapped),

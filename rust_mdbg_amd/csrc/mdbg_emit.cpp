@@ -4,6 +4,8 @@
 // shared with the CPU oracle.  Data structures differ from the reference (flat arrays + one hash map from a (k-1)-mer
 // to the nodes listing it), the emitted multiset of edges is the same.
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <cctype>
 #include <cerrno>
 #include <cstdlib>
@@ -18,6 +20,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
@@ -172,6 +175,7 @@ void mdbg_emit_destroy(mdbg_emit* e) { delete e; }
 
 int mdbg_emit_edges(mdbg_emit* E, const mdbg_nodes* nd, float presimp, mdbg_edges* out) {
     if (!E || !nd || !out || nd->k < 2) return MDBG_E_PARAM;
+    if (nd->n && (!nd->keys || !nd->index || !nd->seqlen || !nd->shift)) return MDBG_E_PARAM;      // a table of mdbg_finalize_gfa: the edges of such a run come from mdbg_graph_edges
     const u64 n = nd->n; const u32 k = nd->k, km = k - 1;
     E->n1.clear(); E->n2.clear(); E->ov.clear(); E->o1.clear(); E->o2.clear();
     // km_index (main.rs:1017-1033): every node is listed under its normalized prefix AND under its normalized suffix
@@ -241,13 +245,14 @@ static inline char* put_u32(char* p, u32 v) {
 }
 int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nd, const mdbg_edges* ed) {
     if (!path || !nd) return MDBG_E_PARAM;
+    if (nd->n && (!nd->index || !nd->seqlen || !nd->abundance)) return MDBG_E_PARAM;      // (a table of mdbg_finalize_gfa holds these three columns and nothing else)
     FILE* f = fopen(path, "wb");
     if (!f) return MDBG_E_IO;
     // The lines are formatted by a few threads, each a contiguous range of the S lines and of the L lines into a buffer of its own, and written in order
     // (one thread: 31 ms per 465 k nodes + 910 k edges, a tenth of a file -> .gfa run at 25 Gbases/s).  Small graphs stay on the caller's thread.
     const u64 n_s = nd->n, n_l = ed ? ed->n : 0;
     const unsigned hw = std::thread::hardware_concurrency();
-    const int T = n_s + n_l < 200000 ? 1 : (int)std::min<u64>(8, std::max<unsigned>(1, hw));
+    const int T = n_s + n_l < 200000 ? 1 : (int)std::min<u64>(16, std::max<unsigned>(1, hw));
     std::vector<std::string> s_part((size_t)T), l_part((size_t)T);
     auto fmt = [&](int t) {
         const u64 s0 = n_s * (u64)t / (u64)T, s1 = n_s * (u64)(t + 1) / (u64)T, l0 = n_l * (u64)t / (u64)T, l1 = n_l * (u64)(t + 1) / (u64)T;
@@ -272,6 +277,29 @@ int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nd, const mdbg_edges
         for (int t = 1; t < T; ++t) th.emplace_back(fmt, t);
         fmt(0);
         for (auto& x : th) x.join();
+    }
+    struct stat fst;
+    if (T > 1 && fstat(fileno(f), &fst) == 0 && S_ISREG(fst.st_mode)) {
+        // a regular file: every thread writes its parts at their places (the copy into the page cache was 10 of the 19 ms of this call for 465 k nodes + 910 k edges)
+        std::vector<u64> at(2 * (size_t)T + 1, 11);
+        for (int t = 0; t < T; ++t) at[(size_t)t + 1] = at[(size_t)t] + s_part[(size_t)t].size();
+        for (int t = 0; t < T; ++t) at[(size_t)T + t + 1] = at[(size_t)T + t] + l_part[(size_t)t].size();
+        std::atomic<int> bad{0};
+        const int fd = fileno(f);
+        auto put = [&](const char* p, size_t n, u64 off) {
+            while (n) { const ssize_t w = pwrite(fd, p, n, (off_t)off); if (w < 0 && errno == EINTR) continue; if (w <= 0) { bad.store(1); return; } p += w; n -= (size_t)w; off += (u64)w; }
+        };
+        auto wr = [&](int t) {
+            if (t == 0) put("H\tVN:Z:1.0\n", 11, 0);                                                // main.rs:1011
+            put(s_part[(size_t)t].data(), s_part[(size_t)t].size(), at[(size_t)t]);
+            put(l_part[(size_t)t].data(), l_part[(size_t)t].size(), at[(size_t)T + t]);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(wr, t);
+        wr(0);
+        for (auto& x : th) x.join();
+        const bool okc = fclose(f) == 0;
+        return okc && !bad.load() ? MDBG_OK : MDBG_E_IO;
     }
     bool ok = fwrite("H\tVN:Z:1.0\n", 1, 11, f) == 11;                                              // main.rs:1011
     for (int t = 0; ok && t < T; ++t) ok = s_part[(size_t)t].empty() || fwrite(s_part[(size_t)t].data(), 1, s_part[(size_t)t].size(), f) == s_part[(size_t)t].size();
@@ -305,6 +333,7 @@ static inline void put_u64s(std::string& out, u64 v) {
 // the lines of the nodes i with i % n_parts == part whose A-th sighting lies in this batch
 static int seqfile_write_part(mdbg_seqfile* s, const mdbg_nodes* nd, uint32_t part, uint32_t n_parts, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t first) {
     if (!s || !nd || !offsets || (n_reads && !bases && offsets[n_reads]) || !n_parts || part >= n_parts) return MDBG_E_PARAM;
+    if (nd->n && (!nd->keys || !nd->src_read || !nd->src_start || !nd->src_end || !nd->reversed || !nd->shift_full || !nd->index)) return MDBG_E_PARAM;      // a table of mdbg_finalize_gfa
     const u32 k = nd->k;
     for (u64 i = part; i < nd->n; i += n_parts) {
         const u64 r = nd->src_read[i];
@@ -448,25 +477,37 @@ struct Lz4In {
 // A pool of worker threads that lives as long as its reader: run(f) executes f(0) .. f(n - 1), f(0) on the caller.  (std::thread per batch and stage: 64 threads x 3
 // stages x ~40 us of spawn + join per 256-Mbase batch was a third of the reader's time at 64 threads, profiles/r04_n_file_pipeline.json -> r05_file_pipeline.json.)
 struct WorkerPool {
-    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv_go, cv_done;
-    const std::function<void(int)>* job = nullptr; u64 epoch = 0; int pending = 0, n = 1; bool quit = false;
+    // A window of the reader is 2 - 3 ms of work for all threads, so how a round starts and ends matters: the round number and the count of workers still busy are
+    // atomics; a worker that has finished spins on the round number for a moment (the next window usually follows at once) before it goes to sleep on the condition
+    // variable, and the caller spins on the busy count (it was a second condition variable: 63 woken workers queueing for one mutex twice per round).
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv_go;
+    const std::function<void(int)>* job = nullptr; std::atomic<u64> epoch{0}; std::atomic<int> pending{0}; int n = 1; std::atomic<int> sleepers{0}; bool quit = false;
     explicit WorkerPool(int n_) : n(std::max(1, n_)) {
         for (int i = 1; i < n; ++i) th.emplace_back([this, i] {
             u64 seen = 0;
             for (;;) {
-                const std::function<void(int)>* f;
-                { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return quit || epoch != seen; }); if (quit) return; seen = epoch; f = job; }
-                (*f)(i);
-                { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+                bool got = false;
+                for (int spin = 0; spin < 20000 && !got; ++spin) { if (epoch.load(std::memory_order_acquire) != seen) got = true; else __builtin_ia32_pause(); }
+                if (!got) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleepers.fetch_add(1, std::memory_order_relaxed);
+                    cv_go.wait(lk, [&] { return quit || epoch.load(std::memory_order_acquire) != seen; });
+                    sleepers.fetch_sub(1, std::memory_order_relaxed);
+                    if (quit) return;
+                }
+                seen = epoch.load(std::memory_order_acquire);
+                (*job)(i);
+                pending.fetch_sub(1, std::memory_order_acq_rel);
             }
         });
     }
     void run(const std::function<void(int)>& f) {
         if (n == 1) { f(0); return; }
-        { std::lock_guard<std::mutex> lk(mu); job = &f; pending = n - 1; ++epoch; }
-        cv_go.notify_all();
+        job = &f; pending.store(n - 1, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(mu); epoch.fetch_add(1, std::memory_order_release); }      // (under the mutex: a worker between its predicate and its sleep cannot miss it)
+        if (sleepers.load(std::memory_order_relaxed)) cv_go.notify_all();
         f(0);
-        std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return pending == 0; });
+        for (u32 spin = 0; pending.load(std::memory_order_acquire) != 0; ++spin) { if (spin < 4096) __builtin_ia32_pause(); else sched_yield(); }
     }
     ~WorkerPool() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
 };
@@ -483,6 +524,15 @@ struct mdbg_reader {
     const u8* data() const { return mem ? mem : buf.data(); }
     // whole-file mapping of an uncompressed input read by several threads (mdbg_reader_open_mt); cur = first unread byte
     const u8* map = nullptr; size_t map_size = 0, map_cur = 0; int threads = 1;
+    int fd = -1;                                              // the mapped file, kept open: the fast path READS its chunks (pread into a buffer that stays in L2) instead of touching the mapping
+    std::vector<std::vector<u8>> chunk_buf;                   // one per worker
+    // the batch buffers handed to the caller (big / big2 / pw / pw2) come from here: malloc / free unless mdbg_reader_set_allocator named something else
+    // (mdbg_host_alloc of libmdbg_hip.so: buffers the ingest calls page-lock, so the copy to the device is one DMA instead of a staged memcpy)
+    void* (*alloc_fn)(size_t) = nullptr; void (*free_fn)(void*) = nullptr;
+    void* buf_alloc(size_t n) { return alloc_fn ? alloc_fn(n) : malloc(n); }
+    void buf_free(void* p) { if (!p) return; if (free_fn) free_fn(p); else free(p); }
+    bool grow_big(size_t bytes) { if (bytes <= big_cap) return true; buf_free(big); big_cap = bytes; big = (u8*)buf_alloc(big_cap); if (!big) big_cap = 0; return big != nullptr; }
+    bool grow_pw(size_t words) { if (words <= pw_cap) return true; buf_free(pw); pw_cap = words; pw = (u64*)buf_alloc(pw_cap * 8); if (!pw) pw_cap = 0; return pw != nullptr; }
     u8* big = nullptr; size_t big_cap = 0;                    // batch buffer of the parallel path (not zero-filled like a vector)
     u8* big2 = nullptr; size_t big2_cap = 0; std::vector<u64> offs2;      // ... the previous batch: the parallel path alternates two buffers, so a
                                                               // batch stays valid while the next one is being read (a packer thread can work on it)
@@ -654,7 +704,7 @@ size_t next_record_start(const u8* m, size_t n, size_t p, bool fasta) {
 
 // the fast path (defined behind the packer): 1 = the batch is complete (offsets, and the ASCII copy or the packed words), 0 = a record of the window needs the
 // general parser (FASTA sequence over several lines, --reference stripping, stray lines), < 0 = error
-static int reader_fast_window(mdbg_reader* r, const std::vector<size_t>& cut, bool ascii_out);
+static int reader_fast_window(mdbg_reader* r, size_t w0, size_t w1, int T, bool ascii_out);
 // ascii_out: the sequences are copied side by side into r->big; otherwise they stay in the per-thread pieces (mdbg_reader_next_packed
 // packs them from there) and only the offsets are laid out
 static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_out = true) {
@@ -665,18 +715,21 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_o
     size_t end = r->map_cur + std::max<size_t>(window, 1) >= n ? n : next_record_start(m, n, r->map_cur + std::max<size_t>(window, 1), r->fasta);
     if (end <= r->map_cur) end = n;
     const int T = std::max(1, r->threads);
+    r->packed_done = false;
+    {
+        static const bool no_fast = getenv("MDBG_READER_NO_FAST") != nullptr;      // (A/B switch and test hook: the general parser on every window)
+        // (the fast path is bound by memory, not by threads: 16 - 24 of them reach what this host gives — 56 - 76 Gbases/s —, 64 get a third of that, across two
+        // sockets with the page cache on one; profiles/r05_f_reader_threads.json.  MDBG_READER_MAX_WORKERS overrides the cap.)
+        static const int max_workers = [] { const char* e = getenv("MDBG_READER_MAX_WORKERS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 24; }();
+        const int f = no_fast ? 0 : reader_fast_window(r, r->map_cur, end, std::min(T, max_workers), ascii_out);
+        if (f < 0) return f;
+        if (f == 1) { r->map_cur = end; r->unmap_upto(end); return MDBG_OK; }
+    }
     std::vector<size_t> cut(T + 1);
     cut[0] = r->map_cur; cut[T] = end;
     for (int i = 1; i < T; ++i) {
         const size_t guess = r->map_cur + (size_t)((double)(end - r->map_cur) * i / T);
         cut[i] = std::min(end, std::max(cut[i - 1], next_record_start(m, end, guess, r->fasta)));
-    }
-    r->packed_done = false;
-    {
-        static const bool no_fast = getenv("MDBG_READER_NO_FAST") != nullptr;      // (A/B switch and test hook: the general parser on every window)
-        const int f = no_fast ? 0 : reader_fast_window(r, cut, ascii_out);
-        if (f < 0) return f;
-        if (f == 1) { r->map_cur = end; r->unmap_upto(end); return MDBG_OK; }
     }
     r->piece_bases.resize(T); r->piece_lens.resize(T);
     struct PieceRef { std::vector<u8>& bases; std::vector<u64>& lens; };
@@ -697,7 +750,7 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_o
     size_t total = 0, reads = 0;
     std::vector<size_t> base0(T), read0(T);
     for (int i = 0; i < T; ++i) { base0[i] = total; read0[i] = reads; total += pc[i].bases.size(); reads += pc[i].lens.size(); }
-    if (ascii_out && total + 64 > r->big_cap) { free(r->big); r->big_cap = total + total / 8 + 4096; r->big = (u8*)malloc(r->big_cap); if (!r->big) { r->big_cap = 0; return MDBG_E_NOMEM; } }
+    if (ascii_out && total + 64 > r->big_cap && !r->grow_big(total + total / 8 + 4096)) return MDBG_E_NOMEM;
     r->offs.resize(reads + 1);
     auto place = [&](int i) {
         if (ascii_out && !pc[i].bases.empty()) memcpy(r->big + base0[i], pc[i].bases.data(), pc[i].bases.size());
@@ -778,6 +831,12 @@ static int reader_next_window(mdbg_reader* r, uint64_t max_bases, bool ascii_out
 }
 
 int mdbg_reader_is_fasta(const mdbg_reader* r) { return r && r->fasta ? 1 : 0; }
+int mdbg_reader_set_allocator(mdbg_reader* r, void* (*alloc_fn)(size_t), void (*free_fn)(void*)) {
+    if (!r || !alloc_fn != !free_fn) return MDBG_E_PARAM;
+    if (r->big || r->big2 || r->pw || r->pw2) return MDBG_E_STATE;      // before the first batch: a buffer goes back where it came from
+    r->alloc_fn = alloc_fn; r->free_fn = free_fn;
+    return MDBG_OK;
+}
 int mdbg_reader_is_parallel(const mdbg_reader* r) { return r && r->map ? 1 : 0; }
 
 mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err) {
@@ -803,8 +862,8 @@ mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threa
     u8 magic[2] = {0, 0};
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2 || pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) { close(fd); return r; }
     void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (mp == MAP_FAILED) return r;
+    if (mp == MAP_FAILED) { close(fd); return r; }
+    r->fd = fd;
     // (no MADV_SEQUENTIAL: the fast path reads every window twice — the scan, then the pack / copy — and that advice lets the kernel drop the pages in between)
     r->map = (const u8*)mp; r->map_size = (size_t)st.st_size; r->map_cur = 0; r->threads = threads;
     return r;
@@ -834,7 +893,25 @@ int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, 
     return r->io_error ? MDBG_E_IO : MDBG_OK;                // a malformed / truncated compressed stream
 }
 
-void mdbg_reader_close(mdbg_reader* r) { if (r) { delete r->pool; if (r->gzin) delete r->gzin; if (r->gz_map) munmap((void*)r->gz_map, r->gz_size); r->unmap_finish(); free(r->gw); free(r->big); free(r->big2); free(r->pw); free(r->pw2); if (r->f) gzclose(r->f); if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; } delete r; } }
+void mdbg_reader_close(mdbg_reader* r) {
+    if (!r) return;
+    static const bool timing = getenv("MDBG_READER_TIMING") != nullptr;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+    const double t0 = timing ? now() : 0;
+    delete r->pool;
+    const double t1 = timing ? now() : 0;
+    if (r->fd >= 0) close(r->fd);
+    if (r->gzin) delete r->gzin;
+    if (r->gz_map) munmap((void*)r->gz_map, r->gz_size);
+    r->unmap_finish();
+    const double t2 = timing ? now() : 0;
+    free(r->gw); r->buf_free(r->big); r->buf_free(r->big2); r->buf_free(r->pw); r->buf_free(r->pw2);
+    const double t3 = timing ? now() : 0;
+    if (r->f) gzclose(r->f);
+    if (r->lz) { if (r->lz->f) fclose(r->lz->f); delete r->lz; }
+    delete r;
+    if (timing) fprintf(stderr, "[mdbg reader] close: workers %.2f ms, unmap %.2f, batch buffers %.2f, the rest %.2f\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
+}
 
 }  // extern "C"
 
@@ -913,7 +990,7 @@ void pack_piece(const u8* src, u64 B, u64 E, u64* words, ExcList& ex, std::vecto
 int reader_pack_pieces(mdbg_reader* r, u64 total) {
     const size_t T = r->piece_bases.size();
     const u64 nw = (total + 31) / 32;
-    if (nw + 8 > r->pw_cap) { free(r->pw); r->pw_cap = nw + nw / 8 + 64; r->pw = (u64*)malloc(r->pw_cap * 8); if (!r->pw) { r->pw_cap = 0; return MDBG_E_NOMEM; } }
+    if (nw + 8 > r->pw_cap && !r->grow_pw(nw + nw / 8 + 64)) return MDBG_E_NOMEM;
     const bool avx2 = __builtin_cpu_supports("avx2");
     std::vector<u64> base0(T + 1, 0);
     for (size_t i = 0; i < T; ++i) base0[i + 1] = base0[i] + r->piece_bases[i].size();
@@ -974,49 +1051,104 @@ bool scan_piece(const u8* m, size_t a, size_t b, size_t file_end, bool fasta, bo
     return true;
 }
 }  // namespace
-static int reader_fast_window(mdbg_reader* r, const std::vector<size_t>& cut, bool ascii_out) {
-    const int T = (int)cut.size() - 1;
+static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, const int T, bool ascii_out) {
+    // One pass over the text.  The window is taken in CHUNKS of ~256 KB (cut at record starts) that the workers claim in file order; a worker locates the records of its
+    // chunk (stage A), waits until the chunk in front has published where its own records go in the batch (a running sum of bases and records handed down the
+    // chunks: the workers in front were started earlier on equally sized chunks, so the wait is short), publishes the sum for the next chunk, and packs / copies
+    // its records (stage B) while the chunk's text is still in its L2.  (The first version of this path ran stage A over the whole window, then stage B over the
+    // whole window: every byte came from DRAM twice.)  The batch buffer is sized BEFORE the scan from a bound: a base is at least one byte of a FASTA text,
+    // two of a FASTQ text (a record that breaks the bound sends the window to the general parser).
+    // A chunk's text is READ (pread into the worker's buffer), not touched through the mapping: 16 threads walking a mapping of page-cache pages take a minor fault
+    // per 16 pages and get 53 - 62 GB/s out of this host, the same threads reading into 256-KB buffers 210 - 244 (scratch/ubench/mmap_vs_pread.cpp,
+    // profiles/r05_f_mmap_vs_pread.txt); the mapping is still what the chunk boundaries are looked up in (a few pages per chunk) and what the general parser walks.
     const u8* m = r->map;
+    const bool by_read = r->fd >= 0 && !r->gw_mode;
+    if (r->chunk_buf.size() < (size_t)T) r->chunk_buf.resize((size_t)T);
     if (!r->pool || r->pool->n != T) { delete r->pool; r->pool = new WorkerPool(T); }
-    r->fast_recs.resize((size_t)T);
-    std::vector<u64> nb((size_t)T, 0); std::vector<u8> ok((size_t)T, 1);
+    static const size_t chunk_bytes = [] { const char* e = getenv("MDBG_READER_CHUNK_BYTES"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)256 << 10; }();      // (tests: chunks of a few bytes)
+    const size_t C = std::max<size_t>(1, (w1 - w0 + chunk_bytes - 1) / chunk_bytes);
+    const u64 cap_bases = r->fasta ? (u64)(w1 - w0) : (u64)(w1 - w0) / 2 + 4096;
+    if (ascii_out) { if (cap_bases + 64 > r->big_cap && !r->grow_big(cap_bases + cap_bases / 64 + (64u << 10))) return MDBG_E_NOMEM; }
+    else { const u64 nwb = (cap_bases + 31) / 32; if (nwb + 8 > r->pw_cap && !r->grow_pw(nwb + nwb / 64 + 1024)) return MDBG_E_NOMEM; }
+    if (r->fast_recs.size() < C) r->fast_recs.resize(C);
+    // one cache line per link of the chain (flag + the two sums): the workers behind spin on THEIR link only, a publication moves one line once
+    struct alignas(64) Link { std::atomic<u32> ready; u64 base0, read0; };
+    std::unique_ptr<Link[]> link(new Link[C + 1]);
+    for (size_t c = 0; c <= C; ++c) { link[c].ready.store(c == 0 ? 1u : 0u, std::memory_order_relaxed); link[c].base0 = link[c].read0 = 0; }
+    std::atomic<size_t> next_chunk{0};
+    std::atomic<int> bad{0}, io_bad{0};
+    const bool avx2 = __builtin_cpu_supports("avx2");
+    std::vector<ExcList> ex((size_t)T); std::vector<std::vector<Partial>> parts((size_t)T);
     static const bool timing = getenv("MDBG_READER_TIMING") != nullptr;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
     const double t0 = timing ? now() : 0;
-    const std::function<void(int)> scan = [&](int i) { ok[(size_t)i] = scan_piece(m, cut[(size_t)i], cut[(size_t)i + 1], cut[(size_t)T], r->fasta, r->strip, r->fast_recs[(size_t)i], nb[(size_t)i]) ? 1 : 0; };
-    r->pool->run(scan);
-    const double t1 = timing ? now() : 0;
-    for (int i = 0; i < T; ++i) if (!ok[(size_t)i]) return 0;
-    std::vector<u64> base0((size_t)T + 1, 0), read0((size_t)T + 1, 0);
-    for (int i = 0; i < T; ++i) { base0[(size_t)i + 1] = base0[(size_t)i] + nb[(size_t)i]; read0[(size_t)i + 1] = read0[(size_t)i] + r->fast_recs[(size_t)i].size(); }
-    const u64 total = base0[(size_t)T], reads = read0[(size_t)T];
-    r->offs.resize(reads + 1);
-    const u64 nw = (total + 31) / 32;
-    if (ascii_out) { if (total + 64 > r->big_cap) { free(r->big); r->big_cap = total + total / 8 + 4096; r->big = (u8*)malloc(r->big_cap); if (!r->big) { r->big_cap = 0; return MDBG_E_NOMEM; } } }
-    else if (nw + 8 > r->pw_cap) { free(r->pw); r->pw_cap = nw + nw / 8 + 64; r->pw = (u64*)malloc(r->pw_cap * 8); if (!r->pw) { r->pw_cap = 0; return MDBG_E_NOMEM; } }
-    const bool avx2 = __builtin_cpu_supports("avx2");
-    std::vector<ExcList> ex((size_t)T); std::vector<std::vector<Partial>> parts((size_t)T);
-    const std::function<void(int)> place = [&](int i) {
-        u64 o = base0[(size_t)i]; size_t j = read0[(size_t)i];
-        for (const mdbg_reader::FastRec& q : r->fast_recs[(size_t)i]) {
-            r->offs[j++] = o;
-            if (q.len) { if (ascii_out) memcpy(r->big + o, m + q.off, q.len); else pack_piece(m + q.off, o, o + q.len, r->pw, ex[(size_t)i], parts[(size_t)i], avx2); }
-            o += q.len;
+    std::vector<double> waited((size_t)T, 0.0);
+    const std::function<void(int)> work = [&](int i) {
+        for (;;) {
+            const size_t c = next_chunk.fetch_add(1, std::memory_order_relaxed);
+            if (c >= C || bad.load(std::memory_order_relaxed)) return;
+            const size_t a = c == 0 ? w0 : next_record_start(m, w1, w0 + c * chunk_bytes, r->fasta), b = c + 1 == C ? w1 : next_record_start(m, w1, w0 + (c + 1) * chunk_bytes, r->fasta);
+            std::vector<mdbg_reader::FastRec>& recs = r->fast_recs[c];
+            u64 nb = 0;
+            const u8* mc = m;                                      // base pointer under which this chunk's bytes [a, b) are found at their file offsets
+            if (by_read && a < b) {
+                std::vector<u8>& tb = r->chunk_buf[(size_t)i];
+                if (tb.size() < b - a) tb.resize(b - a + (b - a) / 4);
+                size_t got = 0;
+                while (got < b - a) { const ssize_t n = pread(r->fd, tb.data() + got, b - a - got, (off_t)(a + got)); if (n <= 0) { if (n < 0 && errno == EINTR) continue; break; } got += (size_t)n; }
+                if (got < b - a) { io_bad.store(1, std::memory_order_relaxed); bad.store(1, std::memory_order_relaxed); return; }      // (the file shrank under the mapping)
+                mc = tb.data() - a;
+            }
+            const bool ok = a >= b ? (recs.clear(), true) : scan_piece(mc, a, b, w1, r->fasta, r->strip, recs, nb);
+            const double tw = timing ? now() : 0;
+            for (u32 spins = 0; !link[c].ready.load(std::memory_order_acquire); ++spins) {
+                if (bad.load(std::memory_order_relaxed)) return;
+                if (spins < 4096) __builtin_ia32_pause(); else sched_yield();
+            }
+            if (timing) waited[(size_t)i] += now() - tw;
+            if (!ok || link[c].base0 + nb > cap_bases) { bad.store(1, std::memory_order_relaxed); return; }
+            link[c + 1].base0 = link[c].base0 + nb; link[c + 1].read0 = link[c].read0 + recs.size();
+            link[c + 1].ready.store(1, std::memory_order_release);
+            u64 o = link[c].base0;
+            for (const mdbg_reader::FastRec& q : recs) {
+                if (q.len) { if (ascii_out) memcpy(r->big + o, mc + q.off, q.len); else pack_piece(mc + q.off, o, o + q.len, r->pw, ex[(size_t)i], parts[(size_t)i], avx2); }
+                o += q.len;
+            }
         }
     };
-    const double t2 = timing ? now() : 0;
-    r->pool->run(place);
-    const double t3 = timing ? now() : 0;
+    r->pool->run(work);
+    if (io_bad.load()) { r->io_error = true; return MDBG_E_IO; }
+    if (bad.load()) return 0;
+    const double t1 = timing ? now() : 0;
+    const u64 total = link[C].base0, reads = link[C].read0;
+    r->offs.resize(reads + 1);
+    const std::function<void(int)> lay = [&](int i) {
+        for (size_t c = (size_t)i; c < C; c += (size_t)T) { u64 o = link[c].base0; size_t j = link[c].read0; for (const mdbg_reader::FastRec& q : r->fast_recs[c]) { r->offs[j++] = o; o += q.len; } }
+    };
+    if (reads > 200000) r->pool->run(lay); else for (int i = 0; i < T; ++i) lay(i);
     r->offs[reads] = total;
     if (!ascii_out) {
         for (int i = 0; i < T; ++i) for (const Partial& q : parts[(size_t)i]) r->pw[q.word] = 0;       // words shared by records: clear, then OR the contributions
         for (int i = 0; i < T; ++i) for (const Partial& q : parts[(size_t)i]) r->pw[q.word] |= (u64)q.lo | ((u64)q.hi << 32);
+        // the exception list in ascending position order: a worker's chunks are in file order, the workers' lists interleave
         r->pexc_pos.clear(); r->pexc_val.clear();
-        for (int i = 0; i < T; ++i) { r->pexc_pos.insert(r->pexc_pos.end(), ex[(size_t)i].pos.begin(), ex[(size_t)i].pos.end()); r->pexc_val.insert(r->pexc_val.end(), ex[(size_t)i].val.begin(), ex[(size_t)i].val.end()); }
+        size_t n_exc = 0; int lists = 0;
+        for (int i = 0; i < T; ++i) { n_exc += ex[(size_t)i].pos.size(); lists += ex[(size_t)i].pos.empty() ? 0 : 1; }
+        if (lists == 1) { for (int i = 0; i < T; ++i) if (!ex[(size_t)i].pos.empty()) { r->pexc_pos.swap(ex[(size_t)i].pos); r->pexc_val.swap(ex[(size_t)i].val); } }
+        else if (lists > 1) {
+            std::vector<std::pair<u64, u8>> all; all.reserve(n_exc);
+            for (int i = 0; i < T; ++i) for (size_t e = 0; e < ex[(size_t)i].pos.size(); ++e) all.emplace_back(ex[(size_t)i].pos[e], ex[(size_t)i].val[e]);
+            std::sort(all.begin(), all.end());
+            r->pexc_pos.resize(n_exc); r->pexc_val.resize(n_exc);
+            for (size_t e = 0; e < n_exc; ++e) { r->pexc_pos[e] = all[e].first; r->pexc_val[e] = all[e].second; }
+        }
         r->packed_done = true;
     }
-    if (timing) fprintf(stderr, "[mdbg reader] window %.1f MB, %d threads: scan %.2f ms, layout %.2f, %s %.2f, merge %.2f\n", (double)(cut[(size_t)T] - cut[0]) / 1e6, T, t1 - t0, t2 - t1,
-                        ascii_out ? "copy" : "pack", t3 - t2, now() - t3);
+    if (timing) {
+        double wsum = 0; for (double w : waited) wsum += w;
+        fprintf(stderr, "[mdbg reader] window %.1f MB, %d threads, %zu chunks: scan + %s %.2f ms (waiting for the chunk in front: %.2f ms per thread), offsets + merge %.2f\n", (double)(w1 - w0) / 1e6, T, C,
+                ascii_out ? "copy" : "pack", t1 - t0, wsum / T, now() - t1);
+    }
     return 1;
 }
 
@@ -1038,7 +1170,7 @@ int mdbg_reader_next_packed(mdbg_reader* r, uint64_t max_bases, mdbg_packed_batc
         r->offs.swap(r->offs2);                                // the offsets handed out last stay intact during this call
         int e = mdbg_reader_next(r, max_bases, &b, &o, &n); if (e) return e;
         const u64 total = r->offs.back(), nw = (total + 31) / 32;
-        if (nw + 8 > r->pw_cap) { free(r->pw); r->pw_cap = nw + nw / 8 + 64; r->pw = (u64*)malloc(r->pw_cap * 8); if (!r->pw) { r->pw_cap = 0; return MDBG_E_NOMEM; } }
+        if (nw + 8 > r->pw_cap && !r->grow_pw(nw + nw / 8 + 64)) return MDBG_E_NOMEM;
         ExcList ex;
         pack_range(b, total, 0, nw, r->pw, ex, __builtin_cpu_supports("avx2"));
         r->pexc_pos.swap(ex.pos); r->pexc_val.swap(ex.val);

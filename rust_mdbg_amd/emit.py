@@ -50,12 +50,14 @@ class NodeTable:
     """host node table (dict of numpy arrays as returned by Mdbg.finalize) viewed as a C `mdbg_nodes`"""
 
     def __init__(self, nodes):
-        self.keep = {f: np.ascontiguousarray(nodes[f], dtype=t) for f, t in (
+        # (a table from Mdbg.finalize(gfa_only=True) holds index / seqlen / abundance only: the other pointers are null, write_gfa reads none of them)
+        self.keep = {f: (None if nodes.get(f) is None else np.ascontiguousarray(nodes[f], dtype=t)) for f, t in (
             ("keys", np.uint64), ("index", np.uint32), ("abundance", np.uint16), ("seqlen", np.uint32), ("shift", np.uint16),
             ("shift_full", np.uint64), ("src_read", np.uint64), ("src_start", np.uint64), ("src_end", np.uint64), ("reversed", np.uint8))}
-        k = self.keep["keys"].shape[1] if self.keep["keys"].ndim == 2 else int(nodes.get("k", 0))
+        self.gfa_only = self.keep["keys"] is None
+        k = self.keep["keys"].shape[1] if (not self.gfa_only and self.keep["keys"].ndim == 2) else int(nodes.get("k", 0))
         n = len(self.keep["index"])
-        P = lambda f, t: self.keep[f].ctypes.data_as(C.POINTER(t))
+        P = lambda f, t: self.keep[f].ctypes.data_as(C.POINTER(t)) if self.keep[f] is not None else None
         self.c = Nodes(n=n, k=k, keys=P("keys", C.c_uint64), index=P("index", C.c_uint32), abundance=P("abundance", C.c_uint16),
                        seqlen=P("seqlen", C.c_uint32), shift=P("shift", C.c_uint16), shift_full=P("shift_full", C.c_uint64),
                        src_read=P("src_read", C.c_uint64), src_start=P("src_start", C.c_uint64), src_end=P("src_end", C.c_uint64),
@@ -71,6 +73,8 @@ class Emitter:
     def edges(self, nodes, presimp=0.01):
         """-> dict(n1, o1, n2, o2, overlap, presimp_removed) — the L-lines of the graph"""
         self.nt = nodes if isinstance(nodes, NodeTable) else NodeTable(nodes)
+        if self.nt.gfa_only:
+            raise ValueError("a gfa_only node table holds no minimizer lists: edges come from Mdbg.graph_edges")
         e = Edges()
         rc = self.L.mdbg_emit_edges(self.h, C.byref(self.nt.c), presimp, C.byref(e))
         if rc:
@@ -91,6 +95,8 @@ class Emitter:
     def write_sequences(self, path, nodes, l, batches):
         """batches: iterable of (bases u8 array, offsets u64 array, first_read_ordinal) — what was ingested"""
         nt = nodes if isinstance(nodes, NodeTable) else NodeTable(nodes)
+        if nt.gfa_only:
+            raise ValueError("a gfa_only node table cannot be written as .sequences")
         err = C.c_int()
         f = self.L.mdbg_seqfile_open(path.encode(), nt.c.k, l, C.byref(err))
         if not f:
@@ -112,6 +118,8 @@ class Emitter:
         threads: every batch is handed to all of them, thread t writes the lines of the nodes i with i % threads == t.  -> the paths"""
         from concurrent.futures import ThreadPoolExecutor
         nt = nodes if isinstance(nodes, NodeTable) else NodeTable(nodes)
+        if nt.gfa_only:
+            raise ValueError("a gfa_only node table cannot be written as .sequences")
         paths = ["%s.%d.sequences" % (prefix, t) for t in range(threads)]
         files, err = [], C.c_int()
         try:
@@ -149,14 +157,16 @@ class Emitter:
 
 # ---- host ingest (include/mdbg_emit.h: mdbg_reader_*) -----------------------------------------------------
 READER_EXPORTS = ["mdbg_reader_open", "mdbg_reader_open_mt", "mdbg_reader_next", "mdbg_reader_next_packed", "mdbg_reader_is_fasta", "mdbg_reader_is_parallel",
-                  "mdbg_reader_close"]
+                  "mdbg_reader_set_allocator", "mdbg_reader_close"]
 
 
 class Reader:
     """FASTA/FASTQ(.gz) -> batches in the layout of Mdbg.ingest; format by file name like src/main.rs:461-467"""
 
-    def __init__(self, path, strip_newlines=False, threads=1):
-        """threads > 1: uncompressed files are mapped and parsed by that many threads (mdbg_reader_open_mt)"""
+    def __init__(self, path, strip_newlines=False, threads=1, device_buffers=False):
+        """threads > 1: uncompressed files are mapped and parsed by that many threads (mdbg_reader_open_mt).
+        device_buffers: the batch buffers come from mdbg_host_alloc of libmdbg_hip.so (page-locked by the first ingest call that sees them: the copy to the
+        device is one DMA); needs the GPU library, so only a caller that ingests asks for it"""
         L = load_library()
         L.mdbg_reader_open.restype = C.c_void_p
         L.mdbg_reader_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
@@ -172,6 +182,13 @@ class Reader:
         if not self.h:
             raise OSError("cannot open %s (err %d)" % (path, err.value))
         self.is_fasta = bool(L.mdbg_reader_is_fasta(self.h))
+        if device_buffers:
+            from .api import load_library as load_hip
+            H = load_hip()
+            L.mdbg_reader_set_allocator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            rc = L.mdbg_reader_set_allocator(self.h, C.cast(H.mdbg_host_alloc, C.c_void_p), C.cast(H.mdbg_host_free, C.c_void_p))
+            if rc:
+                raise RuntimeError("mdbg_reader_set_allocator failed: %d" % rc)
         L.mdbg_reader_is_parallel.argtypes = [C.c_void_p]
         self.parallel = bool(L.mdbg_reader_is_parallel(self.h))      # True: batches(copy=False) views stay valid while the NEXT batch is read
 

@@ -43,7 +43,7 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
 
     def produce():
         try:
-            with Reader(path, strip_newlines, threads=threads) as r:
+            with Reader(path, strip_newlines, threads=threads, device_buffers=True) as r:
                 if packed:
                     # the reader packs while it parses (mdbg_reader_next_packed); batch i+1 is produced while batch i is ingested
                     it = r.batches_packed(batch_bases, copy=False)
@@ -57,8 +57,7 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                         if not put((pk, None, pk["n_bases"])):
                             return
                     put(None)
-                    while not stop.is_set():      # the reader's buffers must outlive the last batch's ingest: wait until the consumer is done
-                        time.sleep(0.005)
+                    stop.wait()                   # the reader's buffers must outlive the last batch's ingest: wait until the consumer is done
                     return
                 if r.parallel:
                     # ASCII batches of the parallel reader are views into its two alternating buffers: no copy, at most two outstanding (as the packed ones);
@@ -74,8 +73,7 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                         if not put((item[0], item[1].copy(), len(item[0]))):
                             return
                     put(None)
-                    while not stop.is_set():
-                        time.sleep(0.005)
+                    stop.wait()
                     return
                 for bases, offs in r.batches(batch_bases):
                     if not put((bases, offs, len(bases))):
@@ -109,7 +107,9 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
                 n_reads += (len(payload["offsets"]) if packed else len(offs)) - 1
                 n_bases += nb
             tm["ingest"] = time.perf_counter() - t0
-            nodes = m.finalize()
+            # without the .sequences pass the host needs three columns of the node table (the S lines); the minimizer lists stay on the device, where the edge
+            # stage reads them (the full copy-out was 150 MB for 465 k nodes: 40 ms of a 190-ms run)
+            nodes = m.finalize(gfa_only=not write_sequences)
             stats = m.stats()
             tm["finalize"] = time.perf_counter() - t0
             # edges on the GPU from the device-resident node table (the reference's single-threaded loop, src/main.rs:1017-1117);
@@ -120,9 +120,11 @@ def run_file(path, prefix, k, l, density, min_abundance=2, reads_already_hpc=Fal
             em = Emitter()
             em.write_gfa(prefix + ".gfa", nodes, raw)
             tm["gfa"] = time.perf_counter() - t0
+        tm["close"] = time.perf_counter() - t0
     finally:
         stop.set()                          # error or not: release the reader (it closes the file) and wait for it
         th.join()
+    tm["reader_closed"] = time.perf_counter() - t0
     if write_sequences:                              # second pass over the input for the node sequences
         def again():
             first = 0

@@ -21,9 +21,9 @@ out = {}
 pipeline.run_file(path, "/tmp/out", K, Lm, Dn, 2, write_sequences=False)          # warm-up (library load, page cache)
 for label, kw in (("1 reader thread, ASCII batches", dict(threads=1)), ("1 thread, packed batches", dict(threads=1, packed=True)),
                   ("16 threads, packed batches", dict(threads=16)), ("32 threads, packed batches", dict(threads=32)), ("64 threads, packed batches", dict(threads=64)),
-                  ("64 threads, ASCII batches", dict(threads=64, packed=False))):
+                  ("16 threads, ASCII batches", dict(threads=16, packed=False)), ("32 threads, ASCII batches", dict(threads=32, packed=False)), ("64 threads, ASCII batches", dict(threads=64, packed=False))):
     best = None
-    for rep in range(2):
+    for rep in range(3):
         t = time.perf_counter()
         c = pipeline.run_file(path, "/tmp/out", K, Lm, Dn, 2, write_sequences=False, **kw)
         dt = time.perf_counter() - t

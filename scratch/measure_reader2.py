@@ -7,9 +7,9 @@ from rust_mdbg_amd import emit as E
 from rust_mdbg_amd.api import PackedBatch
 n, ln = int(sys.argv[1]) if len(sys.argv) > 1 else 40000, 15000
 ths = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 4, 8]
-path = "/tmp/mr2_reads_%d.fa" % n
+path = os.environ.get("MR2_PATH") or "/tmp/mr2_reads_%d.fa" % n      # MR2_PATH: an existing FASTA (e.g. the one measure_file_pipeline.py wrote)
 rng = np.random.default_rng(1)
-if not os.path.exists(path) or os.path.getsize(path) < n * ln:
+if not os.environ.get("MR2_PATH") and (not os.path.exists(path) or os.path.getsize(path) < n * ln):
     with open(path, "wb") as f:
         for i in range(0, n, 1000):
             arr = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(1000, ln))]

@@ -243,3 +243,28 @@ def test_large_gfa_written_by_several_threads_is_the_same_text(tmp_path):
     want = ["H\tVN:Z:1.0"] + ["S\t%d\t*\tLN:i:%d\tKC:i:%d" % (nodes["index"][i], nodes["seqlen"][i], nodes["abundance"][i]) for i in range(n)]
     want += ["L\t%d\t%s\t%d\t%s\t%dM" % (n1[i], chr(o1[i]), n2[i], chr(o2[i]), ov[i]) for i in range(m)]
     assert open(p).read() == "\n".join(want) + "\n"
+
+
+def test_a_gfa_only_node_table_is_refused_where_the_minimizer_lists_are_needed(tmp_path):
+    """mdbg_finalize_gfa hands out index / seqlen / abundance and NULL for the rest: write_gfa takes it, the edge builder and the .sequences writer say MDBG_E_PARAM"""
+    import ctypes as C
+    import numpy as np
+    from rust_mdbg_amd import emit as E
+    from rust_mdbg_amd.api import Nodes
+    L = E.load_library()
+    idx, sl, ab = np.array([0, 3], np.uint32), np.array([120, 90], np.uint32), np.array([2, 5], np.uint16)
+    nd = Nodes(n=2, k=5, index=idx.ctypes.data_as(C.POINTER(C.c_uint32)), seqlen=sl.ctypes.data_as(C.POINTER(C.c_uint32)), abundance=ab.ctypes.data_as(C.POINTER(C.c_uint16)))
+    p = str(tmp_path / "g.gfa")
+    assert L.mdbg_emit_write_gfa(p.encode(), C.byref(nd), None) == 0
+    assert open(p).read() == "H\tVN:Z:1.0\nS\t0\t*\tLN:i:120\tKC:i:2\nS\t3\t*\tLN:i:90\tKC:i:5\n"
+    em = E.Emitter()
+    e = E.Edges()
+    assert L.mdbg_emit_edges(em.h, C.byref(nd), C.c_float(0.01), C.byref(e)) == -1
+    err = C.c_int()
+    f = L.mdbg_seqfile_open(str(tmp_path / "x.sequences").encode(), 5, 8, C.byref(err))
+    assert f
+    b, o = np.frombuffer(b"ACGTACGT", np.uint8), np.array([0, 8], np.uint64)
+    assert L.mdbg_seqfile_write_batch(f, C.byref(nd), b.ctypes.data, o.ctypes.data, 1, 0) == -1
+    assert L.mdbg_seqfile_close(f) == 0
+    nd.index = None
+    assert L.mdbg_emit_write_gfa(p.encode(), C.byref(nd), None) == -1

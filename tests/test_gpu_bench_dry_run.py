@@ -10,8 +10,9 @@ import pytest
 from conftest import ROOT
 
 
-def _bench(*flags):
+def _bench(*flags, **extra_env):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -80,3 +81,18 @@ def test_bench_one_rank_through_the_rccl_transport():
     rccl = _bench("--gpus", "1", "--force-dist", *small)
     assert rccl["config"]["comm"] == "rccl" and "RCCL" in rccl["exchange"]["transport"] and rccl["graph"]["partitions_add_up"] is True
     assert rccl["graph"]["nodes"] == one["graph"]["nodes"] and rccl["config"]["batches_per_step"] == 8 and rccl["no_exchange_anchor"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_prints_its_line_when_side_measurements_fail():
+    """everything measured beside the headline (recorded profiles, the ASCII leg, the edge stage, the CPU leg, the anchors) may fail: the line is still
+    printed, with the failure named under side_errors"""
+    every = "pmc_traffic,issue_roofline,sq_counters,ascii_in,edges_after_timed_region,cpu_baseline,n1_same_workload,no_exchange_anchor"
+    j = _bench("--gpus", "1", "--genome-mb", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "5", "--no-scale-anchor", MDBG_BENCH_FAIL_SIDE=every)
+    assert j["value"] > 0 and j["graph"]["nodes"] > 1000 and j["roofline"]["frac"] > 0
+    assert set(j["side_errors"]) == {"pmc_traffic", "issue_roofline", "sq_counters", "ascii_in", "edges_after_timed_region", "cpu_baseline"}
+    assert j["ascii_in"] is None and j["edges_after_timed_region"] is None and j["cpu_baseline"] is None and j["roofline"]["traffic"] is None
+    small = ["--workload", "human", "--genome-mb", "40", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0"]
+    two = _bench("--gpus", "2", "--comm", "host", *small, MDBG_BENCH_FAIL_SIDE=every)
+    assert two["n_gpus"] == 2 and two["value"] > 0 and two["graph"]["partitions_add_up"] is True
+    assert two["no_exchange_anchor"] is None and two["n1_same_workload"] is None and "n1_same_workload" in two["side_errors"]

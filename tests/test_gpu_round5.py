@@ -200,3 +200,89 @@ def test_dist_reset_to_another_k_under_segments(W, chunks, k2):
     S._assert_partitions_equal(parts, ref)
     assert all(t[0] > 0 and t[1] > 0 for t in traffic), traffic          # the new k cost an exchange of its own
     print("bytes received per rank, first k / new k:", traffic)
+
+
+@pytest.mark.gpu
+def test_gfa_without_the_sequences_pass_is_the_same_file(tmp_path):
+    """run_file(write_sequences=False) copies three columns of the node table to the host instead of all of it (Mdbg.finalize(gfa_only=True)): the .gfa is
+    byte for byte the one of the full run, and such a table is refused where the minimizer lists would be needed"""
+    import os
+    from conftest import GOLDEN
+    from rust_mdbg_amd import pipeline
+    from rust_mdbg_amd.emit import Emitter
+    src = os.path.join(GOLDEN, "reads-0.00.fa.gz")
+    full = pipeline.run_file(src, str(tmp_path / "full"), 7, 10, 0.0008, 2, batch_bases=3_000_000)
+    light = pipeline.run_file(src, str(tmp_path / "light"), 7, 10, 0.0008, 2, batch_bases=3_000_000, write_sequences=False, threads=4)
+    assert open(str(tmp_path / "full.gfa"), "rb").read() == open(str(tmp_path / "light.gfa"), "rb").read()
+    assert {f: full[f] for f in full if f != "seconds_until"} == {f: light[f] for f in light if f != "seconds_until"}
+    assert not os.path.exists(str(tmp_path / "light.0.sequences"))
+    import rust_mdbg_amd as R
+    with R.Mdbg(7, 10, 0.0008, 2, device=0) as m:
+        reads = [b"ACGTTGCATGCAGTCAGTCGATGCTAGCTAGTCGATCGATGCATGCTAGCATCGATCGATGCATGC" * 40]
+        from rust_mdbg_amd.api import concat_reads
+        b, o = concat_reads(reads)
+        m.ingest(b, o, 0)
+        nd = m.finalize(gfa_only=True)
+        assert nd["keys"] is None and len(nd["index"]) == nd["n_nodes"] and nd["k"] == 7
+        em = Emitter()
+        with pytest.raises(ValueError):
+            em.edges(nd)
+        with pytest.raises(ValueError):
+            em.write_sequences(str(tmp_path / "x.sequences"), nd, 10, [(b, o, 0)])
+
+
+@pytest.mark.gpu
+def test_reader_batches_are_page_locked_by_the_first_ingest(tmp_path):
+    """mdbg_host_alloc: ordinary memory until an ingest call is given a pointer into it, page-locked from then on (one DMA per batch instead of the staged copy);
+    the graph is the one of a run on malloc'd buffers; memory from elsewhere is not touched"""
+    import random
+    import numpy as np
+    import rust_mdbg_amd as R
+    from rust_mdbg_amd import emit as E
+    from rust_mdbg_amd.api import load_library
+    rnd = random.Random(3)
+    genome = bytes(rnd.choice(b"ACGT") for _ in range(300_000))
+    with open(str(tmp_path / "r.fa"), "wb") as f:
+        for i in range(400):
+            a = rnd.randrange(0, len(genome) - 12_000)
+            f.write(b">r%d\n" % i + genome[a:a + rnd.randrange(6_000, 12_000)] + b"\n")
+    H = load_library()
+    out = {}
+    for mode in ("malloc", "device-packed", "device-ascii"):
+        H.mdbg_release_cached_memory()          # (page-locked allocations are kept for the next reader: start every mode from none)
+        with R.Mdbg(5, 8, 0.01, 2, device=0) as m, E.Reader(str(tmp_path / "r.fa"), threads=4, device_buffers=mode != "malloc") as r:
+            first, seen = 0, []
+            if mode == "device-ascii":
+                for b, o in r.batches(600_000, copy=False):
+                    assert H.mdbg_host_is_pinned(b.ctypes.data) == (1 if b.ctypes.data in seen else 0)
+                    m.ingest(b, o, first)
+                    assert H.mdbg_host_is_pinned(b.ctypes.data) == 1
+                    seen.append(b.ctypes.data); first += len(o) - 1
+            else:
+                for pk in r.batches_packed(600_000, copy=False):
+                    p = pk["words"].ctypes.data
+                    m.ingest_packed(pk, first)
+                    assert H.mdbg_host_is_pinned(p) == (0 if mode == "malloc" else 1)
+                    seen.append(p); first += len(pk["offsets"]) - 1
+            assert len(seen) >= 4 and len(set(seen)) == 2
+            nd = m.finalize()
+            out[mode] = (nd["n_nodes"], nd["keys"].tobytes(), nd["abundance"].tobytes())
+        assert all(H.mdbg_host_is_pinned(p) == 0 for p in seen)          # the reader has given its buffers back
+    assert out["malloc"][0] > 100 and out["malloc"] == out["device-packed"] == out["device-ascii"]
+    q = H.mdbg_host_alloc(1 << 20)
+    assert q and H.mdbg_host_is_pinned(q) == 0
+    H.mdbg_host_free(q)
+    # an allocation that was page-locked is kept for the next request of about its size, still locked
+    with R.Mdbg(5, 8, 0.01, 2, device=0) as m, E.Reader(str(tmp_path / "r.fa"), threads=4, device_buffers=True) as r:
+        pk = next(r.batches_packed(600_000, copy=False))
+        p1 = pk["words"].ctypes.data
+        m.ingest_packed(pk, 0)
+        assert H.mdbg_host_is_pinned(p1) == 1
+    assert H.mdbg_host_is_pinned(p1) == 0
+    with E.Reader(str(tmp_path / "r.fa"), threads=4, device_buffers=True) as r:
+        got = {pk["words"].ctypes.data for pk in r.batches_packed(600_000, copy=False)}
+        assert p1 in got and H.mdbg_host_is_pinned(p1) == 1          # locked before any ingest call has seen it
+    H.mdbg_release_cached_memory()
+    with E.Reader(str(tmp_path / "r.fa"), threads=4, device_buffers=True) as r:
+        pk = next(r.batches_packed(600_000, copy=False))
+        assert H.mdbg_host_is_pinned(pk["words"].ctypes.data) == 0

@@ -465,3 +465,39 @@ def test_ordinary_gzip_with_a_thread_budget(tmp_path):
     p.write_bytes(bytes(bad))
     with pytest.raises(RuntimeError):
         collect(str(p), threads=5)
+
+
+def test_reader_takes_its_batch_buffers_from_the_callers_allocator(tmp_path):
+    """mdbg_reader_set_allocator: the batch buffers of a parallel reader (ASCII bases, packed words) come from the pair of functions the host names (the GPU host names
+    mdbg_host_alloc / mdbg_host_free) and every one of them goes back there at close; the batches are what malloc'd buffers hold; too late after the first batch"""
+    import ctypes as C
+    import random
+    data = random_records(random.Random(11), 300, False, False, False)
+    p = tmp_path / "r.fa"
+    p.write_bytes(data)
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]; libc.free.argtypes = [C.c_void_p]
+    live, sizes = set(), []
+    ALLOC, FREE = C.CFUNCTYPE(C.c_void_p, C.c_size_t), C.CFUNCTYPE(None, C.c_void_p)
+
+    def a(n):
+        q = libc.malloc(n); live.add(q); sizes.append(n); return q
+
+    def f(q):
+        assert q in live; live.discard(q); libc.free(q)
+    a_c, f_c = ALLOC(a), FREE(f)
+    L = E.load_library()
+    L.mdbg_reader_set_allocator.argtypes = [C.c_void_p, ALLOC, FREE]
+    for packed in (False, True):
+        sizes.clear()
+        with E.Reader(str(p), threads=4) as r:
+            assert L.mdbg_reader_set_allocator(r.h, a_c, f_c) == 0
+            got = [(pk["n_bases"], pk["words"].tobytes(), pk["offsets"].tobytes()) for pk in r.batches_packed(40_000)] if packed else [(b.tobytes(), o.tobytes()) for b, o in r.batches(40_000)]
+            assert L.mdbg_reader_set_allocator(r.h, a_c, f_c) == -6          # MDBG_E_STATE: buffers are out
+            assert len(live) == 2 and len(sizes) >= 2                         # two alternating buffers
+        assert not live
+        with E.Reader(str(p), threads=4) as r:
+            ref = [(pk["n_bases"], pk["words"].tobytes(), pk["offsets"].tobytes()) for pk in r.batches_packed(40_000)] if packed else [(b.tobytes(), o.tobytes()) for b, o in r.batches(40_000)]
+        assert got == ref and len(got) > 3
+    with E.Reader(str(p), threads=4) as r:
+        assert L.mdbg_reader_set_allocator(r.h, a_c, C.cast(None, FREE)) == -1   # both or neither
