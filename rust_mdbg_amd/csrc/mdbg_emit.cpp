@@ -719,7 +719,7 @@ static int reader_next_parallel(mdbg_reader* r, uint64_t max_bases, bool ascii_o
     {
         static const bool no_fast = getenv("MDBG_READER_NO_FAST") != nullptr;      // (A/B switch and test hook: the general parser on every window)
         // (the fast path is bound by memory, not by threads: 16 - 24 of them reach what this host gives — 56 - 76 Gbases/s —, 64 get a third of that, across two
-        // sockets with the page cache on one; profiles/r05_f_reader_threads.json.  MDBG_READER_MAX_WORKERS overrides the cap.)
+        // sockets with the page cache on one; profiles/r05_f_reader_threads_before_cap.json.  MDBG_READER_MAX_WORKERS overrides the cap.)
         static const int max_workers = [] { const char* e = getenv("MDBG_READER_MAX_WORKERS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 24; }();
         const int f = no_fast ? 0 : reader_fast_window(r, r->map_cur, end, std::min(T, max_workers), ascii_out);
         if (f < 0) return f;
