@@ -9,7 +9,11 @@
 // the un-vendored third-party crate `nthash` (Cargo.toml:26 `nthash = "*"`, no lockfile; newest
 // release at reference time: 0.5.1).  The oracle is anchored instead on
 //   (1) the nthash crate's published known-answer vectors (tests/test_oracle_kat.py), and
-//   (2) the reference's own call sites, restated line by line below (file:line cited per function).
+//   (2) the reference's own call sites, restated line by line below (file:line cited per function), and
+//   (3) for ONE function something the reference itself produced: encode_rle against the outputs of the reference's Python helper
+//       utils/remove_homopoly.py (the same rule and the same literal "ACTGactgNn" as src/read.rs:157-174), run in the build container on 80
+//       committed inputs (tests/golden/make_reference_py_vectors.py -> reference_py_vectors.json; tests/test_oracle_golden.py).  The Rust
+//       path as a whole stays unpinned.
 //
 // What is restated (all paths relative to /root/reference):
 //   src/read.rs:157-174      Read::encode_rle          -> orc::encode_rle

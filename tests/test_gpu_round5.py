@@ -286,3 +286,28 @@ def test_reader_batches_are_page_locked_by_the_first_ingest(tmp_path):
     with E.Reader(str(tmp_path / "r.fa"), threads=4, device_buffers=True) as r:
         pk = next(r.batches_packed(600_000, copy=False))
         assert H.mdbg_host_is_pinned(pk["words"].ctypes.data) == 0
+
+
+@pytest.mark.gpu
+def test_hip_path_compresses_homopolymers_like_the_references_python_helper():
+    """the ACGT cases of tests/golden/reference_py_vectors.json (outputs of the reference's utils/remove_homopoly.py): with density 1 every l-mer of the
+    compressed read is selected, so the positions the HIP path reports ARE the compression's run starts — they must spell the helper's output"""
+    import json
+    import numpy as np
+    import rust_mdbg_amd as R
+    from conftest import GOLDEN
+    v = json.load(open(os.path.join(GOLDEN, "reference_py_vectors.json")))
+    cases = [c for c in v["hpc"] if set(c["input"]) <= set("ACGT") and len(c["output"]) >= 2]
+    assert len(cases) >= 15
+    l = 2
+    reads = [c["input"].encode() for c in cases]
+    offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.frombuffer(b"".join(reads), np.uint8)
+    with R.Mdbg(3, l, 1.0, 1, device=0) as m:
+        sk = m.sketch(bases, offs)
+    for i, c in enumerate(cases):
+        pos = [int(p) for p in sk["pos"][int(sk["off"][i]):int(sk["off"][i + 1])]]
+        out = c["output"]
+        assert len(pos) == len(out) - l + 1, c
+        assert "".join(c["input"][p] for p in pos) == out[:len(out) - l + 1], c
+        assert all(p == 0 or c["input"][p - 1] != c["input"][p] for p in pos)

@@ -37,3 +37,40 @@ def test_example_cfg1(example_reads):
     # threaded timing variant agrees on the counts
     solid, wins = O.count_threaded(bases, offs, c["k"], c["l"], c["density"], c["minabund"], threads=4)
     assert (solid, wins) == (gold["n_nodes"], gold["n_windows"])
+
+
+def test_oracle_against_the_references_own_python_helpers():
+    """tests/golden/reference_py_vectors.json holds what two of the reference's Python utilities print when run on committed inputs
+    (tests/golden/make_reference_py_vectors.py ran them from /root/reference in the build container): utils/remove_homopoly.py — the homopolymer
+    compression of src/read.rs:157-174, same literal "ACTGactgNn" — and utils/parse_gfa.py — how the reference's tools read S lines.
+    The oracle's encode_rle must give the compressed string of every case, with positions that are the run starts."""
+    v = json.load(open(os.path.join(GOLDEN, "reference_py_vectors.json")))
+    assert len(v["hpc"]) == 80
+    changed = 0
+    for case in v["hpc"]:
+        s = case["input"].encode()
+        hpc, pos = O.encode_rle(s)
+        assert hpc.decode() == case["output"], case
+        assert len(pos) == len(hpc) and all(s[p] == hpc[i] for i, p in enumerate(pos)) and pos == sorted(set(pos))
+        assert all(p == 0 or not (s[p - 1] == s[p] and s[p:p + 1] in b"ACTGactgNn") for p in pos)      # every kept position starts a run
+        changed += hpc != s
+    assert changed > 40
+
+
+def test_emitted_gfa_is_read_by_the_references_parser_as_meant(example_reads, tmp_path):
+    """the S lines this framework's emitter writes for BASELINE configs[0] are the ones the reference's utils/parse_gfa.py was run on when the vectors were
+    made, and what that parser read out of them (id -> KC abundance) is the oracle's node table"""
+    from rust_mdbg_amd.emit import Emitter
+    v = json.load(open(os.path.join(GOLDEN, "reference_py_vectors.json")))
+    b, o = O.concat_reads(example_reads)
+    g = O.Graph(7, 10, 0.0008, 2)
+    g.ingest(b, o)
+    r = g.finalize(with_edges=True)
+    em = Emitter()
+    em.edges(r, 0.01)
+    p = str(tmp_path / "cfg1.gfa")
+    em.write_gfa(p, r)
+    text = open(p).read()
+    assert hashlib.sha256(text.encode()).hexdigest() == v["gfa_text_sha256"]
+    assert [ln for ln in text.split("\n") if ln.startswith("S")] == v["gfa_s_lines"]
+    assert v["gfa_abundance"] == {str(int(r["index"][i])): int(r["abundance"][i]) for i in range(r["n_nodes"])} and len(v["gfa_abundance"]) == 104
