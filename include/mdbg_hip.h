@@ -111,7 +111,9 @@ typedef struct mdbg_stats {
     uint64_t n_sketch_tile_launches;
     uint64_t n_sketch_tile_bases; /* raw bases covered by those launches */
     uint64_t tile_bases;        /* raw bases a tile owns under this context's parameters (n_tiles = sum over batches of ceil(batch bases / tile_bases)) */
-    uint64_t reserved[4];
+    uint64_t n_link_matches;    /* only with MDBG_COUNT_LINKS in the environment (test hook; 0 otherwise): repeats of a key confirmed as a LINK of their left neighbour's
+                                 * match (one value compared instead of k: csrc/table.hip, upsert_wave), since create / mdbg_reset */
+    uint64_t reserved[3];
 } mdbg_stats;
 
 mdbg_ctx* mdbg_create(const mdbg_params* p, int* err);

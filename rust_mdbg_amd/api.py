@@ -41,7 +41,7 @@ class Stats(C.Structure):
                 ("n_distinct", C.c_uint64), ("table_capacity", C.c_uint64), ("n_slow_tiles", C.c_uint64), ("n_tiles", C.c_uint64),
                 ("ms_sketch", C.c_double), ("ms_insert", C.c_double), ("ms_finalize", C.c_double), ("ms_sketch_tile", C.c_double),
                 ("n_sketch_tile_launches", C.c_uint64), ("n_sketch_tile_bases", C.c_uint64), ("tile_bases", C.c_uint64),
-                ("reserved", C.c_uint64 * 4)]
+                ("n_link_matches", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
 class RoutedLists(C.Structure):

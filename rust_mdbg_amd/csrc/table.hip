@@ -84,6 +84,9 @@ struct TableArgs {
     const u64* own_thr;           // see OwnerSpec
     u32* probe_err;               // set when a probe sequence visited every slot: the table was sized from a wrong window count
     u64* own_inserted;            // sharded counter: owned windows actually inserted (checked against the senders' counts)
+    u64 fp_mask;                  // 0x3FFFFFFF; MDBG_WEAK_FP (test hook) leaves two bits, so that most probes meet ANOTHER key behind their fingerprint
+    unsigned long long* link_ctr; // non-null (MDBG_COUNT_LINKS): matches confirmed as links are counted here
+    u32 no_chain;                 // 1: every fingerprint hit is confirmed by the full comparison (MDBG_NO_CHAIN; see insert_windows_kernel)
     u8* claim;                    // non-null: claim[i] <- 1 when the window starting at minimizer index i CLAIMED its slot (created the key), else 0 — written for every
                                   // index of the span, so the map needs no zeroing; finalize starts from it instead of marking every key's first sighting (fin_mark_kernel)
 };
@@ -108,14 +111,20 @@ __device__ inline void push_ordinal(const TableArgs& T, u64 s, u64 x) {
     }
 }
 
-// find-or-claim the slot of a key; same_key(word) = full comparison of my key with the representative a slot word names
+// find-or-claim the slot of a key; same_key(word) = full comparison of my key with the representative a slot word names.
+// upsert_slot_from: the same walk entered at slot s after `probes` slots have been looked at already (insert_windows_kernel's second stage).
+template <class EqFn>
+__device__ inline u64 upsert_slot_from(const TableArgs& T, u64 h, u64 myword_lo, EqFn same_key, bool& claimed, u64 s, u64 probes);
 template <class EqFn>
 __device__ inline u64 upsert_slot(const TableArgs& T, u64 h, u64 myword_lo, EqFn same_key, bool& claimed) {
+    return upsert_slot_from(T, h, myword_lo, same_key, claimed, home_slot(h, T.cap), 0);
+}
+template <class EqFn>
+__device__ inline u64 upsert_slot_from(const TableArgs& T, u64 h, u64 myword_lo, EqFn same_key, bool& claimed, u64 s, u64 probes) {
     claimed = false;
-    const u64 fp = (h >> 34) & 0x3FFFFFFFull;
+    const u64 fp = (h >> 34) & T.fp_mask;
     const u64 myword = (fp << 34) | myword_lo;
-    u64 s = home_slot(h, T.cap);
-    for (u64 probes = 0; probes <= T.cap; ++probes) {
+    for (; probes <= T.cap; ++probes) {
         u64 w = load_relaxed(&T.tab[s].word);      // (claiming without looking first — one round trip for a new key instead of two — is slower:
         if (w == EMPTY) {                          //  0.72 instead of 0.65 ms per 6.6 M windows; the kernel is bound by the rate of its atomics)
             const u64 old = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)myword);
@@ -142,6 +151,10 @@ __device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, b
         for (u32 j = 0; j < k; ++j) diff |= rp[j] ^ wl[cross ? k - 1 - j : j];
         return !diff;
     }
+#ifdef MDBG_EXP_SHORT_COMPARE
+    // EXPERIMENT ONLY (never in a product build; results are not exact): how much of the insertion is the representative's traffic?  Compare two values (one sector).
+    { const u64x2_a8 a = *(const u64x2_a8*)rp; return !cross ? (a.x == wl[0] && a.y == wl[1]) : (a.x == wl[k - 1] && a.y == wl[k - 2]); }
+#endif
     if (k >= 16) {
         // sixteen values per round trip (eight 16-byte loads in flight): k = 35 takes three dependent rounds instead of five
         for (u32 j = 0;; j += 16) {
@@ -235,6 +248,68 @@ void launch_owner_thresholds(double bound, u32 k, u32 world, u64* thr, hipStream
     if (world > 1) hipLaunchKernelGGL(owner_thresholds_kernel, dim3(1), dim3(64), 0, s, bound, k, world, thr);
 }
 
+// find-or-claim for a whole wave: every lane calls it together, act = the lane has a window (its k values at w, window start = store index i, position li in a
+// list that is in window order where consecutive entries are consecutive windows of a read).  claimed: the lane created the key; found: it met its key in slot s.
+// The walk of upsert_slot is cut in two.  (1) Every lane walks to the first slot that is empty (claims it) or carries its fingerprint.  (2) The fingerprint
+// hits are confirmed: with all lanes' first stage behind them, the loads of the representatives are issued side by side instead of each at the end of its
+// lane's own chain of probes — 0.713 -> 0.665 ms per 6.6 M windows, 36.6 -> 33.5 ms for the human data set (profiles/r05_x_insert_two_stage.txt).
+// A lane whose hit CONTINUES its left neighbour's — the neighbour (window i - 1) sits in a slot whose representative is store index r, this lane's slot names
+// r + 1 (r - 1 when the orientations cross), same orientation relation — is a LINK: k - 1 of its k comparisons are the neighbour's, it compares its newest
+// value only (8 bytes instead of 8 k in three cache lines); it is confirmed when it and every lane between it and its HEAD (the nearest lane below that is not a
+// link; lane 0 always is one, nothing crosses a wave) passed.  Nothing is taken on trust: every accepted match is a full comparison or follows from one.  Links
+// need the neighbouring keys to have been created by neighbouring windows of ONE earlier read: common when a batch holds a copy or two of a region (a file
+// streamed in 256-Mbase batches), rare when one launch inserts dozens of copies that race for the claim (the benchmark's 50x batches: no gain there; an
+// experiment that compared 16 bytes of every representative — MDBG_EXP_SHORT_COMPARE, not exact — bounds what links can give at -18 % / -22 %).
+// A lane that fails either way walks on with full comparisons like upsert_slot.
+__device__ inline u64 upsert_wave(const TableArgs& T, bool act, u32 li, u64 i, const u64* w, u32 k, bool& claimed, bool& found) {
+    const int lane = threadIdx.x & 63;
+    bool rev = false; u64 h = 0;
+    if (act) { rev = window_reversed(w, k); h = key_hash_window(w, k, rev); }
+    const u64 fp = (h >> 34) & T.fp_mask;
+    const u64 myword_lo = ((u64)rev << 32) | (u64)(u32)i;
+    auto eq = [&](u64 word) { return same_key_window(T.ks, word, w, rev); };
+    // (1) to the first slot that is empty or carries the fingerprint
+    u64 s = act ? home_slot(h, T.cap) : 0, word = EMPTY, probes = 0;
+    claimed = false;
+    bool cand = false;
+    if (act) {
+        for (; probes <= T.cap; ++probes) {
+            u64 wv = load_relaxed(&T.tab[s].word);
+            if (wv == EMPTY) {
+                const u64 old = atomicCAS((unsigned long long*)&T.tab[s].word, (unsigned long long)EMPTY, (unsigned long long)((fp << 34) | myword_lo));
+                if (old == EMPTY) { wave_agg_inc(T.n_distinct); claimed = true; break; }
+                wv = old;
+            }
+            if ((wv >> 34) == fp) { word = wv; cand = true; break; }
+            s = s + 1 == T.cap ? 0 : s + 1;
+        }
+        if (!claimed && !cand) { *T.probe_err = 1; s = ~0ull; }      // table full: cannot happen when it was sized from the true number of windows
+    }
+    // (2) heads and links
+    const bool cross = rev != ((word & (1ull << 32)) != 0);
+    const u32 rep = (u32)word;
+    const u32 p_li = (u32)__shfl_up((int)li, 1, 64), p_rep = (u32)__shfl_up((int)rep, 1, 64);
+    const int p_info = __shfl_up((int)((cand && !(word & (1ull << 33)) ? 1 : 0) | (cross ? 2 : 0)), 1, 64);
+    const bool link = cand && !T.no_chain && lane > 0 && !(word & (1ull << 33)) && (p_info & 1) && p_li + 1 == li && ((p_info >> 1) & 1) == (int)cross &&
+                      rep == (cross ? p_rep - 1u : p_rep + 1u);
+    bool pass = false;
+    if (cand) pass = link ? T.ks.mh[(u64)rep + (cross ? 0u : k - 1u)] == w[k - 1] : eq(word);
+    const u64 heads = __ballot(!link), fails = __ballot(cand && !pass);
+    found = pass;
+    if (link && pass) {
+        const int hp = 63 - __clzll((unsigned long long)(heads & ((2ull << lane) - 1ull)));      // the nearest head below: lane 0 is one
+        found = ((fails >> hp) & ((2ull << (lane - hp)) - 1ull)) == 0;
+    }
+    if (T.link_ctr) { const u64 lm = __ballot(link && found); if (lane == 0 && lm) atomicAdd(T.link_ctr, (unsigned long long)__popcll(lm)); }
+    if (cand && !found) {
+        // another key behind this fingerprint, or a chain that broke in front of this lane: the plain walk, entered at this slot (a head has compared it already)
+        const bool skip = !link;
+        s = upsert_slot_from(T, h, myword_lo, eq, claimed, skip ? (s + 1 == T.cap ? 0 : s + 1) : s, probes + (skip ? 1 : 0));
+        found = !claimed && s != ~0ull;
+    }
+    return s;
+}
+
 // Windows of the minimizers [i0, i1) of a batch -> counting table.  src/main.rs:756 — only reads with MORE than k minimizers contribute,
 // so most minimizer indices start no window (15 kb reads at d = 0.002: 14 of 48), and with a partitioned table (replicated-sketch mode)
 // most windows belong to other ranks.  One workgroup stages the OWN_SPAN + k - 1 hashes its span covers in LDS (coalesced), lists the
@@ -282,22 +357,25 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     __syncthreads();
     const u32 n = *n_own;
     if (threadIdx.x == 0 && n) atomicAdd((unsigned long long*)ctr_shard(T.own_inserted), (unsigned long long)n);
-    for (u32 j = threadIdx.x; j < n; j += 256) {
-        const u32 li = list[j];
+    for (u32 j0 = 0; j0 < n; j0 += 256) {          // (the same trip count for every lane: upsert_wave is a wave-wide call)
+        const u32 j = j0 + threadIdx.x;
+        bool act = j < n;
+        const u32 li = act ? list[j] : 0u;
         const u64 i = b0 + li;
-        const u32 slot = mread[i];
-        const u64 win = i - roff[slot];
-        if (win > WIN_MASK) { *cap_err = 1; continue; }
-        const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
-        const u64* w = sh_keys + li;
-        const bool rev = window_reversed(w, k);
-        const u64 h = key_hash_window(w, k, rev);
-        bool claimed;
-        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+        u64 ord = 0;
+        if (act) {
+            const u32 slot = mread[i];
+            const u64 win = i - roff[slot];
+            if (win > WIN_MASK) { *cap_err = 1; act = false; }
+            ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
+        }
+        bool claimed, found;
+        const u64 s = upsert_wave(T, act, li, i, sh_keys + li, k, claimed, found);
         if (claimed && T.claim) cl[li] = 1;
-        if (claimed || s == ~0ull) continue;
-        atomicAdd(&T.tab[s].count, 1u);
-        push_ordinal(T, s, ord);
+        if (found) {
+            atomicAdd(&T.tab[s].count, 1u);
+            push_ordinal(T, s, ord);
+        }
     }
     if (T.claim) {                             // the span's claim bytes, 64 consecutive bytes per wave and store (a slice's last workgroup stops at its end: n_lim)
         __syncthreads();
@@ -566,19 +644,16 @@ __global__ __launch_bounds__(256) void insert_listed_span_kernel(TableArgs T, co
             ok = i >= rs && re - rs > k && i + k <= re && (!listed_check(j) || window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank);
         }
         wave_count_add(ok, T.own_inserted);
-        if (!ok) continue;
         const u64 win = i - rs;
-        if (win > WIN_MASK) { *cap_err = 1; continue; }
+        if (ok && win > WIN_MASK) { *cap_err = 1; ok = false; }
         const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
-        const u64* w = sh_keys + li;
-        const bool rev = window_reversed(w, k);
-        const u64 h = key_hash_window(w, k, rev);
-        bool claimed;
-        const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
+        bool claimed, found;
+        const u64 s = upsert_wave(T, ok, li, i, sh_keys + li, k, claimed, found);      // (a wave-wide call: no lane leaves the loop early)
         if (claimed) mread[i] = slot;              // rep_ordinal() finds the representative's read through it; the rest of a listed batch's map is filled on demand
-        if (claimed || s == ~0ull) continue;
-        atomicAdd(&T.tab[s].count, 1u);
-        push_ordinal(T, s, ord);
+        if (found) {
+            atomicAdd(&T.tab[s].count, 1u);
+            push_ordinal(T, s, ord);
+        }
     }
 }
 u32 owner_list_spans(u64 n_minimizers) { return (u32)((n_minimizers + OWNL_SPAN - 1) / OWNL_SPAN); }
@@ -887,7 +962,7 @@ __global__ __launch_bounds__(256) void wrap_list_kernel(Slot* __restrict__ tab, 
 // lookup without insertion: slot of a key that is known to be in the table, or ~0 (keys of other ranks)
 template <class EqFn>
 __device__ inline u64 find_slot(const TableArgs& T, u64 h, EqFn same_key) {
-    const u64 fp = (h >> 34) & 0x3FFFFFFFull;
+    const u64 fp = (h >> 34) & T.fp_mask;
     u64 s = home_slot(h, T.cap);
     for (;;) {
         const u64 w = load_relaxed(&T.tab[s].word);

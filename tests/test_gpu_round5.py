@@ -311,3 +311,67 @@ def test_hip_path_compresses_homopolymers_like_the_references_python_helper():
         assert len(pos) == len(out) - l + 1, c
         assert "".join(c["input"][p] for p in pos) == out[:len(out) - l + 1], c
         assert all(p == 0 or c["input"][p - 1] != c["input"][p] for p in pos)
+
+
+# the insertion's two stages (csrc/table.hip, upsert_wave): first stage to a fingerprint hit, second stage heads (full comparison) and links (the left neighbour's
+# match continued: one value compared).  Child process: the hooks are read once per process.
+CHILD_INSERT = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import rust_mdbg_amd as R
+from oracle import oracle as O
+rng = np.random.default_rng(7)
+genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=400_000).tobytes()
+def reads_of(n, seed):
+    r = np.random.default_rng(seed); out = []
+    for _ in range(n):
+        a = int(r.integers(0, len(genome) - 30_000)); s = bytearray(genome[a:a + int(r.integers(12_000, 30_000))])
+        for p in r.integers(0, len(s), size=len(s) // 2500): s[int(p)] = b"ACGT"[int(r.integers(0, 4))]      # a few errors: chains break and start again
+        out.append(bytes(s) if r.random() < 0.5 else O.revcomp(bytes(s)))
+    return out
+k, l, d, A = 9, 8, 0.02, 2
+batches = [reads_of(30, 100 + i) for i in range(12)]          # ~1.5x per batch, 18x in all: a later batch's windows repeat keys that ONE earlier read created
+exp = O.Graph(k, l, d, A)
+first = 0
+with R.Mdbg(k, l, d, A, device=0) as m:
+    for rs in batches:
+        b, o = O.concat_reads(rs)
+        exp.ingest(b, o, first); m.ingest(b, o, first); first += len(rs)
+    r = exp.finalize(with_edges=False); nd = m.finalize(); st = m.stats()
+    assert nd["n_nodes"] == r["n_nodes"] > 2000 and nd["n_nodes_before"] == r["n_nodes_before"]
+    for f in ("keys", "index", "abundance", "seqlen", "shift_full", "src_read", "src_start", "src_end", "reversed"):
+        assert np.array_equal(np.asarray(nd[f]).reshape(-1), np.asarray(r[f]).reshape(-1)), f
+    print("LINKS", st["n_link_matches"], "WINDOWS", st["n_windows"], "DISTINCT", st["n_distinct"])
+    # one batch with every copy in it (the copies race for the claim), then the same reads once more (every window a repeat)
+    m.reset(0)
+    allr = [x for rs in batches for x in rs]
+    b, o = O.concat_reads(allr)
+    m.ingest(b, o, 0); m.ingest(b, o, len(allr))
+    e2 = O.Graph(k, l, d, A); e2.ingest(b, o, 0); e2.ingest(b, o, len(allr)); r2 = e2.finalize(with_edges=False); n2 = m.finalize()
+    for f in ("keys", "index", "abundance", "seqlen", "shift_full", "src_read", "src_start", "src_end", "reversed"):
+        assert np.array_equal(np.asarray(n2[f]).reshape(-1), np.asarray(r2[f]).reshape(-1)), f
+print("INSERT_OK")
+"""
+
+
+def _insert_child(**env):
+    e = dict(os.environ, MDBG_COUNT_LINKS="1", **{k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, "-c", CHILD_INSERT % ROOT], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0 and "INSERT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    f = r.stdout.split("LINKS")[1].split()
+    return int(f[0]), int(f[2]), int(f[4])
+
+
+@pytest.mark.gpu
+def test_insertion_confirms_neighbouring_repeats_as_links_and_stays_exact():
+    """batches that hold a copy or two of a region: most repeats are confirmed as links of their left neighbour (counted: MDBG_COUNT_LINKS); the node table is the
+    oracle's field by field — also without links (MDBG_NO_CHAIN), and with a two-bit fingerprint (MDBG_WEAK_FP), under which most probes meet another key behind
+    their fingerprint and heads and links fail into the plain walk"""
+    links, windows, distinct = _insert_child()
+    assert windows > 20_000 and links > (windows - distinct) // 3, (links, windows, distinct)
+    assert _insert_child(MDBG_NO_CHAIN=1)[0] == 0
+    weak, _, _ = _insert_child(MDBG_WEAK_FP=1)
+    assert weak > 0
+    _insert_child(MDBG_WEAK_FP=1, MDBG_NO_CHAIN=1)
+    _insert_child(MDBG_WEAK_FP=1, MDBG_POISON=1)
