@@ -1,9 +1,9 @@
 #!/bin/bash
 # kernel timeline of one human step: where is the GPU idle?
 set -u
-R=$(pwd); O=$R/gpurun_out/r5k; mkdir -p $O
+R=$(pwd); O=$R/gpurun_out/r5k${TAG:-}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/kt -o q -- python $R/bench.py --gpus 1 --workload human --steps 2 --warmup 1 --cpu-seconds 0 --plain > $O/out.json 2> $O/err.txt
+env ${EXTRA:-X=1} rocprofv3 --kernel-trace --output-format csv -d $O/kt -o q -- python $R/bench.py --gpus 1 --workload human --steps 2 --warmup 1 --cpu-seconds 0 --plain > $O/out.json 2> $O/err.txt
 python - $O/kt/q_kernel_trace.csv > $O/timeline.txt <<'PY'
 import csv, sys
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:40]) for r in csv.DictReader(open(sys.argv[1]))]
@@ -26,5 +26,7 @@ import collections
 c = collections.Counter()
 for s, e, n in seg: c[n] += e - s
 for n, t in c.most_common(25): print("%-42s %.3f ms" % (n, t / 1e6))
+print("the step's first kernels (start, end in ms from the step's start):")
+for s, e, n in seg[:14]: print("  %8.3f %8.3f  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, n))
 PY
 find $O -name "*.csv" -size +5M -delete; find $O -name "*.db" -delete
