@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--multik", action="store_true",
                     help="BASELINE.json configs[4]: a step = sketch ONCE (l=12 d=0.003), then the graph of every k in 10,15,..,40 from the resident sketches (mdbg_reset(new_k): the table is "
                          "cleared and refilled, nothing is sketched or — at N>1, where the ranks hold whole sketches — exchanged again); value counts every k's graph: bases x 7 / time")
+    ap.add_argument("--watchdog-seconds", type=int, default=1500, help="a rank that is still running after this long dumps the tracebacks of all its threads to stderr and exits (a hang "
+                    "in a collective would otherwise sit there until the caller's own limit, without a word); 0 = off")
     ap.add_argument("--no-scale-anchor", action="store_true", help="default N=1 run: skip the human data set's pass through this GPU after the timed region (scale_anchor_n1)")
     ap.add_argument("--plain", action="store_true", help="only the warm-up and the timed steps (no ASCII legs, no edge stage, no CPU leg): for profiler runs, where every launch should be one of the timed kind")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
@@ -320,6 +322,9 @@ def scale_anchor_n1(R, torch, np, device_index, minabund):
 
 def main():
     args = parse()
+    if args.watchdog_seconds > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)      # (cancelled by the process's end)
     # stdout carries exactly one JSON line: native libraries (RCCL prints a version banner) write to file descriptor 1
     # directly, so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor
     sys.stdout.flush()
