@@ -903,6 +903,75 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
             F.solid_list[j] = s0 + 1024ull * u; F.solid_dense[j] = dense[u];
         }
 }
+// fin_mark_kernel for the claim-map mode (F.claims), in two passes over the workgroup's 4,096 slots.  A slot needs more than a look only when its key was seen again
+// (the first sighting may lie in front of the claimer: one scattered read, up to two scattered byte stores) or is solid (a row of the node table): 9 % of the human
+// table's slots, which in fin_mark_kernel sit spread over every wave, so every wave waits for its few slow lanes on each of its four rounds.  Here the first pass
+// only looks (word and count) and lists those slots in LDS; the second pass works the list off on full waves, and lists the solid ones once more for the ONE
+// allocation atomic per workgroup (the counter is a single address: ~12 ns per atomic, serialised).
+__global__ __launch_bounds__(1024) void fin_mark_claims_kernel(FinArgs F) {
+    constexpr u32 SPAN = 1024 * FIN_SPT;
+    __shared__ u16 lst[SPAN], sol_li[SPAN];
+    __shared__ u32 sol_D[SPAN];
+    __shared__ u32 n_lst, n_sol;
+    __shared__ u64 bbase;
+    const u64 b0 = (u64)blockIdx.x * SPAN;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) { n_lst = 0; n_sol = 0; }
+    __syncthreads();
+    u32 n_occ = 0, n_wrapped = 0;
+#pragma unroll
+    for (int u = 0; u < FIN_SPT; ++u) {
+        const u32 li = (u32)u * 1024u + threadIdx.x;
+        const u64 s = b0 + li;
+        bool slow = false;
+        if (s < F.cap) {
+            const u64 word = F.tab[s].word;
+            if (word != EMPTY) {
+                const u32 c0 = F.tab[s].count, count = c0 + 1u;
+                ++n_occ; n_wrapped += count >= 65536u ? 1u : 0u;
+                slow = c0 != 0 || F.A == 1 || (u16)count >= (u16)F.A;          // seen again, or solid (as slot_view)
+            }
+        }
+        const u64 mk = __ballot(slow);
+        u32 base = 0;
+        if (lane == 0 && mk) base = atomicAdd(&n_lst, (u32)__popcll(mk));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (slow) lst[base + (u32)__popcll(mk & ((1ull << lane) - 1ull))] = (u16)li;
+    }
+    for (int d = 32; d; d >>= 1) { n_occ += __shfl_down(n_occ, d, 64); n_wrapped += __shfl_down(n_wrapped, d, 64); }
+    if (lane == 0) {
+        if (n_occ) atomicAdd((unsigned long long*)ctr_shard(F.sh_distinct), (unsigned long long)n_occ);
+        if (n_wrapped) atomicAdd((unsigned long long*)ctr_shard(F.sh_wrapped), (unsigned long long)n_wrapped);
+    }
+    __syncthreads();
+    const u32 n = n_lst;
+    for (u32 t0 = 0; t0 < n; t0 += 1024) {            // (the same trip count for every lane: ballots inside)
+        const u32 t = t0 + threadIdx.x;
+        bool solid = false; u32 li = 0; u64 D = 0;
+        if (t < n) {
+            li = lst[t];
+            const Slot e = F.tab[b0 + li];
+            const u32 count = e.count + 1u;
+            solid = F.A == 1 || (u16)count >= (u16)F.A;
+            // the claimer's byte is set already (insert_windows_kernel); a key seen again may have an earlier sighting: move the mark there.  ONE map in this mode: bit 0 =
+            // first sighting, bit 1 = the key is solid; a byte only ever gains bits between two resets (see fin_mark_kernel)
+            const u64 Dc = (u32)e.word;
+            D = Dc;
+            if (e.count) { u64 i, D1; decode_ordinal(F, e.m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; } }
+            if (D != Dc || solid) F.by_first[D] = solid ? 3 : 1;
+        }
+        const u64 mk = __ballot(solid);
+        u32 base = 0;
+        if (lane == 0 && mk) base = atomicAdd(&n_sol, (u32)__popcll(mk));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (solid) { const u32 q = base + (u32)__popcll(mk & ((1ull << lane) - 1ull)); sol_li[q] = (u16)li; sol_D[q] = (u32)D; }
+    }
+    __syncthreads();
+    const u32 ns = n_sol;
+    if (threadIdx.x == 0) bbase = ns ? atomicAdd((unsigned long long*)F.solid_count, (unsigned long long)ns) : 0;
+    __syncthreads();
+    for (u32 t = threadIdx.x; t < ns; t += 1024) { F.solid_list[bbase + t] = b0 + sol_li[t]; F.solid_dense[bbase + t] = (u64)sol_D[t]; }
+}
 // bitmap word w <- bit i = (byte 64 w + i != 0), for both maps; one thread per word (four 16-byte loads per map).  by1 == null: ONE map whose bytes hold bit 0 = first
 // sighting, bit 1 = solid (the claim-map mode of fin_mark_kernel)
 __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const u8* __restrict__ by0, const u8* __restrict__ by1, u64 n_words, u64* __restrict__ bm0, u64* __restrict__ bm1) {
@@ -1488,6 +1557,8 @@ void launch_fin_order(const FinArgs& F, u64 n_solid, u64* order, hipStream_t s) 
     if (n_solid) hipLaunchKernelGGL(fin_order_kernel, dim3((unsigned)((n_solid + 255) / 256)), dim3(256), 0, s, F, n_solid, order);
 }
 void launch_fin_mark(const FinArgs& F, hipStream_t s) {
+    static const bool one_pass = getenv("MDBG_FIN_ONE_PASS") != nullptr;      // (A/B switch: the round-5 kernel for the claim-map mode too)
+    if (F.claims && !one_pass) { hipLaunchKernelGGL(fin_mark_claims_kernel, dim3((unsigned)((F.cap + 1024 * FIN_SPT - 1) / (1024 * FIN_SPT))), dim3(1024), 0, s, F); return; }
     hipLaunchKernelGGL(fin_mark_kernel, dim3((unsigned)((F.cap + 1024 * FIN_SPT - 1) / (1024 * FIN_SPT))), dim3(1024), 0, s, F);
 }
 void launch_wrap_list(Slot* tab, u64 cap, u32 A, bool all_solid, u64* w_jstar, u32* w_count, unsigned long long* counters, hipStream_t s) {
