@@ -375,3 +375,4 @@ def test_insertion_confirms_neighbouring_repeats_as_links_and_stays_exact():
     assert weak > 0
     _insert_child(MDBG_WEAK_FP=1, MDBG_NO_CHAIN=1)
     _insert_child(MDBG_WEAK_FP=1, MDBG_POISON=1)
+    _insert_child(MDBG_FIN_ONE_PASS=1)          # finalize's marking kernel of the claim-map mode in one pass (the default lists the slots that need work and takes two)
