@@ -526,6 +526,7 @@ struct mdbg_reader {
     const u8* map = nullptr; size_t map_size = 0, map_cur = 0; int threads = 1;
     int fd = -1;                                              // the mapped file, kept open: the fast path READS its chunks (pread into a buffer that stays in L2) instead of touching the mapping
     std::vector<std::vector<u8>> chunk_buf;                   // one per worker
+    std::atomic<size_t> margin_hint{32u << 10};               // text read behind a chunk's nominal end to find the record start there (grows to what the records of this file need)
     // the batch buffers handed to the caller (big / big2 / pw / pw2) come from here: malloc / free unless mdbg_reader_set_allocator named something else
     // (mdbg_host_alloc of libmdbg_hip.so: buffers the ingest calls page-lock, so the copy to the device is one DMA instead of a staged memcpy)
     void* (*alloc_fn)(size_t) = nullptr; void (*free_fn)(void*) = nullptr;
@@ -682,6 +683,33 @@ size_t line_end(const u8* m, size_t n, size_t p) { const u8* nl = p < n ? (const
 // first record start >= p.  FASTA: a line that starts with '>'.  FASTQ (four-line records, as the streaming reader assumes): a line that
 // starts with '@' whose third line starts with '+' and whose second and fourth lines have the same length — a quality line that happens
 // to start with '@' fails both tests.
+// next_record_start on a PIECE of the text: the same walk over [.., n), and hit_end says whether any of its line searches ran into n without finding a terminator — then
+// (and only then) the answer may depend on bytes behind n.  A caller that holds the text up to n < the real end reads more and asks again.
+size_t next_record_start_in(const u8* m, size_t n, size_t p, bool fasta, bool& hit_end) {
+    hit_end = false;
+    auto lend = [&](size_t from) -> size_t { const u8* nl = from < n ? (const u8*)memchr(m + from, '\n', n - from) : nullptr; if (!nl) { hit_end = true; return n; } return (size_t)(nl - m); };
+    size_t q;
+    if (p == 0 || p >= n) { if (p >= n) hit_end = true; q = p >= n ? n : 0; }
+    else if (m[p - 1] == '\n') q = p;
+    else { const size_t e = lend(p); q = e < n ? e + 1 : n; }
+    if (q >= n) hit_end = true;                                      // the line start itself lies at or behind n
+    while (q < n) {
+        if (fasta) { if (m[q] == '>') return q; }
+        else if (m[q] == '@') {
+            const size_t e0 = lend(q), s1 = e0 + 1, e1 = lend(s1), s2 = e1 + 1;
+            if (s2 < n && m[s2] == '+') {
+                const size_t e2 = lend(s2), s3 = e2 + 1, e3 = lend(s3);
+                size_t l1 = e1 - s1, l3 = s3 <= n ? e3 - std::min(s3, n) : 0;
+                if (l1 && m[e1 - 1] == '\r') --l1;
+                if (l3 && e3 <= n && e3 > 0 && m[e3 - 1] == '\r') --l3;
+                if (l1 == l3) return q;
+            } else if (s2 >= n) hit_end = true;
+        }
+        q = lend(q) + 1;
+    }
+    hit_end = true;
+    return n;
+}
 size_t next_record_start(const u8* m, size_t n, size_t p, bool fasta) {
     size_t q = line_start_after(m, n, p);
     while (q < n) {
@@ -1087,17 +1115,36 @@ static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, 
         for (;;) {
             const size_t c = next_chunk.fetch_add(1, std::memory_order_relaxed);
             if (c >= C || bad.load(std::memory_order_relaxed)) return;
-            const size_t a = c == 0 ? w0 : next_record_start(m, w1, w0 + c * chunk_bytes, r->fasta), b = c + 1 == C ? w1 : next_record_start(m, w1, w0 + (c + 1) * chunk_bytes, r->fasta);
+            // the chunk's records: those that start in [n0, n1) of the text, i.e. [a, b) with a / b = the first record start at or behind n0 / n1 (as next_record_start
+            // on the whole window finds them: the chunk in front computes the same b as this one's a)
+            const size_t n0 = w0 + c * chunk_bytes, n1 = std::min(w1, n0 + chunk_bytes);
+            size_t a, b;
             std::vector<mdbg_reader::FastRec>& recs = r->fast_recs[c];
             u64 nb = 0;
             const u8* mc = m;                                      // base pointer under which this chunk's bytes [a, b) are found at their file offsets
-            if (by_read && a < b) {
+            if (!by_read) {
+                a = c == 0 ? w0 : next_record_start(m, w1, n0, r->fasta); b = c + 1 == C ? w1 : next_record_start(m, w1, n1, r->fasta);
+            } else {
+                // ... looked up in the worker's own copy of the text: [n0 - 1, n1 + margin), read on until neither answer can depend on what lies behind the copy.
+                // (Through the mapping these two lookups were ~2,000 minor faults per window, serviced at about one per microsecond whatever the number of threads:
+                // most of the 2.7 ms a 268-MB window took with 16 threads.)
                 std::vector<u8>& tb = r->chunk_buf[(size_t)i];
-                if (tb.size() < b - a) tb.resize(b - a + (b - a) / 4);
-                size_t got = 0;
-                while (got < b - a) { const ssize_t n = pread(r->fd, tb.data() + got, b - a - got, (off_t)(a + got)); if (n <= 0) { if (n < 0 && errno == EINTR) continue; break; } got += (size_t)n; }
-                if (got < b - a) { io_bad.store(1, std::memory_order_relaxed); bad.store(1, std::memory_order_relaxed); return; }      // (the file shrank under the mapping)
-                mc = tb.data() - a;
+                const size_t lo = c == 0 ? w0 : n0 - 1;
+                static const size_t margin_test = [] { const char* e = getenv("MDBG_READER_MARGIN_BYTES"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)0; }();      // (tests: margins of a few bytes, so that reading on happens)
+                size_t hi = lo, want = std::min(w1, n1 + (margin_test ? margin_test : r->margin_hint.load(std::memory_order_relaxed)));
+                for (;;) {
+                    if (tb.size() < want - lo) tb.resize(want - lo + (want - lo) / 4);
+                    while (hi < want) { const ssize_t n = pread(r->fd, tb.data() + (hi - lo), want - hi, (off_t)hi); if (n <= 0) { if (n < 0 && errno == EINTR) continue; break; } hi += (size_t)n; }
+                    if (hi < want) { io_bad.store(1, std::memory_order_relaxed); bad.store(1, std::memory_order_relaxed); return; }      // (the file shrank under the mapping)
+                    mc = tb.data() - lo;
+                    bool ha = false, hb = false;
+                    a = c == 0 ? w0 : next_record_start_in(mc, hi, n0, r->fasta, ha);
+                    b = c + 1 == C ? w1 : next_record_start_in(mc, hi, n1, r->fasta, hb);
+                    if (hi >= w1 || !(ha || hb)) break;            // (with the whole window in hand the answers are next_record_start's on the window)
+                    want = std::min(w1, hi + (margin_test ? margin_test : std::max<size_t>(hi - n1, 32u << 10)));
+                }
+                const size_t used = hi > n1 ? hi - n1 : 0;          // the next chunks start with the margin this one needed (bounded: one long record must not tax all that follow)
+                if (used > r->margin_hint.load(std::memory_order_relaxed) && used <= (1u << 20)) r->margin_hint.store((used + 0x3FFF) & ~(size_t)0x3FFF, std::memory_order_relaxed);
             }
             const bool ok = a >= b ? (recs.clear(), true) : scan_piece(mc, a, b, w1, r->fasta, r->strip, recs, nb);
             const double tw = timing ? now() : 0;
