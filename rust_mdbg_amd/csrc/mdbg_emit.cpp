@@ -1141,7 +1141,7 @@ static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, 
                     a = c == 0 ? w0 : next_record_start_in(mc, hi, n0, r->fasta, ha);
                     b = c + 1 == C ? w1 : next_record_start_in(mc, hi, n1, r->fasta, hb);
                     if (hi >= w1 || !(ha || hb)) break;            // (with the whole window in hand the answers are next_record_start's on the window)
-                    want = std::min(w1, hi + (margin_test ? margin_test : std::max<size_t>(hi - n1, 32u << 10)));
+                    want = std::min(w1, hi + std::max<size_t>(hi > n1 ? hi - n1 : 0, margin_test ? margin_test : (size_t)(32u << 10)));      // (doubling: a long record is a few more reads, not thousands)
                 }
                 const size_t used = hi > n1 ? hi - n1 : 0;          // the next chunks start with the margin this one needed (bounded: one long record must not tax all that follow)
                 if (used > r->margin_hint.load(std::memory_order_relaxed) && used <= (1u << 20)) r->margin_hint.store((used + 0x3FFF) & ~(size_t)0x3FFF, std::memory_order_relaxed);

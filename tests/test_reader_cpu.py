@@ -501,3 +501,49 @@ def test_reader_takes_its_batch_buffers_from_the_callers_allocator(tmp_path):
         assert got == ref and len(got) > 3
     with E.Reader(str(p), threads=4) as r:
         assert L.mdbg_reader_set_allocator(r.h, a_c, C.cast(None, FREE)) == -1   # both or neither
+
+
+CHUNKED_CHILD = r"""
+import sys, random
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from test_reader_cpu import collect, random_records
+from rust_mdbg_amd import emit as E
+def packed(path, max_bases, threads):
+    out = []
+    with E.Reader(path, threads=threads) as r:
+        for pk in r.batches_packed(max_bases):
+            out.append((pk["n_bases"], pk["words"].tobytes(), pk["offsets"].tobytes(), pk["exc_pos"].tobytes(), pk["exc_val"].tobytes()))
+    return out
+n_fast = 0
+for kind in ("fasta", "fasta-crlf", "fastq", "fastq-crlf", "fastq-noeol", "fasta-multiline"):
+    rnd = random.Random(hash(kind) & 0xFFF)
+    fastq = kind.startswith("fastq")
+    data = random_records(rnd, 400, fastq, crlf="crlf" in kind, multiline="multiline" in kind)
+    if kind == "fastq-noeol": data = data.rstrip(b"\n")
+    p = %r + ("/r.fastq" if fastq else "/r.fa")
+    open(p, "wb").write(data)
+    ref, _ = collect(p)
+    refp = packed(p, 1 << 30, 1)
+    for threads in (2, 5):
+        for mb in (1 << 30, 150_000, 20_000):
+            got, _ = collect(p, max_bases=mb, threads=threads)
+            assert got == ref, (kind, threads, mb)
+            gp = packed(p, mb, threads)
+            assert sum(x[0] for x in gp) == sum(x[0] for x in refp)
+            if mb == 1 << 30: assert gp == refp, (kind, threads)
+print("CHUNKED_OK")
+"""
+
+
+@pytest.mark.parametrize("chunk,margin", [(300, 5), (4096, 1), (70, 33), (20000, 700)])
+def test_fast_path_with_small_chunks_and_margins(chunk, margin, tmp_path):
+    """the one-pass reader takes a window in chunks that the workers claim in file order; a chunk's two boundaries are looked up in the worker's own copy of the text,
+    which is read on while an answer could depend on what lies behind it.  With chunks and look-ahead margins of a few bytes (the hooks are read once per process: a
+    child) every record straddles chunks and every lookup reads on — batches equal to the streaming reader's, packed batches to the one-thread reader's"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MDBG_READER_CHUNK_BYTES=str(chunk), MDBG_READER_MARGIN_BYTES=str(margin))
+    r = subprocess.run([sys.executable, "-c", CHUNKED_CHILD % (os.path.dirname(here), here, str(tmp_path))], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "CHUNKED_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
