@@ -1141,6 +1141,9 @@ static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, 
                     a = c == 0 ? w0 : next_record_start_in(mc, hi, n0, r->fasta, ha);
                     b = c + 1 == C ? w1 : next_record_start_in(mc, hi, n1, r->fasta, hb);
                     if (hi >= w1 || !(ha || hb)) break;            // (with the whole window in hand the answers are next_record_start's on the window)
+                    // records of many megabytes (a chromosome on one line): every chunk inside one would read to its end — the general parser cuts a window into
+                    // one piece per thread and looks T boundaries up, not thousands
+                    if (hi > n1 && hi - n1 > (8u << 20)) { bad.store(1, std::memory_order_relaxed); return; }
                     want = std::min(w1, hi + std::max<size_t>(hi > n1 ? hi - n1 : 0, margin_test ? margin_test : (size_t)(32u << 10)));      // (doubling: a long record is a few more reads, not thousands)
                 }
                 const size_t used = hi > n1 ? hi - n1 : 0;          // the next chunks start with the margin this one needed (bounded: one long record must not tax all that follow)

@@ -547,3 +547,24 @@ def test_fast_path_with_small_chunks_and_margins(chunk, margin, tmp_path):
     env = dict(os.environ, MDBG_READER_CHUNK_BYTES=str(chunk), MDBG_READER_MARGIN_BYTES=str(margin))
     r = subprocess.run([sys.executable, "-c", CHUNKED_CHILD % (os.path.dirname(here), here, str(tmp_path))], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "CHUNKED_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_a_record_of_many_megabytes_sends_its_window_to_the_general_parser(tmp_path):
+    """a chromosome on one line between ordinary records: a chunk inside it would have to read to its end to find the next record start, so the one-pass path gives the
+    window up (look-ahead bounded at 8 MB) and the general parser — one piece per thread — takes it; the records are the streaming reader's"""
+    import random
+    rnd = random.Random(1)
+    p = tmp_path / "long.fa"
+    with open(p, "wb") as f:
+        for i in range(40):
+            f.write(b">r%d\n" % i + bytes(rnd.choice(b"ACGT") for _ in range(1500)) + b"\n")
+        f.write(b">chr\n" + b"ACGTTGCA" * 2_500_000 + b"\n")          # 20 Mb, one line
+        for i in range(40):
+            f.write(b">s%d\n" % i + bytes(rnd.choice(b"ACGT") for _ in range(1500)) + b"\n")
+    ref, _ = collect(str(p))
+    assert len(ref) == 81 and len(ref[40]) == 20_000_000
+    for threads in (2, 8):
+        got, _ = collect(str(p), threads=threads)
+        assert got == ref
+        got, _ = collect(str(p), max_bases=5_000_000, threads=threads)      # (the long record alone exceeds the batch limit: a batch of its own)
+        assert got == ref
