@@ -91,6 +91,18 @@ def test_create_without_gpu_fails_cleanly():
     assert e.value.code == -1
 
 
+def test_the_built_library_is_a_product_build():
+    """mdbg_build_flags() == 0: neither the wave-tile experiment's kernels nor an experiment's macros (inexact comparison, the ISA probe) went into the in-tree library;
+    the host-memory calls work without a device (ordinary memory until an ingest call sees it)"""
+    from rust_mdbg_amd import api
+    L = api.load_library()
+    assert L.mdbg_build_flags() == 0 and L.mdbg_abi_version() > 0
+    p = L.mdbg_host_alloc(1 << 16)
+    assert p and p % 4096 == 0 and L.mdbg_host_is_pinned(p) == 0
+    L.mdbg_host_free(p)
+    L.mdbg_host_free(None)
+
+
 def test_headers_are_plain_c_and_the_example_links(tmp_path):
     """include/*.h must be usable from C (the drop-in boundary is a C ABI): the plain-C example host compiles with gcc -std=c99
     and links against the two libraries (running it needs a GPU: tests/test_gpu_pipeline.py)"""
