@@ -62,21 +62,24 @@ mdbg_reader* mdbg_reader_open(const char* path, int strip_newlines, int* err);
 int mdbg_reader_next(mdbg_reader* r, uint64_t max_bases, const uint8_t** bases, const uint64_t** offsets, uint64_t* n_reads);
 int mdbg_reader_is_fasta(const mdbg_reader* r);
 /* The same reader with `threads` parser threads for UNCOMPRESSED files (seq_io's parallel readers, src/main.rs:830-839, parse records on
- * one thread and only run the per-read work in parallel): the file is mapped, every batch is a window of about max_bases file bytes
- * (2 * max_bases for FASTQ) cut at record starts and parsed piecewise by the same record code, so batches hold the same records in the
- * same order with the same bytes as mdbg_reader_open's, only cut at other places (never more than max_bases bases unless a window's last
- * record is longer).  FASTQ is taken as four-line records (as the streaming reader does).  .lz4 input and threads <= 1 fall back to
- * the streaming reader.  gzip input is inflated AHEAD of the parser on a thread of its own — a BGZF file (bgzip: independent blocks of at most
- * 64 KiB) by threads - 1 threads at once, and from four threads on an ordinary gzip stream too (pieces entered at block headers found by search,
- * decoded without their history, accepted only where the exact decoding of the piece in front ended) — and the inflated text is parsed in windows like a mapped file: the part of a window that holds whole
- * records goes to the parser threads, the rest is carried into the next window.  When the file is read in parallel, mdbg_reader_next alternates two buffers: a batch stays valid until the call
- * AFTER the next one, so that another thread can pack / copy batch i while batch i+1 is being parsed. */
+ * one thread and only run the per-read work in parallel): every batch is a window of about max_bases file bytes (2 * max_bases for FASTQ) cut at
+ * record starts, so batches hold the same records in the same order with the same bytes as mdbg_reader_open's, only cut at other places (never
+ * more than max_bases bases unless a window's last record is longer).  A window whose records are "header line + one sequence line" (FASTA) or
+ * four-line records (FASTQ, as the streaming reader takes them) is read ONCE: in chunks of 256 KB that up to 24 of the threads claim in file
+ * order, each read with pread into the thread's own buffer, its records located there and copied / packed from there to their place in the
+ * batch (a running sum of bases and records handed down the chunks).  Any other window (FASTA sequences over several lines, strip_newlines,
+ * stray lines, a record of many megabytes) is cut into one piece per thread and parsed by the streaming reader's record code on the mapped file.
+ * .lz4 input and threads <= 1 fall back to the streaming reader.  gzip input is inflated AHEAD of the parser on a thread of its own — a BGZF file
+ * (bgzip: independent blocks of at most 64 KiB) by several threads at once, an ordinary gzip stream by one — and the inflated text is parsed in
+ * windows the same way: the part of a window that holds whole records goes to the parser threads, the rest is carried into the next window.
+ * When the file is read in parallel, mdbg_reader_next alternates two buffers: a batch stays valid until the call AFTER the next one, so that
+ * another thread can pack / copy / ingest batch i while batch i+1 is being read. */
 mdbg_reader* mdbg_reader_open_mt(const char* path, int strip_newlines, int threads, int* err);
 /* Where the batch buffers handed out by a parallel reader (mdbg_reader_open_mt on an uncompressed file: the ASCII bases of mdbg_reader_next, the packed words of
  * mdbg_reader_next_packed of any reader) come from; default malloc / free.  With mdbg_host_alloc / mdbg_host_free of mdbg_hip.h the ingest calls page-lock them on
  * first use and the copy to the device is one DMA.  Before the first batch (MDBG_E_STATE afterwards); both or neither (NULL, NULL = malloc / free). */
 int mdbg_reader_set_allocator(mdbg_reader* r, void* (*alloc_fn)(size_t), void (*free_fn)(void*));
-int mdbg_reader_is_parallel(const mdbg_reader* r);      /* 1: the file is mapped and parsed by several threads (two alternating batch buffers) */
+int mdbg_reader_is_parallel(const mdbg_reader* r);      /* 1: the input is read by several threads (two alternating batch buffers) */
 void mdbg_reader_close(mdbg_reader* r);
 
 /* The next batch straight in the 2-bit packed layout (mdbg_packed_batch of mdbg_hip.h, HOST memory owned by the reader): what
