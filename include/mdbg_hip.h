@@ -213,8 +213,7 @@ const char* mdbg_strerror(int err);
 const char* mdbg_last_error(mdbg_ctx* ctx); /* detail of the last failure on ctx ("" if none) */
 uint32_t mdbg_abi_version(void);
 /* how the library was compiled: bit 0 = the wave-tile kernels of the round-4 experiment are in it (-DMDBG_WAVE_TILES; the default build has ONE tile shape
- * and ignores MDBG_TILE); bit 1 = an experiment's build (-DMDBG_EXP_SHORT_COMPARE: inexact key comparison; -DMDBG_ISA_PROBE: hot path only) — never a product
- * library.  The Makefile sets none of them: 0. */
+ * and ignores MDBG_TILE); bit 1: reserved (rounds 4-5 flagged experiment macros with it; the sources carry none since round 6).  The Makefile's build: 0. */
 uint32_t mdbg_build_flags(void);
 /* Device memory that contexts of this process have released is kept by the library for the next allocation (a hipMalloc that follows large
  * frees takes seconds on this stack); at most MDBG_CACHE_MB megabytes per device (environment; default a third of each device, 0 = keep nothing).

@@ -5,8 +5,8 @@ The SQ counters give instruction COUNTS per type (SQ_INSTS_VALU, ...); none of t
 SQ_THREAD_CYCLES_VALU = SQ_INSTS_VALU x 64 for a v_xor stream and a v_alignbit stream alike, profiles/r05_a_thread_cycles_probe.txt; PC sampling is
 not supported on the pool's boxes, ATT has no decoder library in the image).  So the split comes from the ISA:
 
-  1. the kernel is compiled once more with -DMDBG_ISA_PROBE (csrc/sketch.hip: the run-time conditions that are constant on the benchmark's workload
-     become compile-time constants, the phase stamps become marker lines), so the ISA of the probe build IS the hot path;
+  1. the kernel is compiled once more from a patched COPY of csrc/ (build_probe: MDBG_HOT(cond, value) yields `value`, i.e. the run-time conditions that are constant
+     on the benchmark's workload become compile-time constants, the phase stamps become marker lines), so the ISA of the probe build IS the hot path;
   2. every instruction is classed (full-rate VALU / half-rate VALU / SALU / LDS / VMEM / SMEM / control) with the rules measured in
      profiles/r01_g_valu_rates.txt (half rate: v_alignbit, v_perm, shifts left, v_bfe, v_bcnt, v_mbcnt, v_min/max, v_cmp, v_cndmask, multiplies,
      three-operand integer ops other than v_bitop3, packed 16-bit, DPP / SDWA forms, v_bfrev, 64-bit shifts, ANY VALU instruction with an SGPR source);
@@ -95,6 +95,30 @@ def parse_kernel(path, l):
     return insts
 
 
+def build_probe(l, asm):
+    """the probe: a COPY of csrc/ in a temporary directory in which MDBG_HOT(cond, value) yields `value` (the run-time conditions that are constant on the
+    benchmark's workload become compile-time constants) and the phase stamps become marker lines — the product sources have no switch for this"""
+    import shutil
+    import tempfile
+    src = os.path.join(ROOT, "rust_mdbg_amd", "csrc")
+    tmp = tempfile.mkdtemp(prefix="mdbg_isa_probe_")
+    work = os.path.join(tmp, "rust_mdbg_amd", "csrc")
+    shutil.copytree(src, work, ignore=shutil.ignore_patterns("*.o", "*.so"))
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+    p = os.path.join(work, "sketch.hip")
+    t = open(p).read()
+    hot, stamp = "#define MDBG_HOT(cond, value) (cond)", "#define MDBG_STAMP(i) do {"
+    assert t.count(hot) == 1 and t.count(stamp) == 1, "sketch.hip: the MDBG_HOT / MDBG_STAMP definitions moved"
+    t = t.replace(hot, "#define MDBG_HOT(cond, value) (value)")
+    a = t.index(stamp); b = t.index("\n", a)
+    t = t[:a] + '#define MDBG_STAMP(i) asm volatile("s_nop 0 ; MDBG_PHASE_MARK " #i ::: "memory")' + t[b:]
+    open(p, "w").write(t)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-DMDBG_ONLY_L=%d" % l,
+                           "-o", asm, "libmdbg.hip"], cwd=work, stderr=subprocess.DEVNULL)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return asm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--l", type=int, default=12)
@@ -110,8 +134,7 @@ def main():
     asm = args.asm
     if asm is None:
         asm = "/tmp/mdbg_isa_probe_l%d.s" % args.l
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-DMDBG_ONLY_L=%d" % args.l,
-                               "-DMDBG_ISA_PROBE", "-o", asm, "libmdbg.hip"], cwd=os.path.join(ROOT, "rust_mdbg_amd", "csrc"), stderr=subprocess.DEVNULL)
+        asm = build_probe(args.l, asm)
     insts = parse_kernel(asm, args.l)
     # dynamic counts per phase from the early-exit passes: cumulative -> per phase; per launch
     cum = {}

@@ -475,14 +475,11 @@ struct CandOut { u64 hash; u32 pos, read; };
 // comes from the arguments (no bit-sliced filter: phase 3 is the window-minimum machine over the dense stream).
 // WMAX (syncmers): the window w = l - s + 1 itself (1 .. 32): the register window of s-mer hashes and its loops are unrolled over exactly w entries
 // with static register indices
-// MDBG_ISA_PROBE (profiles/isa_issue.py only, never the product build): the run-time conditions that are constant on the benchmark's workload
-// (packed input, interior tile, homopolymer compression, no exception, sparse density) become compile-time constants, so that the ISA of the
-// probe build IS the hot path and its static instruction counts x trip counts can be compared with the SQ counters
-#ifdef MDBG_ISA_PROBE
-#define MDBG_HOT(cond, value) (value)
-#else
+// MDBG_HOT(cond, value) marks the run-time conditions that are constant on the benchmark's workload (packed input, interior tile, homopolymer
+// compression, no exception, sparse density).  The product evaluates `cond`.  profiles/isa_issue.py makes a COPY of these sources in a temporary
+// directory in which the macro yields `value` and the phase stamps become marker lines, and disassembles that copy: its ISA is the hot path, whose
+// static instruction counts x trip counts are compared with the SQ counters.  No build flag of the product sources does that.
 #define MDBG_HOT(cond, value) (cond)
-#endif
 template <int L, int SCHEME = 0, int WMAX = 1, int NW = 4, int TPW = 1>
 __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kernel(SketchArgs a) {
     typedef TG<NW> G;
@@ -503,11 +500,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     const u32 wg = blockIdx.x * TPW + (u32)tslot, gt = a.tile0 + wg;       // the launch's wg-th tile
     if (TPW > 1 && gt >= a.tile_end) return;          // (a whole wave; nothing below waits for it)
     Rec* const slab = a.slab + (size_t)wg * a.slab_cap;
-#ifdef MDBG_ISA_PROBE
-#define MDBG_STAMP(i) asm volatile("s_nop 0 ; MDBG_PHASE_MARK " #i ::: "memory")      // a line the ISA tool can find
-#else
 #define MDBG_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(size_t)gt * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-#endif
     MDBG_STAMP(0);
     const int64_t raw0 = (int64_t)gt * G::STRIDE - G::HALO;      // first staged raw position (negative for tile 0)
     const bool interior = MDBG_HOT(raw0 >= 0 && raw0 + RW * 32 <= nb, true);

@@ -151,10 +151,6 @@ __device__ inline bool same_key_window(const KeySrc& ks, u64 w, const u64* wl, b
         for (u32 j = 0; j < k; ++j) diff |= rp[j] ^ wl[cross ? k - 1 - j : j];
         return !diff;
     }
-#ifdef MDBG_EXP_SHORT_COMPARE
-    // EXPERIMENT ONLY (never in a product build; results are not exact): how much of the insertion is the representative's traffic?  Compare two values (one sector).
-    { const u64x2_a8 a = *(const u64x2_a8*)rp; return !cross ? (a.x == wl[0] && a.y == wl[1]) : (a.x == wl[k - 1] && a.y == wl[k - 2]); }
-#endif
     if (k >= 16) {
         // sixteen values per round trip (eight 16-byte loads in flight): k = 35 takes three dependent rounds instead of five
         for (u32 j = 0;; j += 16) {
@@ -259,7 +255,7 @@ void launch_owner_thresholds(double bound, u32 k, u32 world, u64* thr, hipStream
 // link; lane 0 always is one, nothing crosses a wave) passed.  Nothing is taken on trust: every accepted match is a full comparison or follows from one.  Links
 // need the neighbouring keys to have been created by neighbouring windows of ONE earlier read: common when a batch holds a copy or two of a region (a file
 // streamed in 256-Mbase batches), rare when one launch inserts dozens of copies that race for the claim (the benchmark's 50x batches: no gain there; an
-// experiment that compared 16 bytes of every representative — MDBG_EXP_SHORT_COMPARE, not exact — bounds what links can give at -18 % / -22 %).
+// experiment that compared 16 bytes of every representative — not exact, never shipped: profiles/r05_x_shortcmp.txt — bounds what links can give at -18 % / -22 %).
 // A lane that fails either way walks on with full comparisons like upsert_slot.
 __device__ inline u64 upsert_wave(const TableArgs& T, bool act, u32 li, u64 i, const u64* w, u32 k, bool& claimed, bool& found) {
     const int lane = threadIdx.x & 63;

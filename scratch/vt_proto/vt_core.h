@@ -21,7 +21,7 @@
 //          positions behind the END of an l-mer whose forward or reverse hash has its top VT_B bits clear (a NECESSARY condition
 //          for hash <= bound when the bound's top VT_B bits are clear; the survivors are re-evaluated exactly, 64 bits).
 #pragma once
-#include "bs_core.h"
+#include "../../rust_mdbg_amd/csrc/bs_core.h"
 
 constexpr int VT_B = 8;               // hash bits evaluated by the vertical filter
 

@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../rust_mdbg_amd/csrc/vt_core.h"
+#include "vt_core.h"
 
 typedef uint32_t u32; typedef uint64_t u64;
 

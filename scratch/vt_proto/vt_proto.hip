@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../rust_mdbg_amd/csrc/vt_core.h"
+#include "vt_core.h"
 typedef uint32_t u32;
 #ifndef PL
 #define PL 12

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../../rust_mdbg_amd/csrc/vt_core.h"
+#include "vt_core.h"
 typedef uint32_t u32;
 #ifndef PL
 #define PL 12

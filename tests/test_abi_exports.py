@@ -92,7 +92,7 @@ def test_create_without_gpu_fails_cleanly():
 
 
 def test_the_built_library_is_a_product_build():
-    """mdbg_build_flags() == 0: neither the wave-tile experiment's kernels nor an experiment's macros (inexact comparison, the ISA probe) went into the in-tree library;
+    """mdbg_build_flags() == 0: the wave-tile experiment's kernels did not go into the in-tree library (the product sources carry no other experiment switch since round 6);
     the host-memory calls work without a device (ordinary memory until an ingest call sees it)"""
     from rust_mdbg_amd import api
     L = api.load_library()

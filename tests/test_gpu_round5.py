@@ -61,7 +61,7 @@ def test_small_tile_gather_survives_slab_overflow_and_several_launches():
 @pytest.mark.gpu
 def test_default_build_has_one_tile_shape():
     from rust_mdbg_amd import api
-    assert api.load_library().mdbg_build_flags() == 0          # neither the wave tiles nor an experiment's macros (bit 1)
+    assert api.load_library().mdbg_build_flags() == 0          # no wave tiles (the only build switch left)
 
 
 @pytest.mark.gpu
