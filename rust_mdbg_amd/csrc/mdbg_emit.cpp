@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <new>
+#include <system_error>
 #include <cctype>
 #include <cerrno>
 #include <cstdlib>
@@ -248,65 +250,72 @@ int mdbg_emit_write_gfa(const char* path, const mdbg_nodes* nd, const mdbg_edges
     if (nd->n && (!nd->index || !nd->seqlen || !nd->abundance)) return MDBG_E_PARAM;      // (a table of mdbg_finalize_gfa holds these three columns and nothing else)
     FILE* f = fopen(path, "wb");
     if (!f) return MDBG_E_IO;
-    // The lines are formatted by a few threads, each a contiguous range of the S lines and of the L lines into a buffer of its own, and written in order
-    // (one thread: 31 ms per 465 k nodes + 910 k edges, a tenth of a file -> .gfa run at 25 Gbases/s).  Small graphs stay on the caller's thread.
+    // The lines are formatted by a few threads, each a contiguous range of lines into a buffer of its own, and written in order (one thread: 31 ms per 465 k nodes +
+    // 910 k edges, a tenth of a file -> .gfa run at 25 Gbases/s).  Small graphs stay on the caller's thread.  The work goes in ROUNDS of at most GFA_ROUND lines
+    // (first the S lines, then the L lines): the buffers hold one round, not the file (tens of millions of lines would be gigabytes), and an allocation that fails
+    // in a formatting thread ends the call with MDBG_E_NOMEM instead of the process.
     const u64 n_s = nd->n, n_l = ed ? ed->n : 0;
     const unsigned hw = std::thread::hardware_concurrency();
     const int T = n_s + n_l < 200000 ? 1 : (int)std::min<u64>(16, std::max<unsigned>(1, hw));
-    std::vector<std::string> s_part((size_t)T), l_part((size_t)T);
-    auto fmt = [&](int t) {
-        const u64 s0 = n_s * (u64)t / (u64)T, s1 = n_s * (u64)(t + 1) / (u64)T, l0 = n_l * (u64)t / (u64)T, l1 = n_l * (u64)(t + 1) / (u64)T;
-        char tmp[96];
-        std::string& S = s_part[(size_t)t]; S.reserve((s1 - s0) * 40 + 64);
-        for (u64 i = s0; i < s1; ++i) {                                                             // main.rs:1021  S\t{index}\t*\tLN:i:{seqlen}\tKC:i:{abundance}
-            char* p = tmp;
-            *p++ = 'S'; *p++ = '\t'; p = put_u32(p, nd->index[i]); memcpy(p, "\t*\tLN:i:", 8); p += 8; p = put_u32(p, nd->seqlen[i]); memcpy(p, "\tKC:i:", 6); p += 6;
-            p = put_u32(p, (u32)nd->abundance[i]); *p++ = '\n';
-            S.append(tmp, (size_t)(p - tmp));
-        }
-        std::string& Lp = l_part[(size_t)t]; Lp.reserve((l1 - l0) * 40 + 64);
-        for (u64 i = l0; i < l1; ++i) {                                                             // main.rs:1095  L\t{n1}\t{o1}\t{n2}\t{o2}\t{overlap}M
-            char* p = tmp;
-            *p++ = 'L'; *p++ = '\t'; p = put_u32(p, ed->n1[i]); *p++ = '\t'; *p++ = (char)ed->o1[i]; *p++ = '\t'; p = put_u32(p, ed->n2[i]); *p++ = '\t'; *p++ = (char)ed->o2[i]; *p++ = '\t';
-            p = put_u32(p, ed->overlap[i]); *p++ = 'M'; *p++ = '\n';
-            Lp.append(tmp, (size_t)(p - tmp));
+    static const u64 GFA_ROUND = [] { const char* e = getenv("MDBG_GFA_ROUND_LINES"); const u64 v = e ? strtoull(e, nullptr, 10) : 0; return v ? v : (u64)4 << 20; }();      // (the variable: tests)
+    std::vector<std::string> part((size_t)T);
+    std::atomic<int> bad{0}, nomem{0};
+    struct stat fst;
+    const int fd = fileno(f);
+    const bool positioned = T > 1 && fstat(fd, &fst) == 0 && S_ISREG(fst.st_mode);      // a regular file: every thread writes its part at its place (the copy into the page
+                                                                                         // cache was 10 of the 19 ms of this call for 465 k nodes + 910 k edges)
+    auto s_line = [&](u64 i, char* p) -> char* {                                        // main.rs:1021  S\t{index}\t*\tLN:i:{seqlen}\tKC:i:{abundance}
+        *p++ = 'S'; *p++ = '\t'; p = put_u32(p, nd->index[i]); memcpy(p, "\t*\tLN:i:", 8); p += 8; p = put_u32(p, nd->seqlen[i]); memcpy(p, "\tKC:i:", 6); p += 6;
+        p = put_u32(p, (u32)nd->abundance[i]); *p++ = '\n';
+        return p;
+    };
+    auto l_line = [&](u64 i, char* p) -> char* {                                        // main.rs:1095  L\t{n1}\t{o1}\t{n2}\t{o2}\t{overlap}M
+        *p++ = 'L'; *p++ = '\t'; p = put_u32(p, ed->n1[i]); *p++ = '\t'; *p++ = (char)ed->o1[i]; *p++ = '\t'; p = put_u32(p, ed->n2[i]); *p++ = '\t'; *p++ = (char)ed->o2[i]; *p++ = '\t';
+        p = put_u32(p, ed->overlap[i]); *p++ = 'M'; *p++ = '\n';
+        return p;
+    };
+    auto put = [&](const char* p, size_t n, u64 off) {
+        while (n) { const ssize_t w = pwrite(fd, p, n, (off_t)off); if (w < 0 && errno == EINTR) continue; if (w <= 0) { bad.store(1); return; } p += w; n -= (size_t)w; off += (u64)w; }
+    };
+    u64 file_at = 11;                                                                   // behind the header line
+    bool ok = true;
+    if (positioned) put("H\tVN:Z:1.0\n", 11, 0); else ok = fwrite("H\tVN:Z:1.0\n", 1, 11, f) == 11;      // main.rs:1011
+    auto emit = [&](u64 n_lines, bool l_lines) {
+        for (u64 r0 = 0; r0 < n_lines && ok && !bad.load() && !nomem.load(); r0 += GFA_ROUND) {
+            const u64 rn = std::min<u64>(GFA_ROUND, n_lines - r0);
+            auto fmt = [&](int t) {
+                const u64 i0 = r0 + rn * (u64)t / (u64)T, i1 = r0 + rn * (u64)(t + 1) / (u64)T;
+                char tmp[96];
+                try {
+                    std::string& S = part[(size_t)t]; S.clear(); S.reserve((i1 - i0) * 40 + 64);
+                    for (u64 i = i0; i < i1; ++i) { char* const e = l_lines ? l_line(i, tmp) : s_line(i, tmp); S.append(tmp, (size_t)(e - tmp)); }
+                } catch (const std::bad_alloc&) { nomem.store(1); }
+            };
+            {
+                std::vector<std::thread> th;
+                for (int t = 1; t < T; ++t) th.emplace_back(fmt, t);
+                fmt(0);
+                for (auto& x : th) x.join();
+            }
+            if (nomem.load()) return;
+            if (positioned) {
+                std::vector<u64> at((size_t)T + 1, file_at);
+                for (int t = 0; t < T; ++t) at[(size_t)t + 1] = at[(size_t)t] + part[(size_t)t].size();
+                auto wr = [&](int t) { put(part[(size_t)t].data(), part[(size_t)t].size(), at[(size_t)t]); };
+                std::vector<std::thread> th;
+                for (int t = 1; t < T; ++t) th.emplace_back(wr, t);
+                wr(0);
+                for (auto& x : th) x.join();
+                file_at = at[(size_t)T];
+            } else
+                for (int t = 0; ok && t < T; ++t) ok = part[(size_t)t].empty() || fwrite(part[(size_t)t].data(), 1, part[(size_t)t].size(), f) == part[(size_t)t].size();
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(fmt, t);
-        fmt(0);
-        for (auto& x : th) x.join();
-    }
-    struct stat fst;
-    if (T > 1 && fstat(fileno(f), &fst) == 0 && S_ISREG(fst.st_mode)) {
-        // a regular file: every thread writes its parts at their places (the copy into the page cache was 10 of the 19 ms of this call for 465 k nodes + 910 k edges)
-        std::vector<u64> at(2 * (size_t)T + 1, 11);
-        for (int t = 0; t < T; ++t) at[(size_t)t + 1] = at[(size_t)t] + s_part[(size_t)t].size();
-        for (int t = 0; t < T; ++t) at[(size_t)T + t + 1] = at[(size_t)T + t] + l_part[(size_t)t].size();
-        std::atomic<int> bad{0};
-        const int fd = fileno(f);
-        auto put = [&](const char* p, size_t n, u64 off) {
-            while (n) { const ssize_t w = pwrite(fd, p, n, (off_t)off); if (w < 0 && errno == EINTR) continue; if (w <= 0) { bad.store(1); return; } p += w; n -= (size_t)w; off += (u64)w; }
-        };
-        auto wr = [&](int t) {
-            if (t == 0) put("H\tVN:Z:1.0\n", 11, 0);                                                // main.rs:1011
-            put(s_part[(size_t)t].data(), s_part[(size_t)t].size(), at[(size_t)t]);
-            put(l_part[(size_t)t].data(), l_part[(size_t)t].size(), at[(size_t)T + t]);
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(wr, t);
-        wr(0);
-        for (auto& x : th) x.join();
-        const bool okc = fclose(f) == 0;
-        return okc && !bad.load() ? MDBG_OK : MDBG_E_IO;
-    }
-    bool ok = fwrite("H\tVN:Z:1.0\n", 1, 11, f) == 11;                                              // main.rs:1011
-    for (int t = 0; ok && t < T; ++t) ok = s_part[(size_t)t].empty() || fwrite(s_part[(size_t)t].data(), 1, s_part[(size_t)t].size(), f) == s_part[(size_t)t].size();
-    for (int t = 0; ok && t < T; ++t) ok = l_part[(size_t)t].empty() || fwrite(l_part[(size_t)t].data(), 1, l_part[(size_t)t].size(), f) == l_part[(size_t)t].size();
+    try { emit(n_s, false); emit(n_l, true); } catch (const std::bad_alloc&) { nomem.store(1); } catch (const std::system_error&) { nomem.store(1); }      // (a thread that could not be started)
     ok = ok && !ferror(f);                     // a short write (disk full) must not pass for a complete graph
     ok = (fclose(f) == 0) && ok;
-    return ok ? MDBG_OK : MDBG_E_IO;
+    if (nomem.load()) return MDBG_E_NOMEM;
+    return ok && !bad.load() ? MDBG_OK : MDBG_E_IO;
 }
 
 mdbg_seqfile* mdbg_seqfile_open(const char* path, uint32_t k, uint32_t l, int* err) {
@@ -476,18 +485,27 @@ struct Lz4In {
 
 // A pool of worker threads that lives as long as its reader: run(f) executes f(0) .. f(n - 1), f(0) on the caller.  (std::thread per batch and stage: 64 threads x 3
 // stages x ~40 us of spawn + join per 256-Mbase batch was a third of the reader's time at 64 threads, profiles/r04_n_file_pipeline.json -> r05_file_pipeline.json.)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
 struct WorkerPool {
     // A window of the reader is 2 - 3 ms of work for all threads, so how a round starts and ends matters: the round number and the count of workers still busy are
     // atomics; a worker that has finished spins on the round number for a moment (the next window usually follows at once) before it goes to sleep on the condition
     // variable, and the caller spins on the busy count (it was a second condition variable: 63 woken workers queueing for one mutex twice per round).
     std::vector<std::thread> th; std::mutex mu; std::condition_variable cv_go;
-    const std::function<void(int)>* job = nullptr; std::atomic<u64> epoch{0}; std::atomic<int> pending{0}; int n = 1; std::atomic<int> sleepers{0}; bool quit = false;
+    const std::function<void(int)>* job = nullptr; std::atomic<u64> epoch{0}; std::atomic<int> pending{0}, failed{0}; int n = 1; std::atomic<int> sleepers{0}; bool quit = false;
     explicit WorkerPool(int n_) : n(std::max(1, n_)) {
         for (int i = 1; i < n; ++i) th.emplace_back([this, i] {
             u64 seen = 0;
             for (;;) {
                 bool got = false;
-                for (int spin = 0; spin < 20000 && !got; ++spin) { if (epoch.load(std::memory_order_acquire) != seen) got = true; else __builtin_ia32_pause(); }
+                for (int spin = 0; spin < 20000 && !got; ++spin) { if (epoch.load(std::memory_order_acquire) != seen) got = true; else cpu_relax(); }
                 if (!got) {
                     std::unique_lock<std::mutex> lk(mu);
                     sleepers.fetch_add(1, std::memory_order_relaxed);
@@ -496,18 +514,21 @@ struct WorkerPool {
                     if (quit) return;
                 }
                 seen = epoch.load(std::memory_order_acquire);
-                (*job)(i);
+                try { (*job)(i); } catch (...) { failed.store(1, std::memory_order_relaxed); }      // (std::bad_alloc from a job's containers: the round's caller reports it)
                 pending.fetch_sub(1, std::memory_order_acq_rel);
             }
         });
     }
-    void run(const std::function<void(int)>& f) {
-        if (n == 1) { f(0); return; }
+    // false: a job threw (out of memory in one of its containers): the round's results are not to be used
+    bool run(const std::function<void(int)>& f) {
+        failed.store(0, std::memory_order_relaxed);
+        if (n == 1) { try { f(0); } catch (...) { return false; } return true; }
         job = &f; pending.store(n - 1, std::memory_order_relaxed);
         { std::lock_guard<std::mutex> lk(mu); epoch.fetch_add(1, std::memory_order_release); }      // (under the mutex: a worker between its predicate and its sleep cannot miss it)
         if (sleepers.load(std::memory_order_relaxed)) cv_go.notify_all();
-        f(0);
-        for (u32 spin = 0; pending.load(std::memory_order_acquire) != 0; ++spin) { if (spin < 4096) __builtin_ia32_pause(); else sched_yield(); }
+        try { f(0); } catch (...) { failed.store(1, std::memory_order_relaxed); }
+        for (u32 spin = 0; pending.load(std::memory_order_acquire) != 0; ++spin) { if (spin < 4096) cpu_relax(); else sched_yield(); }
+        return failed.load(std::memory_order_relaxed) == 0;
     }
     ~WorkerPool() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
 };
@@ -1066,7 +1087,9 @@ bool scan_piece(const u8* m, size_t a, size_t b, size_t file_end, bool fasta, bo
             size_t he = eol(p);
             if (he == p) { p = he + 1; continue; }                           // the general parser skips empty lines in front of a header
             if (he >= b) break;                                              // a header and nothing else: no record (as the general parser: its sequence line is missing)
-            const size_t s = he + 1, e = eol(s);
+            const size_t s = he + 1;
+            if (s >= b) break;                                               // "@header\n" and the end of the text: the same — no sequence line, no record (record_append)
+            const size_t e = eol(s);
             size_t ee = e; if (ee > s && m[ee - 1] == '\r') --ee;
             recs.push_back({s, ee - s}); n_bases += ee - s;
             if (e >= b) break;
@@ -1104,14 +1127,14 @@ static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, 
     std::unique_ptr<Link[]> link(new Link[C + 1]);
     for (size_t c = 0; c <= C; ++c) { link[c].ready.store(c == 0 ? 1u : 0u, std::memory_order_relaxed); link[c].base0 = link[c].read0 = 0; }
     std::atomic<size_t> next_chunk{0};
-    std::atomic<int> bad{0}, io_bad{0};
+    std::atomic<int> bad{0}, io_bad{0}, nomem{0};
     const bool avx2 = __builtin_cpu_supports("avx2");
     std::vector<ExcList> ex((size_t)T); std::vector<std::vector<Partial>> parts((size_t)T);
     static const bool timing = getenv("MDBG_READER_TIMING") != nullptr;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
     const double t0 = timing ? now() : 0;
     std::vector<double> waited((size_t)T, 0.0);
-    const std::function<void(int)> work = [&](int i) {
+    auto work_body = [&](int i) {
         for (;;) {
             const size_t c = next_chunk.fetch_add(1, std::memory_order_relaxed);
             if (c >= C || bad.load(std::memory_order_relaxed)) return;
@@ -1153,7 +1176,7 @@ static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, 
             const double tw = timing ? now() : 0;
             for (u32 spins = 0; !link[c].ready.load(std::memory_order_acquire); ++spins) {
                 if (bad.load(std::memory_order_relaxed)) return;
-                if (spins < 4096) __builtin_ia32_pause(); else sched_yield();
+                if (spins < 4096) cpu_relax(); else sched_yield();
             }
             if (timing) waited[(size_t)i] += now() - tw;
             if (!ok || link[c].base0 + nb > cap_bases) { bad.store(1, std::memory_order_relaxed); return; }
@@ -1166,7 +1189,10 @@ static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, 
             }
         }
     };
-    r->pool->run(work);
+    // (the job allocates — chunk buffers, record and exception lists —: a failure there ends the window with MDBG_E_NOMEM like the allocations of the calling thread; `bad`
+    // releases the workers that wait for the failed chunk's link)
+    const std::function<void(int)> work = [&](int i) { try { work_body(i); } catch (const std::bad_alloc&) { nomem.store(1, std::memory_order_relaxed); bad.store(1, std::memory_order_relaxed); } };
+    if (!r->pool->run(work) || nomem.load()) return MDBG_E_NOMEM;
     if (io_bad.load()) { r->io_error = true; return MDBG_E_IO; }
     if (bad.load()) return 0;
     const double t1 = timing ? now() : 0;
@@ -1175,7 +1201,7 @@ static int reader_fast_window(mdbg_reader* r, const size_t w0, const size_t w1, 
     const std::function<void(int)> lay = [&](int i) {
         for (size_t c = (size_t)i; c < C; c += (size_t)T) { u64 o = link[c].base0; size_t j = link[c].read0; for (const mdbg_reader::FastRec& q : r->fast_recs[c]) { r->offs[j++] = o; o += q.len; } }
     };
-    if (reads > 200000) r->pool->run(lay); else for (int i = 0; i < T; ++i) lay(i);
+    if (reads > 200000) { if (!r->pool->run(lay)) return MDBG_E_NOMEM; } else for (int i = 0; i < T; ++i) lay(i);
     r->offs[reads] = total;
     if (!ascii_out) {
         for (int i = 0; i < T; ++i) for (const Partial& q : parts[(size_t)i]) r->pw[q.word] = 0;       // words shared by records: clear, then OR the contributions

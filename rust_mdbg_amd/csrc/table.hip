@@ -859,12 +859,13 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
             if (F.claims) {
                 // the claimer's byte is set already (insert_windows_kernel); a key seen again may have an earlier sighting: move the mark there.  201 M scattered byte
                 // stores into a 721 MB map were 10 ms of the human table's finalize (1.3 TB/s); 183 M of those keys are seen once and cost nothing here
-                // ONE map in this mode: bit 0 = first sighting, bit 1 = the key is solid (no second map to zero: 2.2 ms per finalize of the human table); a byte only ever
-                // gains bits between two resets (abundances grow, and with the batches in ordinal order — the mode's condition — a first sighting never moves forward)
+                // ONE map in this mode: bit 0 = first sighting, bit 1 = the key is solid (no second map to zero: 2.2 ms per finalize of the human table); with the batches in ordinal order — the mode's
+                // condition — a first sighting never moves forward
                 const u64 Dc = (u32)e[u].word;
                 D = Dc;
                 if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; } }
-                if (D != Dc || solid[u]) F.by_first[D] = solid[u] ? 3 : 1;
+                // (a key seen again always rewrites its byte: its solid bit may have to GO — a u16 abundance that wrapped below minabund between two finalize calls, round-5 advice)
+                if (e[u].count || solid[u]) F.by_first[D] = solid[u] ? 3 : 1;
             } else {
             if (e[u].word & (1ull << 33)) { u64 i; const u64 ro = rep_ordinal(F, e[u].word); decode_ordinal(F, ro < e[u].m1 ? ro : e[u].m1, i, D); }   // routed record
             else {
@@ -950,11 +951,13 @@ __global__ __launch_bounds__(1024) void fin_mark_claims_kernel(FinArgs F) {
             const u32 count = e.count + 1u;
             solid = F.A == 1 || (u16)count >= (u16)F.A;
             // the claimer's byte is set already (insert_windows_kernel); a key seen again may have an earlier sighting: move the mark there.  ONE map in this mode: bit 0 =
-            // first sighting, bit 1 = the key is solid; a byte only ever gains bits between two resets (see fin_mark_kernel)
+            // first sighting, bit 1 = the key is solid (see fin_mark_kernel)
             const u64 Dc = (u32)e.word;
             D = Dc;
             if (e.count) { u64 i, D1; decode_ordinal(F, e.m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; } }
-            if (D != Dc || solid) F.by_first[D] = solid ? 3 : 1;
+            // every listed slot (seen again, or solid) rewrites its byte: the solid bit is also CLEARED — solidity is (u16)count >= (u16)A, which turns false again when the
+            // abundance wraps (count 65535 finalized as solid, more batches, count 65536 = u16 0, finalized again: round-5 advice; the byte-map path zeroes its maps per finalize)
+            F.by_first[D] = solid ? 3 : 1;
         }
         const u64 mk = __ballot(solid);
         u32 base = 0;

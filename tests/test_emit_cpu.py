@@ -226,6 +226,22 @@ def test_sequences_blocks_are_compressed(tmp_path):
 def test_large_gfa_written_by_several_threads_is_the_same_text(tmp_path):
     """graphs of 200 k lines and more are formatted by several threads (round 5), each a range of the S lines and of the L lines: the file is the text one
     thread writes (src/main.rs:1011,1021,1095), checked against Python's own formatting of a synthetic table"""
+    large_gfa_case(str(tmp_path / "big.gfa"))
+
+
+def test_large_gfa_in_several_rounds(tmp_path):
+    """the writer formats and writes in rounds of a bounded number of lines (round 6: its buffers hold one round, not the file); with rounds of 37,000 lines the test
+    table takes five rounds of S lines and six of L lines — the same text (the round size is read once per process: a child)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    child = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nfrom test_emit_cpu import large_gfa_case\nlarge_gfa_case(%r)\nprint('ROUNDS_OK')" % (
+        os.path.dirname(here), here, str(tmp_path / "rounds.gfa"))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=dict(os.environ, MDBG_GFA_ROUND_LINES="37000"), timeout=600)
+    assert r.returncode == 0 and "ROUNDS_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def large_gfa_case(p):
     import ctypes as C
     from rust_mdbg_amd.api import EdgeList
     rng = np.random.default_rng(5)
@@ -238,7 +254,6 @@ def test_large_gfa_written_by_several_threads_is_the_same_text(tmp_path):
     ov = rng.integers(0, 100000, m).astype(np.uint32)
     ed = EdgeList(n=m, n1=n1.ctypes.data_as(C.POINTER(C.c_uint32)), o1=o1.ctypes.data_as(C.POINTER(C.c_uint8)), n2=n2.ctypes.data_as(C.POINTER(C.c_uint32)),
                   o2=o2.ctypes.data_as(C.POINTER(C.c_uint8)), overlap=ov.ctypes.data_as(C.POINTER(C.c_uint32)), presimp_removed=0)
-    p = str(tmp_path / "big.gfa")
     E.Emitter().write_gfa(p, nodes, ed)
     want = ["H\tVN:Z:1.0"] + ["S\t%d\t*\tLN:i:%d\tKC:i:%d" % (nodes["index"][i], nodes["seqlen"][i], nodes["abundance"][i]) for i in range(n)]
     want += ["L\t%d\t%s\t%d\t%s\t%dM" % (n1[i], chr(o1[i]), n2[i], chr(o2[i]), ov[i]) for i in range(m)]

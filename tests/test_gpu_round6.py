@@ -1,0 +1,58 @@
+"""Round-6 additions checked on the GPU."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_gpu_parity import _mdbg, assert_nodes_equal, oracle_graph
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_claims", [False, True])
+def test_a_node_that_stops_being_solid_between_two_finalize_calls(no_claims):
+    """The abundance is a u16 that wraps (src/main.rs:663, release build) and the filter looks at the wrapped value (:927), so a k-min-mer can be solid at one finalize
+    and not at the next: 65,535 sightings (abundance 65535: solid for minabund 2), one more (65536 = u16 0: gone), two more (u16 2: back).  The claim-map finalize
+    keeps "solid" as bit 1 of the claim byte and until round 6 only ever SET it, so the second finalize listed no solid slot but left the bits in the bitmap
+    (round-5 advice).  Child process: MDBG_NO_CLAIMS (the byte-map path, which zeroes its maps per finalize) is read per finalize, the check is the same."""
+    child = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import random
+import numpy as np
+from test_gpu_parity import _mdbg, assert_nodes_equal, oracle_graph
+rnd = random.Random(3)
+read = bytes(rnd.choice(b"ACGT") for _ in range(420))
+other = [bytes(rnd.choice(b"ACGT") for _ in range(900)) for _ in range(6)]      # keys seen twice from the start: their claim bytes carry both bits all along
+k, l, d, A = 3, 8, 0.05, 2
+reads = other + other + [read] * 65535
+R = _mdbg()
+with R.Mdbg(k, l, d, A) as m:
+    m.ingest_reads(reads, 0)
+    a = m.finalize()
+    exp_a = oracle_graph(reads, k, l, d, A)
+    assert_nodes_equal(a, exp_a)
+    n_a = exp_a["n_nodes"]
+    assert int(np.max(exp_a["abundance"])) == 65535
+    m.ingest_reads([read], len(reads)); reads = reads + [read]
+    b = m.finalize()
+    exp_b = oracle_graph(reads, k, l, d, A)
+    assert exp_b["n_nodes"] < n_a and exp_b["n_nodes"] >= 6, (exp_b["n_nodes"], n_a)          # the wrapped keys left the table, the others stay
+    assert_nodes_equal(b, exp_b)
+    assert_nodes_equal(m.finalize(), exp_b)
+    m.ingest_reads([read, read], len(reads)); reads = reads + [read, read]
+    c = m.finalize()
+    exp_c = oracle_graph(reads, k, l, d, A)
+    assert exp_c["n_nodes"] == n_a
+    assert_nodes_equal(c, exp_c)
+    e = m.graph_edges(0.01)
+print("WRAP_BETWEEN_OK", n_a, exp_b["n_nodes"])
+""" % (ROOT, ROOT)
+    env = dict(os.environ)
+    if no_claims:
+        env["MDBG_NO_CLAIMS"] = "1"
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "WRAP_BETWEEN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -568,3 +568,27 @@ def test_a_record_of_many_megabytes_sends_its_window_to_the_general_parser(tmp_p
         assert got == ref
         got, _ = collect(str(p), max_bases=5_000_000, threads=threads)      # (the long record alone exceeds the batch limit: a batch of its own)
         assert got == ref
+
+
+@pytest.mark.parametrize("tail", [b"@last\n", b"@last", b"@last\r\n", b"@last\nACGT", b"@last\nACGT\n+", b"@last\n\n"])
+def test_fastq_that_ends_in_a_header_line(tail, tmp_path):
+    """a truncated FASTQ whose last bytes are a header line (with or without its newline): no record for it, on every path — the one-pass reader's scan pushed an empty
+    read for "@hdr\\n" at the end of the text where the streaming reader and the general parallel parser return none (round-5 advice; found by differential fuzz)"""
+    import random
+    rnd = random.Random(7)
+    data = random_records(rnd, 60, True) + tail
+    p = tmp_path / "t.fastq"
+    p.write_bytes(data)
+    ref, _ = collect(str(p))
+    for threads in (2, 4, 7):
+        for mb in (1 << 30, 9000):
+            got, _ = collect(str(p), max_bases=mb, threads=threads)
+            assert got == ref, (tail, threads, mb)
+    # the same through the general parallel parser (MDBG_READER_NO_FAST is read once per process: a child)
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nfrom test_reader_cpu import collect\n"
+             "a, _ = collect(%r); b, _ = collect(%r, threads=4); assert a == b; print('SAME', len(a))" % (os.path.dirname(here), here, str(p), str(p)))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=dict(os.environ, MDBG_READER_NO_FAST="1"), timeout=300)
+    assert r.returncode == 0 and ("SAME %d" % len(ref)) in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
