@@ -126,7 +126,8 @@ def expected_graph(args, world, shard_reads, total_bases):
                 continue
             if args.multik:
                 return {"nodes_per_k": w["graph"]["nodes_per_k"]}      # (global counts: the same at every N)
-            return dict(w["graph"]) if world == 1 else {"nodes": w["graph"]["nodes"]}
+            # (N > 1: the global node count and the digest of the union of the partitions — the same SET as the one-GPU table — are pinned; the other counts are per-rank stores)
+            return dict(w["graph"]) if world == 1 else {f: w["graph"][f] for f in ("nodes", "node_digest") if f in w["graph"]}
         if (w["n_gpus"], w["reads_per_gpu"], w["bases_per_gpu"]) == (world, shard_reads, total_bases):
             return w["graph"]
     return None
@@ -231,6 +232,11 @@ def issue_roofline(args, roof, n_cus):
     return None
 
 
+def hex_digest(dg):
+    """the order-free digest of a node table {(key, abundance)} (include/mdbg_hip.h, mdbg_nodes_digest; oracle/mdbg_oracle.cpp, orc_node_hash) as two hex words: sum, xor"""
+    return None if dg is None else ["0x%016x" % (int(dg[0]) & 0xFFFFFFFFFFFFFFFF), "0x%016x" % (int(dg[1]) & 0xFFFFFFFFFFFFFFFF)]
+
+
 def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     """Times the CPU oracle on a bounded prefix of the same reads, one worker per host core."""
     import numpy as np
@@ -250,12 +256,12 @@ def cpu_baseline(m_ctx, d_bases, d_off, n_reads, n_bases, args):
     r1 = max(r0, min(r1, n_reads))
     b1 = m_ctx.to_host(d_bases, int(offs[r1]))
     t = time.perf_counter()
-    solid, wins = O.count_threaded(b1, offs[:r1 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
+    solid, wins, dg = O.count_digest_threaded(b1, offs[:r1 + 1], args.k, args.l, args.density, args.minabund, threads=cores)
     dt = time.perf_counter() - t
     # whole: the sample IS the workload of one step, so its node and window counts are the oracle's answer for the configuration the headline is
     # measured on (src/main.rs:926-932 prints the same counters) — main() compares them with the GPU's and prints no line when they differ
     return {"value": float(offs[r1]) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "nodes": int(solid), "windows": int(wins), "whole_workload": bool(r1 == n_reads and int(offs[r1]) == int(n_bases)), "matches_gpu": None,
+            "nodes": int(solid), "windows": int(wins), "node_digest": hex_digest(dg), "whole_workload": bool(r1 == n_reads and int(offs[r1]) == int(n_bases)), "matches_gpu": None,
             "sample": "first %d reads (%.3f Gbases) of the same synthetic workload, %d threads, %.1f s; reads in RAM -> filtered node count; "
                       "the port sketches on all threads, deals the canonical k-min-mers into one bucket per thread by key hash and counts "
                       "every bucket on its own thread (no shared map, no serial merge)"
@@ -298,11 +304,14 @@ def scale_anchor_n1(R, torch, np, device_index, minabund):
     with R.Mdbg(k, l, d, minabund, device=device_index) as mh:
         batches, keep, shard_reads, _ = human_shards(mh, torch, np, gm, cov, range(HUMAN_SHARDS))
 
+        last = {}
+
         def one():
             mh.reset(0)
             for (b_in, b_off, b_reads, b_bases, b_first) in batches:
                 mh.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first)
-            return int(mh.finalize_device().n)
+            last["nd"] = mh.finalize_device()
+            return int(last["nd"].n)
         one()                                     # sizes the store and the table
         mh.sync()
         t1 = time.perf_counter()
@@ -313,11 +322,12 @@ def scale_anchor_n1(R, torch, np, device_index, minabund):
         ms = (time.perf_counter() - t1) / steps * 1e3
         st = mh.stats()
         total = sum(b[3] for b in batches)
+        digest = hex_digest(mh.nodes_digest(last["nd"]))
         del keep
     return {"what": "BASELINE.json configs[3] (synthetic human 3 Gb @52x, k=35 l=14 d=0.003): the workload of the N>1 lines of this script, streamed through THIS one GPU as "
                     "%d batches per step (= bench.py --gpus 1 --workload human), after the timed region" % HUMAN_SHARDS,
             "value": total / ms / 1e6, "unit": "Gbases/s", "ms_per_step": ms, "steps": steps, "total_bases": total,
-            "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": nodes}}
+            "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": nodes, "node_digest": digest}}
 
 
 def main():
@@ -418,6 +428,8 @@ def main():
             plan = D.plan_chunks(m.to_host(d_off, (reads_per_gpu + 1) * 8, np.uint64), n_chunks, keep_empty=replicate)
             offs_t = engine._view(d_off, (reads_per_gpu + 1,))
 
+    last_nd = {}                                      # the device node table of the last step (local context / multi-GPU layer): what the digest below is taken of
+
     def local_step(ascii_in=False):
         """the whole hot path on this rank's own context (no exchange): reset -> batches -> finalize"""
         m.reset(0)
@@ -428,7 +440,8 @@ def main():
                 m.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first)
             else:
                 m.ingest_device(b_in, b_off, b_reads, b_bases, b_first)
-        return m.finalize_device().n
+        last_nd["local"] = m.finalize_device()
+        return last_nd["local"].n
 
     per_k = []                                        # --multik: (k, global nodes) of the last sweep
     sweep_stats = {}                                  # --multik: the context's stats right after the sweep's ingest (every mdbg_reset restarts the timers)
@@ -462,6 +475,7 @@ def main():
                     cdist.ingest_device(b_in, b_off, b_reads, b_bases, b_first)
             nd, _, ng = cdist.finalize()
             cdist.last_local = int(nd.n)
+            last_nd["dist"] = nd
             return ng
         if not routed:
             return local_step()
@@ -501,6 +515,27 @@ def main():
         total_bases, n_ranks = n_bases, 1
     if n_ranks != args.gpus:
         raise SystemExit("bench.py: --gpus %d but %d rank(s) took part in the all-reduce" % (args.gpus, n_ranks))
+    # outside the timed region: the order-free digest of the node table the last timed step left on the device — of every rank's partition at N > 1, folded over the
+    # ranks (sum mod 2^64, XOR): the digest of the UNION of the partitions, comparable with the one-GPU table's and with the CPU oracle's (cpu_baseline)
+    node_digest = None
+    if not args.multik and (cdist is not None or not routed):
+        if os.environ.get("MDBG_BENCH_CORRUPT") == "abundance" and not routed and int(last_nd["local"].n):      # (test hook: one abundance of the device table + 1 — the line must be refused)
+            import ctypes
+            addr = ctypes.cast(last_nd["local"].abundance, ctypes.c_void_p).value
+            a0 = m.to_host(addr, 2, np.uint16)
+            a0[0] = np.uint16((int(a0[0]) + 1) & 0xFFFF)
+            assert m.L.mdbg_copy_to_device(m.h, ctypes.c_void_p(addr), a0.ctypes.data, 2) == 0
+        dg = cdist.nodes_digest(last_nd["dist"]) if cdist is not None else m.nodes_digest(last_nd["local"])
+        if dist is not None:
+            mine = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in dg], device=red_dev, dtype=torch.int64)
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            sm, xr = 0, 0
+            for t in parts:
+                a_, b_ = (int(v) & 0xFFFFFFFFFFFFFFFF for v in t.tolist())
+                sm = (sm + a_) & 0xFFFFFFFFFFFFFFFF; xr ^= b_
+            dg = (sm, xr)
+        node_digest = hex_digest(dg)
     consistent = None
     if routed:               # outside the timed region: the ranks' partitions must add up to the global node count
         loc = int(allreduce([(cdist if cdist is not None else runner).last_local], torch.int64)[0])
@@ -565,11 +600,11 @@ def main():
         multik_graph_rate = total_bases * args.steps * len(MULTIK) / dt / 1e9 if args.multik else None
         mins_per_base = st["n_minimizers"] / max(1, st["n_bases"])
 
-        def roofline(stt, b_in, fmt):
+        def roofline(stt, b_in, fmt, m_per_base=None):
             """algorithmic bytes per raw base of the sketch kernel = b_in + 12 m (input + u64 hash + u32 position)"""
             if not stt["n_sketch_tile_launches"]:
                 return None
-            per_base = b_in + 12.0 * mins_per_base
+            per_base = b_in + 12.0 * (mins_per_base if m_per_base is None else m_per_base)
             alg = stt["n_sketch_tile_bases"] * per_base
             avg_ms = stt["ms_sketch_tile"] / stt["n_sketch_tile_launches"]
             ach = alg / stt["n_sketch_tile_launches"] / (avg_ms * 1e-3) / 1e9
@@ -629,8 +664,27 @@ def main():
                         "value_pack_then_packed": n_bases / (pack_ms + ms_step) / 1e6 if pack_ms else None,
                         "what": "the same steps with the reads resident as ASCII (one byte per base): the tile kernel converts on the fly; pack_ms = mdbg_pack_device "
                                 "(ASCII -> 2-bit planes) alone; value_pack_then_packed = bases / (pack_ms + ms_per_step of the timed region)"}
+        def hpc_leg():
+            # The same launch with reads_already_hpc = 1 (src/read.rs:186-192, --skiphpc): the condition the reference's published timings were taken under ("reads and
+            # assemblies were homopolymer-compressed in those experiments", README.md:134).  The tile kernel then skips its phase 2 (keep masks, compaction, dense
+            # stream: a third of its instructions) and hashes the text as it is — every raw position is a dense one, so phase 3 walks a stream 1 / 0.75 as long.
+            with R.Mdbg(args.k, args.l, args.density, args.minabund, reads_already_hpc=True, device=device_index) as mh:
+                b_in, b_off, b_reads, b_bases, b_first = batches[0]
+                for _ in range(3):
+                    mh.reset(0)
+                    mh.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first, sketch_only=True)
+                sth = mh.stats()
+            rh = roofline(sth, 0.25, "packed, reads_already_hpc", sth["n_minimizers"] / max(1, sth["n_bases"]))
+            if rh:
+                rh["minimizers_per_base"] = sth["n_minimizers"] / max(1, sth["n_bases"])
+                rh["vs_timed_kernel"] = rh["avg_launch_ms"] / roof["avg_launch_ms"] if roof else None
+                rh["what"] = ("the tile kernel of the timed region on the same packed reads with reads_already_hpc = 1 (no homopolymer compression: phase 2 is skipped, the "
+                              "dense stream is the raw text); what the compaction costs, as a measurement")
+            return rh
+        roof_hpc = None
         if packed and not routed and not human and not args.plain:
             roof_ascii, ascii_in = side("ascii_in", ascii_leg, (None, None))
+            roof_hpc = side("roofline_hpc_input", hpc_leg)
             local_step()      # the table the edge stage and the baseline below refer to (not a side measurement: the counts below come from it)
 
         def edge_leg():
@@ -656,13 +710,28 @@ def main():
                 anchor1["checked_against_recorded_counts"] = bool(w3)
                 if w3 and args.minabund == 2 and any(anchor1["graph"][f] != w3[0]["graph"][f] for f in w3[0]["graph"]):
                     raise SystemExit("bench.py: the graph of the scale anchor %r differs from the recorded one %r: no line printed" % (anchor1["graph"], w3[0]["graph"]))
-        graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes)}
+        n1_same = None
+        if human and world > 1:
+            # the N=1 point of the same curve: measured in THIS run on rank 0's GPU when the ranks have a device each (the whole data set streamed through one local context
+            # while the other ranks wait: the same box, the same day, the same code as the N>1 value above it); a dry run on a shared device, or a failure, falls back to
+            # the committed N=1 line of the same workload (another box: the pool's boxes differ by a few per cent)
+            def same_run():
+                if host_comm or args.multik or (args.k, args.l, args.density, args.genome_mb, args.coverage) != (35, 14, 0.003, 3000.0, 52.0):
+                    return None          # (a dry run on a shared device, or not the configs[3] parameters: not measured here)
+                a1 = scale_anchor_n1(R, torch, np, device_index, args.minabund)
+                return {"value": a1["value"], "unit": a1["unit"], "ms_per_step": a1["ms_per_step"], "source": "this run, rank 0's GPU, after the timed region", "graph": a1["graph"],
+                        "what": "the same data set streamed through ONE GPU as %d batches (= bench.py --gpus 1 --workload human)" % HUMAN_SHARDS}
+            n1_same = side("n1_same_workload_same_run", same_run)
+            if n1_same is None:
+                n1_same = side("n1_same_workload", lambda: n1_same_workload(args))
+        graph = {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes), "node_digest": node_digest}
         if cpu is not None and cpu.get("whole_workload") and not human and not routed and not args.multik and not os.environ.get("MDBG_STOP_PHASE"):
             # the oracle has just counted the very reads the timed steps ingested: a full-size parity check of the headline configuration in every run
-            cpu["matches_gpu"] = bool(cpu["nodes"] == graph["nodes"] and cpu["windows"] == graph["windows"])
+            # ... and the node SETS: the oracle's digest over its (key, abundance) pairs against the digest of the device table of the last timed step
+            cpu["matches_gpu"] = bool(cpu["nodes"] == graph["nodes"] and cpu["windows"] == graph["windows"] and cpu["node_digest"] == node_digest)
             if not cpu["matches_gpu"]:
-                raise SystemExit("bench.py: the oracle counts %d nodes / %d windows on the whole workload, the GPU %d / %d: no line printed"
-                                 % (cpu["nodes"], cpu["windows"], graph["nodes"], graph["windows"]))
+                raise SystemExit("bench.py: the oracle finds %d nodes / %d windows / node digest %s on the whole workload, the GPU %d / %d / %s: no line printed"
+                                 % (cpu["nodes"], cpu["windows"], cpu["node_digest"], graph["nodes"], graph["windows"], node_digest))
         want = expected_graph(args, world, shard_reads, total_bases)
         if args.multik:
             graph["nodes_per_k"] = [list(x) for x in per_k]
@@ -697,15 +766,15 @@ def main():
                           "bases_per_gpu": n_bases, "batches_per_step": len(batches), "total_bases": total_bases, "input_format": args.input, "plain": bool(args.plain),
                           "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": par,
                           "comm": None if not routed else ("host-staged over gloo: DRY RUN, not RCCL" if host_comm else "rccl")},
-               "roofline": roof, "roofline_ascii": roof_ascii, "ascii_in": ascii_in,
+               "roofline": roof, "roofline_ascii": roof_ascii, "roofline_hpc_input": roof_hpc, "ascii_in": ascii_in,
                "value_ascii_in": ascii_in["value"] if ascii_in else None, "ms_per_step_ascii_in": ascii_in["ms_per_step"] if ascii_in else None, "pack_ms": pack_ms,
                "cpu_baseline": cpu, "multik_graph_gbases_per_s": multik_graph_rate, "multik_graphs_per_s": (len(MULTIK) * args.steps / dt) if args.multik else None,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
-               "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes),
-                         "checked_against_recorded_counts": want is not None,
+               "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes), "node_digest": node_digest,
+                         "checked_against_recorded_counts": want is not None, "digest_checked_against_recorded": bool(want is not None and "node_digest" in want),
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],
                          "partitions_add_up": consistent, "nodes_per_k": per_k if args.multik else None},
-               "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": side("n1_same_workload", lambda: n1_same_workload(args)) if (human and world > 1) else None, "scale_anchor_n1": anchor1,
+               "exchange": exchange, "no_exchange_anchor": anchor, "n1_same_workload": n1_same, "scale_anchor_n1": anchor1,
                "edges_after_timed_region": edges, "side_errors": side_errors or None}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()

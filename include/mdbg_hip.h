@@ -186,6 +186,13 @@ int mdbg_finalize_device(mdbg_ctx* ctx, mdbg_nodes* out);
  * comes to the host — out->index, out->seqlen, out->abundance (HOST arrays: 10 bytes per node instead of 8 k + 58); every other pointer of *out is NULL.
  * mdbg_emit_write_gfa accepts such a table, the .sequences writer and mdbg_emit_edges do not (they need the minimizer lists: MDBG_E_PARAM). */
 int mdbg_finalize_gfa(mdbg_ctx* ctx, mdbg_nodes* out);
+/* Order-free digest of a node table whose arrays are in DEVICE memory (mdbg_finalize_device, mdbg_dist_finalize): per node
+ *   h = 0x243F6A8885A308D3 ^ abundance;  h = fmix64(h ^ key[j]) for j = 0 .. k-1     (fmix64: the 64-bit finaliser of MurmurHash3)
+ * *sum = the sum of h over the nodes mod 2^64, *xr = their XOR.  Equal digests and node counts: the same set of (key, abundance) pairs, i.e. what
+ * dbg_nodes holds after the abundance filter (src/main.rs:922-929), whatever the order of the rows; the digests of the ranks' partitions of a multi-GPU
+ * run add / XOR up to the digest of the one-GPU table.  Only nodes->n, k, keys, abundance are read.  (bench.py compares it with the CPU oracle's digest
+ * of the same reads in every run: a full-size check of the node SET, not of two counts.) */
+int mdbg_nodes_digest(mdbg_ctx* ctx, const mdbg_nodes* nodes, uint64_t* sum, uint64_t* xr);
 /* Multi-k: keep every cached sketch and all allocations, clear the node table, and re-window the
  * resident sketches with new_k (new_k == 0: also drop the sketches = start over with the same parameters). */
 int mdbg_reset(mdbg_ctx* ctx, uint32_t new_k);

@@ -593,8 +593,26 @@ struct VecHash { size_t operator()(const Kmer& v) const { u64 h = 0x9E3779B97F4A
 struct KeyRef { const u64* p; u32 k; };
 struct KeyRefHash { size_t operator()(const KeyRef& a) const { u64 h = 0x9E3779B97F4A7C15ULL; for (u32 i = 0; i < a.k; ++i) { h ^= a.p[i]; h *= 0xff51afd7ed558ccdULL; h ^= h >> 32; } return (size_t)h; } };
 struct KeyRefEq { bool operator()(const KeyRef& a, const KeyRef& b) const { return std::memcmp(a.p, b.p, (size_t)a.k * 8) == 0; } };
+// Order-free digest of a filtered node table {(key, abundance)} (what dbg_nodes holds after src/main.rs:922-929): per node
+//   h = 0x243F6A8885A308D3 ^ abundance;  h = fmix64(h ^ key[j]) for j = 0 .. k-1   (fmix64: the 64-bit finaliser of MurmurHash3)
+// and over the table digest[0] = sum of h mod 2^64, digest[1] = XOR of h.  Two tables with the same digest and node count hold the same set of
+// (key, abundance) pairs (up to a 2^-64-ish collision); the digests of disjoint partitions add / XOR up to the whole table's.  The library computes the same
+// formula over its device table (mdbg_nodes_digest, include/mdbg_hip.h): bench.py compares the two on the whole benchmark workload in every run.
+static inline u64 orc_fmix64(u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+static inline u64 orc_node_hash(const u64* key, u64 k, u16 abundance) {
+    u64 h = 0x243F6A8885A308D3ULL ^ (u64)abundance;
+    for (u64 j = 0; j < k; ++j) h = orc_fmix64(h ^ key[j]);
+    return h;
+}
+int64_t orc_count_digest_threaded(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t k, uint64_t l, double density,
+                                  uint32_t minabund, int already_hpc, int threads, uint64_t* n_windows, uint64_t* digest);
 int64_t orc_count_threaded(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t k, uint64_t l, double density,
                            uint32_t minabund, int already_hpc, int threads, uint64_t* n_windows) {
+    return orc_count_digest_threaded(bases, offsets, n_reads, k, l, density, minabund, already_hpc, threads, n_windows, nullptr);
+}
+// digest (null: not wanted): [0] sum, [1] XOR of the solid nodes' hashes (above)
+int64_t orc_count_digest_threaded(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t k, uint64_t l, double density,
+                                  uint32_t minabund, int already_hpc, int threads, uint64_t* n_windows, uint64_t* digest) {
     if (threads < 1) threads = 1;
     const size_t P = (size_t)threads;
     std::vector<std::vector<std::vector<u64>>> deal(P, std::vector<std::vector<u64>>(P));      // deal[producer][owner]: keys, k values each
@@ -619,15 +637,19 @@ int64_t orc_count_threaded(const uint8_t* bases, const uint64_t* offsets, uint64
         }
     };
     std::vector<int64_t> solids(P, 0);
+    std::vector<u64> dsum(P, 0), dxor(P, 0);
     auto count = [&](size_t o) {
         size_t n = 0;
         for (size_t t = 0; t < P; ++t) n += deal[t][o].size() / k;
         std::unordered_map<KeyRef, u32, KeyRefHash, KeyRefEq> m;
         m.reserve(n);
         for (size_t t = 0; t < P; ++t) { const auto& v = deal[t][o]; for (size_t q = 0; q + k <= v.size(); q += k) m[KeyRef{v.data() + q, (u32)k}] += 1; }
-        int64_t s = 0;
-        for (auto& kv : m) if ((u16)kv.second >= (u16)minabund || minabund <= 1) ++s;
-        solids[o] = s;
+        int64_t s = 0; u64 ds = 0, dx = 0;
+        for (auto& kv : m) if ((u16)kv.second >= (u16)minabund || minabund <= 1) {
+            ++s;
+            if (digest) { const u64 h = orc_node_hash(kv.first.p, k, (u16)kv.second); ds += h; dx ^= h; }
+        }
+        solids[o] = s; dsum[o] = ds; dxor[o] = dx;
     };
     auto run = [&](auto fn) {
         std::vector<std::thread> th;
@@ -642,6 +664,7 @@ int64_t orc_count_threaded(const uint8_t* bases, const uint64_t* offsets, uint64
     for (auto x : solids) solid += x;
     for (auto x : wins) w += x;
     if (n_windows) *n_windows = w;
+    if (digest) { digest[0] = digest[1] = 0; for (size_t o = 0; o < P; ++o) { digest[0] += dsum[o]; digest[1] ^= dxor[o]; } }
     return solid;
 }
 

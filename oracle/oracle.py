@@ -91,6 +91,9 @@ def lib():
     L.orc_count_threaded.restype = C.c_int64
     L.orc_count_threaded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double,
                                      C.c_uint32, C.c_int, C.c_int, u64p]
+    L.orc_count_digest_threaded.restype = C.c_int64
+    L.orc_count_digest_threaded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double,
+                                            C.c_uint32, C.c_int, C.c_int, u64p, u64p]
     _LIB = L
     return L
 
@@ -306,3 +309,36 @@ def count_threaded(bases, offsets, k, l, density, minabund=2, already_hpc=False,
     if r < 0:
         raise ValueError("oracle error %d" % r)
     return int(r), int(w.value)
+
+
+def count_digest_threaded(bases, offsets, k, l, density, minabund=2, already_hpc=False, threads=1):
+    """-> (solid nodes, window occurrences, (sum, xor)): the counts of count_threaded plus the order-free digest of the filtered node table {(key, abundance)}
+    (mdbg_oracle.cpp, orc_node_hash)"""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    w = C.c_uint64()
+    dg = (C.c_uint64 * 2)()
+    r = L.orc_count_digest_threaded(bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, l, density, minabund,
+                                    int(already_hpc), threads, C.byref(w), dg)
+    if r < 0:
+        raise ValueError("oracle error %d" % r)
+    return int(r), int(w.value), (int(dg[0]), int(dg[1]))
+
+
+def nodes_digest(keys, abundance):
+    """the same digest from a node table held as arrays (keys: n x k u64, abundance: n u16) — plain numpy, for tests"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n = len(abundance)
+    keys = keys.reshape(n, -1) if n else keys.reshape(0, 1)
+    M = (1 << 64) - 1
+
+    def fmix(x):
+        x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xff51afd7ed558ccd)
+        x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xc4ceb9fe1a85ec53)
+        return x ^ (x >> np.uint64(33))
+    with np.errstate(over="ignore"):
+        h = np.uint64(0x243F6A8885A308D3) ^ np.asarray(abundance, dtype=np.uint16).astype(np.uint64)
+        for j in range(keys.shape[1]):
+            h = fmix(h ^ keys[:, j])
+        return (int(h.sum(dtype=np.uint64)) & M if n else 0, int(np.bitwise_xor.reduce(h)) if n else 0)

@@ -1247,6 +1247,26 @@ __global__ __launch_bounds__(256) void fin_emit_kernel(FinArgs F, u64 n_solid) {
     }
 }
 
+// order-free digest of a node table (include/mdbg_hip.h, mdbg_nodes_digest): one thread per node, the workgroup's sum and XOR go to out[0], out[1] with one atomic each
+__global__ __launch_bounds__(256) void nodes_digest_kernel(const u64* __restrict__ keys, const u16* __restrict__ abund, u64 n, u32 k, unsigned long long* __restrict__ out) {
+    __shared__ u64 ws[2][4];
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 h = 0;
+    if (q < n) {
+        h = 0x243F6A8885A308D3ull ^ (u64)abund[q];
+        const u64* kp = keys + q * k;
+        for (u32 j = 0; j < k; ++j) h = fmix64(h ^ kp[j]);
+    }
+    u64 sm = h, xr = h;
+    for (int d = 32; d; d >>= 1) { sm += __shfl_down(sm, d, 64); xr ^= __shfl_down(xr, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = sm; ws[1][threadIdx.x >> 6] = xr; }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&out[0], (unsigned long long)(ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3])); atomicXor(&out[1], (unsigned long long)(ws[1][0] ^ ws[1][1] ^ ws[1][2] ^ ws[1][3])); }
+}
+void launch_nodes_digest(const u64* keys, const u16* abund, u64 n, u32 k, u64* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(nodes_digest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, abund, n, k, (unsigned long long*)out);
+}
+
 // ---- positions of remote sketches, fetched on demand (multi-GPU sketch exchange, include/mdbg_dist.h) ----------------------------------
 // The ranks exchange HASHES only (8 of the 12 bytes per minimizer).  Raw positions are needed for one thing: seqlen / shift / origin of
 // the A-th sighting of a solid node (fin_emit_kernel reads p[0], p[1], p[k-2], p[k-1] of that window), and only the rank that sketched

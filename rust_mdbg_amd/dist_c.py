@@ -183,6 +183,12 @@ class DistMdbg:
         self._chk(self.L.mdbg_dist_finalize(self.h, C.byref(nd), C.byref(row), C.byref(ng)))
         return nd, row.value, int(ng.value)
 
+    def nodes_digest(self, nd):
+        """(sum, xor) over this rank's partition (a table of finalize()): the ranks' digests add / XOR up to the one-GPU table's (include/mdbg_hip.h, mdbg_nodes_digest)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.mdbg_nodes_digest(C.c_void_p(self.L.mdbg_dist_ctx(self.h)), C.byref(nd), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def reset(self, new_k=0):
         self._chk(self.L.mdbg_dist_reset(self.h, new_k))
 

@@ -30,6 +30,8 @@ def test_bench_two_ranks_dry_run_matches_one_rank():
     assert two["config"]["total_bases"] == one["config"]["total_bases"] and 2 * two["config"]["bases_per_gpu"] != 0
     # the same data set, the same graph: the partitions add up to the node count one context finds
     assert two["graph"]["partitions_add_up"] is True and two["graph"]["nodes"] == one["graph"]["nodes"] > 1000
+    # ... and the same SET of (key, abundance) pairs: the digests of the two partitions add / XOR up to the one-GPU table's (round 6)
+    assert one["graph"]["node_digest"] and two["graph"]["node_digest"] == one["graph"]["node_digest"]
     assert two["exchange"]["bytes_in_busiest_rank_per_step"] > 0 and "not RCCL" in two["exchange"]["transport"]
     assert two["no_exchange_anchor"] and two["no_exchange_anchor"]["value"] > 0
     assert "DRY RUN" in two["config"]["parallelism"] and "not RCCL" in two["config"]["comm"]
@@ -41,6 +43,8 @@ def test_bench_default_line_carries_the_ascii_leg():
     j = _bench("--gpus", "1", "--genome-mb", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0")
     a = j["ascii_in"]
     assert j["config"]["workload_key"] == "fly" and a["ms_per_step"] > 0 and a["pack_ms"] > 0 and 0 < a["value_pack_then_packed"] < j["value"]
+    h = j["roofline_hpc_input"]          # round 6: the same launch with reads_already_hpc = 1 (README.md:134: the condition of the published timings)
+    assert h["avg_launch_ms"] > 0 and h["minimizers_per_base"] > j["graph"]["minimizers"] / j["config"]["bases_per_gpu"] and 0 < h["frac"] < 1
     assert "valu_util" not in j["roofline"]
 
 
@@ -52,6 +56,20 @@ def test_bench_cpu_leg_checks_the_whole_workload_against_the_oracle():
     c = j["cpu_baseline"]
     assert c["whole_workload"] is True and c["matches_gpu"] is True
     assert c["nodes"] == j["graph"]["nodes"] > 1000 and c["windows"] == j["graph"]["windows"] > 1000
+    # round 6: not two counts but the node SET — the oracle's order-free digest over its (key, abundance) pairs equals the digest of the device table
+    assert c["node_digest"] == j["graph"]["node_digest"] and len(c["node_digest"]) == 2 and c["node_digest"][0] != "0x%016x" % 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_the_line_when_one_abundance_differs():
+    """the same run with ONE abundance of the device node table changed behind the timed region (a test hook of bench.py): node and window counts are what they were,
+    the digest is not — no line, a non-zero exit and the reason on stderr"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MDBG_BENCH_CORRUPT"] = "abundance"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--genome-mb", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "60", "--no-scale-anchor"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.strip()], (r.returncode, r.stdout[-500:])
+    assert "no line printed" in r.stderr and "node digest" in r.stderr, r.stderr[-2000:]
 
 
 @pytest.mark.gpu
@@ -81,17 +99,18 @@ def test_bench_one_rank_through_the_rccl_transport():
     rccl = _bench("--gpus", "1", "--force-dist", *small)
     assert rccl["config"]["comm"] == "rccl" and "RCCL" in rccl["exchange"]["transport"] and rccl["graph"]["partitions_add_up"] is True
     assert rccl["graph"]["nodes"] == one["graph"]["nodes"] and rccl["config"]["batches_per_step"] == 8 and rccl["no_exchange_anchor"]["value"] > 0
+    assert rccl["graph"]["node_digest"] == one["graph"]["node_digest"]
 
 
 @pytest.mark.gpu
 def test_bench_prints_its_line_when_side_measurements_fail():
     """everything measured beside the headline (recorded profiles, the ASCII leg, the edge stage, the CPU leg, the anchors) may fail: the line is still
     printed, with the failure named under side_errors"""
-    every = "pmc_traffic,issue_roofline,sq_counters,ascii_in,edges_after_timed_region,cpu_baseline,n1_same_workload,no_exchange_anchor"
+    every = "pmc_traffic,issue_roofline,sq_counters,ascii_in,roofline_hpc_input,edges_after_timed_region,cpu_baseline,n1_same_workload,no_exchange_anchor"
     j = _bench("--gpus", "1", "--genome-mb", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "5", "--no-scale-anchor", MDBG_BENCH_FAIL_SIDE=every)
     assert j["value"] > 0 and j["graph"]["nodes"] > 1000 and j["roofline"]["frac"] > 0
-    assert set(j["side_errors"]) == {"pmc_traffic", "issue_roofline", "sq_counters", "ascii_in", "edges_after_timed_region", "cpu_baseline"}
-    assert j["ascii_in"] is None and j["edges_after_timed_region"] is None and j["cpu_baseline"] is None and j["roofline"]["traffic"] is None
+    assert set(j["side_errors"]) == {"pmc_traffic", "issue_roofline", "sq_counters", "ascii_in", "roofline_hpc_input", "edges_after_timed_region", "cpu_baseline"}
+    assert j["roofline_hpc_input"] is None and j["ascii_in"] is None and j["edges_after_timed_region"] is None and j["cpu_baseline"] is None and j["roofline"]["traffic"] is None
     small = ["--workload", "human", "--genome-mb", "40", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0"]
     two = _bench("--gpus", "2", "--comm", "host", *small, MDBG_BENCH_FAIL_SIDE=every)
     assert two["n_gpus"] == 2 and two["value"] > 0 and two["graph"]["partitions_add_up"] is True

@@ -56,3 +56,24 @@ print("WRAP_BETWEEN_OK", n_a, exp_b["n_nodes"])
         env["MDBG_NO_CLAIMS"] = "1"
     r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "WRAP_BETWEEN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_nodes_digest_of_the_device_table_equals_the_oracles():
+    """mdbg_nodes_digest (include/mdbg_hip.h) over the device table of mdbg_finalize_device = the oracle's digest of its own node table (plain numpy over the oracle's
+    rows, and orc_count_digest_threaded over the reads), for minabund 1 and 2; an empty table digests to (0, 0)"""
+    from oracle import oracle as O
+    from rust_mdbg_amd import synth
+    reads = synth.synth_reads(11, 200000, 500, mean_len=9000, sd_len=1500, min_len=3000, max_len=15000, err_ppm=1500)
+    b, o = O.concat_reads(reads)
+    R = _mdbg()
+    for (k, l, d, A) in ((9, 12, 0.004, 2), (5, 10, 0.01, 1), (21, 12, 0.003, 2)):
+        exp = oracle_graph(reads, k, l, d, A)
+        want = O.nodes_digest(exp["keys"], exp["abundance"])
+        assert O.count_digest_threaded(b, o, k, l, d, A, threads=4)[2] == want
+        with R.Mdbg(k, l, d, A) as m:
+            m.ingest(b, o, 0)
+            nd = m.finalize_device()
+            assert int(nd.n) == exp["n_nodes"] > 100 and m.nodes_digest(nd) == want
+            m.reset(0)
+            assert m.nodes_digest(m.finalize_device()) == (0, 0)
