@@ -96,7 +96,11 @@ def test_config3_size_properties():
         import json
         want = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w.get("reads_per_gpu") == n_reads and w["l"] == l][0]
         assert nb == want["bases_per_gpu"]
-        assert {"minimizers": st3["n_minimizers"], "windows": st3["n_windows"], "distinct": st3["n_distinct"], "nodes": three["n_nodes"]} == want["graph"]
+        got3 = {"minimizers": st3["n_minimizers"], "windows": st3["n_windows"], "distinct": st3["n_distinct"], "nodes": three["n_nodes"]}
+        assert all(got3[f] == want["graph"][f] for f in got3)
+        # ... and the recorded node digest (what bench.py compares with the oracle's in every run) is the digest of this very table, computed here in plain numpy
+        from oracle import oracle as O
+        assert ["0x%016x" % v for v in O.nodes_digest(three["keys"], three["abundance"])] == want["graph"]["node_digest"]
         assert (st["n_minimizers"], st["n_windows"], st["n_distinct"]) == (st3["n_minimizers"], st3["n_windows"], st3["n_distinct"])
         # 5. multi-k on the resident sketches == a fresh context with that k
         m.reset(21)
