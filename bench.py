@@ -492,6 +492,12 @@ def main():
         torch.cuda.synchronize()
         m.sync()
 
+    # The timed steps record the events around the tile kernel only (mdbg_set_timing(1): what `roofline` is made of); the events around the stages (~4 microseconds of
+    # stream time each, six per batch + two per finalize) are switched on for ONE further step after the timed region, which is what stage_ms_last_step reports.
+    timed_level = 2 if (os.environ.get("MDBG_BENCH_STAGE_EVENTS") or args.multik or (routed and cdist is None)) else 1      # (the variable: A/B switch — the stage events inside the
+                                                                                                                            # timed region, as until round 5; the sweep and the Python harness keep them)
+    for ctx_ in ([m] + ([cdist] if cdist is not None else [])):
+        ctx_.set_timing(timed_level)
     for _ in range(args.warmup):
         step()
     fence()
@@ -575,6 +581,12 @@ def main():
         if t_min > 0:
             anchor = {"what": "the same %d rank(s), each pushing its own %d batch(es) through one local context: no exchange, table not partitioned (after the timed region; "
                               "slowest rank)" % (world, len(batches)), "value": total_bases / t_max / 1e9, "unit": "Gbases/s", "ms_per_step": t_max * 1e3}
+    # one more step with the stage timers on (outside the timed region): its stage times are the line's stage_ms_last_step
+    for ctx_ in ([m] + ([cdist] if cdist is not None else [])):
+        ctx_.set_timing(2)
+    if not args.multik and (cdist is not None or not routed):
+        step()
+        fence()
     st = m.stats()          # stats of the last step only (reset clears the timers)
     if cdist is not None:
         m_stats = api_stats_of(cdist)
@@ -769,7 +781,9 @@ def main():
                "roofline": roof, "roofline_ascii": roof_ascii, "roofline_hpc_input": roof_hpc, "ascii_in": ascii_in,
                "value_ascii_in": ascii_in["value"] if ascii_in else None, "ms_per_step_ascii_in": ascii_in["ms_per_step"] if ascii_in else None, "pack_ms": pack_ms,
                "cpu_baseline": cpu, "multik_graph_gbases_per_s": multik_graph_rate, "multik_graphs_per_s": (len(MULTIK) * args.steps / dt) if args.multik else None,
-               "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"]},
+               "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"],
+                                      "measured_in": "one further step after the timed region with the stage events on (mdbg_set_timing(2)); the timed steps record the tile kernel's events only"
+                                                     if timed_level == 1 else "the last timed step (stage events on in the timed region: MDBG_BENCH_STAGE_EVENTS)"},
                "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": int(n_nodes), "node_digest": node_digest,
                          "checked_against_recorded_counts": want is not None, "digest_checked_against_recorded": bool(want is not None and "node_digest" in want),
                          "slow_tiles": st["n_slow_tiles"], "tiles": st["n_tiles"], "table_capacity": st["table_capacity"],

@@ -216,6 +216,12 @@ int mdbg_mark(mdbg_ctx* ctx, uint64_t* mark);
 int mdbg_rewind(mdbg_ctx* ctx, uint64_t mark);
 
 int mdbg_get_stats(mdbg_ctx* ctx, mdbg_stats* out);
+/* Which HIP events the context records for the ms_* fields of mdbg_stats.  An event is a marker packet with a timestamp on the stream: about 4 microseconds of device
+ * time each (scratch/ubench/event_cost.hip), i.e. ~35 microseconds per ingested batch + finalize at level 2 — 1.2 % of a 2.8-ms configs[2] step.
+ *   2 (default): around the stages (ms_sketch, ms_insert, ms_finalize) and around every tile-kernel launch (ms_sketch_tile);
+ *   1: around the tile-kernel launches only (ms_sketch / ms_insert / ms_finalize stay 0);   0: none (every ms_* field stays 0).
+ * Results never depend on it. */
+int mdbg_set_timing(mdbg_ctx* ctx, uint32_t level);
 const char* mdbg_strerror(int err);
 const char* mdbg_last_error(mdbg_ctx* ctx); /* detail of the last failure on ctx ("" if none) */
 uint32_t mdbg_abi_version(void);

@@ -76,7 +76,7 @@ class SynthParams(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
-EXPORTS = ["mdbg_abi_version", "mdbg_build_flags", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_finalize_gfa", "mdbg_nodes_digest", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
+EXPORTS = ["mdbg_abi_version", "mdbg_build_flags", "mdbg_create", "mdbg_destroy", "mdbg_finalize_device", "mdbg_finalize_gfa", "mdbg_nodes_digest", "mdbg_set_timing", "mdbg_ingest_batch", "mdbg_ingest_batch_device", "mdbg_sketch_only",
            "mdbg_finalize", "mdbg_reset", "mdbg_get_stats", "mdbg_strerror", "mdbg_last_error", "mdbg_sketch_device",
            "mdbg_insert_resident", "mdbg_route_pack", "mdbg_insert_records", "mdbg_sync", "mdbg_synth_reads_device", "mdbg_copy_to_host", "mdbg_copy_to_device",
            "mdbg_routed_export", "mdbg_resolve_first", "mdbg_resolve_meta", "mdbg_routed_keys", "mdbg_arena_reserve",
@@ -134,6 +134,7 @@ def load_library():
     L.mdbg_finalize.argtypes = [vp, C.POINTER(Nodes)]
     L.mdbg_finalize_device.argtypes = [vp, C.POINTER(Nodes)]
     L.mdbg_finalize_gfa.argtypes = [vp, C.POINTER(Nodes)]
+    L.mdbg_set_timing.argtypes = [vp, u32]
     L.mdbg_nodes_digest.argtypes = [vp, C.POINTER(Nodes), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mdbg_reset.argtypes = [vp, u32]
     L.mdbg_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -311,6 +312,10 @@ class Mdbg:
         nd = Nodes()
         self._chk(self.L.mdbg_finalize_device(self.h, C.byref(nd)))
         return nd
+
+    def set_timing(self, level):
+        """0: no HIP events, 1: around the tile kernel only, 2 (default): also around the stages (include/mdbg_hip.h, mdbg_set_timing)"""
+        self._chk(self.L.mdbg_set_timing(self.h, level))
 
     def nodes_digest(self, nd):
         """(sum, xor) over the rows of a DEVICE node table (finalize_device / DistMdbg.finalize): the order-free digest of {(key, abundance)}, include/mdbg_hip.h"""

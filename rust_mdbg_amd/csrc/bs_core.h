@@ -39,7 +39,14 @@ typedef uint64_t bs_u64;
 #define BS_SEED_G 0x20323ed082572324ull
 #define BS_SEED_T 0x295549f54be24456ull
 
-constexpr int BS_B = 8;              // hash bits evaluated by the bit-sliced filter (top bits 63 .. 64-BS_B)
+// hash bits evaluated by the bit-sliced filter (top bits 63 .. 64-BS_B).  A tunable, not a switch: the filter is a NECESSARY condition (prefix(hash) <= prefix(bound)) and
+// every survivor is evaluated exactly, so any width gives the same minimizers; fewer planes = fewer filter instructions and more exact evaluations.  8 is the measured
+// optimum at the densities of BASELINE.json (profiles/r06_bs_b_sweep.txt: 6 .. 10 at d = 0.002 and 0.003); -DMDBG_BS_B=n builds another width.
+#ifndef MDBG_BS_B
+#define MDBG_BS_B 8
+#endif
+constexpr int BS_B = MDBG_BS_B;
+static_assert(BS_B >= 3 && BS_B <= 12, "filter width");
 constexpr int BS_MAX_L = 32;
 
 BS_HD constexpr bs_u64 bs_seed_f(int code) { return code == 0 ? BS_SEED_A : code == 1 ? BS_SEED_C : code == 2 ? BS_SEED_T : BS_SEED_G; }
@@ -298,11 +305,15 @@ BS_HD bs_u32 bs_strand_compare(const bs_u32 W[BS_B], const bs_u32 Wp[BS_B], bs_u
         xr[i] = d == 0 ? W[i] : bs_alignbit(Wp[i], W[i], (bs_u32)d);        // complements (inv) are folded into the logic below
     }
     if (ZERO) {
-        static_assert(BS_B == 8, "the OR tree below is written for eight planes");
+        // OR tree over the BS_B planes, three inputs per v_bitop3 (the first triple, then the running value with two more planes, a last single plane when one is left)
         bs_u32 any = bs_or3i(xr[0], xr[1], xr[2], inv);
-        any = bs_or3i(any, xr[3], xr[4], (inv >> 2) & 6u);
-        any = bs_or3i(any, xr[5], xr[6], (inv >> 4) & 6u);
-        return ~(any | (((inv >> 7) & 1u) ? ~xr[7] : xr[7]));
+        int i = 3;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (; i + 1 < BS_B; i += 2) any = bs_or3i(any, xr[i], xr[i + 1], (inv >> (i - 1)) & 6u);
+        if (i < BS_B) any |= ((inv >> i) & 1u) ? ~xr[i] : xr[i];
+        return ~any;
     }
 #if defined(__HIPCC__)
 #pragma unroll

@@ -130,16 +130,25 @@ inline u32 crc32(u32 crc, const u8* p, size_t n) {
 }
 
 // ---- raw deflate --------------------------------------------------------------------------------------------------------------
-// table entry: bits 0-3 code bits to drop, 4-6 kind, 8-23 value, 24-28 extra bits (SUB: index bits of the subtable).
-// Literal entries have bit 7 set, their count (1..3) in bits 4-5 and the bytes in bits 8-31: where the codes are short (DNA: 2-4 bits per
-// symbol) one lookup in the primary table delivers up to three literals (pack_literals), which shortens the chain load -> shift -> load that
-// bounds a Huffman decoder.
+// table entry (round 6 layout).  Bits 0-5: ALL the bits the entry consumes — the code AND the extra bits of a length or distance (a subtable pointer: the primary index
+// bits) — so that the bit buffer moves on with ONE shift whose amount is the entry's low bits as they are (x86 shifts take the count modulo 64: no mask).  The decoder is bound by
+// the chain load -> shift -> load (DNA text deflates to a stream of SHORT MATCHES — any 4- to 8-mer recurs within 32 KiB —: 7.8 M matches of 4.6 bytes in 36 MB of FASTQ at
+// level 1, one litlen and one distance lookup each); with the extra bits taken from a copy of the buffer beside the chain a match costs two shifts instead of four.
+// Bits 6-7: number of literals of a literal entry (1..3; 0: not a literal entry), their bytes in bits 8-31: where the codes are short one lookup in the primary table delivers
+// up to three literals (pack_literals).  Other entries: bits 8-10 kind, 11-14 code bits (BASE: the extra bits start behind them; SUB: index bits of the subtable), 15-31 value
+// (base length / base distance / first entry of the subtable).
 enum { K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4 };
-constexpr u32 LITF = 0x80;
-constexpr u32 entry(u32 kind, u32 nbits, u32 extra, u32 value) { return kind == K_LIT ? (nbits | 1u << 4 | LITF | value << 8) : (nbits | kind << 4 | value << 8 | extra << 24); }
-inline u32 e_kind(u32 e) { return (e & LITF) ? (u32)K_LIT : (e >> 4 & 7); }
-inline u32 e_value(u32 e) { return e >> 8 & 0xFFFF; }
-inline u32 e_extra(u32 e) { return e >> 24 & 31; }
+constexpr u32 LITF = 0xC0;                      // (e & LITF) != 0: a literal entry
+constexpr u32 entry(u32 kind, u32 nbits, u32 extra, u32 value) {
+    return kind == K_LIT ? (nbits | 1u << 6 | value << 8) : kind == K_SUB ? (nbits | kind << 8 | extra << 11 | value << 15) : ((nbits + extra) | kind << 8 | nbits << 11 | value << 15);
+}
+inline u32 e_tot(u32 e) { return e & 63; }
+inline u32 e_nlit(u32 e) { return e >> 6 & 3; }
+inline u32 e_kind(u32 e) { return (e & LITF) ? (u32)K_LIT : (e >> 8 & 7); }
+inline u32 e_cb(u32 e) { return e >> 11 & 15; }                          // BASE: code bits; SUB: index bits of the subtable
+inline u32 e_code_bits(u32 e) { return (e & LITF) || (e >> 8 & 7) != K_BASE ? (e & 63) : (e >> 11 & 15); }      // bits of the CODE (careful loop: extra bits are taken separately)
+inline u32 e_value(u32 e) { return e >> 15; }
+inline u32 e_extra(u32 e) { return (e >> 8 & 7) == K_SUB ? (e >> 11 & 15) : (e & 63) - (e >> 11 & 15); }      // BASE: extra bits; SUB: index bits
 constexpr int LIT_BITS = 11, DIST_BITS = 8;
 constexpr int LIT_TAB = (1 << LIT_BITS) + 288 * 16, DIST_TAB = (1 << DIST_BITS) + 32 * 128;
 
@@ -153,6 +162,9 @@ struct Inflater {
     u32 pend_len = 0, pend_dist = 0;            // a match cut by the end of the output chunk
     u32 pend_lit = 0, pend_nlit = 0;            // literals of a packed entry cut by it
     u32 lit[LIT_TAB], dist[DIST_TAB];
+    // the first lookup of the fast loop: lit[]'s primary entries, and where a length (its code and its extra bits) and the distance code behind it fit the index together
+    // a PAIR entry that decodes both — one load and one shift per match on the decoder's dependent chain instead of two and two (pack_pairs)
+    u64 fast[1 << LIT_BITS];
     const char* err = nullptr;
 
     void start(const u8* p, size_t n, size_t at) { in = p; in_n = n; ip = at; bb = 0; bc = 0; st = HEADER; last = false; stored_left = 0; pend_len = pend_dist = 0; pend_lit = pend_nlit = 0; err = nullptr; }
@@ -278,8 +290,8 @@ struct Inflater {
                 if (!need(7 + 7)) { if (!need(1)) return fail("truncated deflate stream"); }      // (the tail of the stream may hold fewer than 14 bits)
                 const u32 e = cltab[bb & 127];
                 if (e_kind(e) != K_LIT) return fail("invalid code length code");
-                if ((e & 15) > bc) return fail("truncated deflate stream");
-                take(e & 15);
+                if (e_tot(e) > bc) return fail("truncated deflate stream");
+                take(e_tot(e));
                 const u32 sym = e >> 8 & 0xFF;
                 if (sym < 16) { lens[i++] = (u8)sym; continue; }
                 u32 rep, val = 0;
@@ -296,8 +308,30 @@ struct Inflater {
         if (!build(lens, hlit, lit, LIT_BITS, LIT_TAB, lit_kind)) return false;
         if (!build(lens + 288, hdist, dist, DIST_BITS, DIST_TAB, dist_kind)) return false;
         pack_literals();
+        pack_pairs();
         st = HUFF;
         return true;
+    }
+    // PAIR entry: bits 0-5 all bits consumed (length code + distance code + distance extra bits), 8-10 = K_PAIR, 11-19 the length, 20-24 bits in front of the distance's
+    // extra bits, 25-28 their number, 32-47 the base distance.  Like pack_literals: the index bits above the length code read as the distance code only when that code does
+    // not reach beyond the index.
+    enum { K_PAIR = 5 };
+    void pack_pairs() {
+        constexpr u32 PM = (1u << LIT_BITS) - 1, DM = (1u << DIST_BITS) - 1;
+        for (u32 i = 0; i <= PM; ++i) {
+            const u32 e = lit[i];
+            u64 f = e;
+            if (!(e & LITF) && (e >> 8 & 7) == K_BASE && (e & 63) < (u32)LIT_BITS) {             // a length whose code AND extra bits lie inside the index: it is known here
+                const u32 l1 = e & 63, lcb = e_cb(e);
+                const u32 len = e_value(e) + ((i >> lcb) & ((1u << (l1 - lcb)) - 1));
+                const u32 d = dist[(i >> l1) & DM];                                                   // (bits above the index read as zero)
+                if (!(d & LITF) && (d >> 8 & 7) == K_BASE && l1 + e_cb(d) <= (u32)LIT_BITS) {
+                    const u32 dcb = e_cb(d), dx = (d & 63) - dcb;
+                    f = (u64)(l1 + (d & 63)) | (u64)K_PAIR << 8 | (u64)len << 11 | (u64)(l1 + dcb) << 20 | (u64)dx << 25 | (u64)e_value(d) << 32;
+                }
+            }
+            fast[i] = f;
+        }
     }
     // Primary entries of short literal codes take the literals that follow along: index bits above the first code that decide a second (and a
     // third) literal completely become part of the entry.  Works on a copy of the single-symbol entries, so a packed entry never feeds another.
@@ -308,16 +342,16 @@ struct Inflater {
         for (u32 i = 0; i <= PM; ++i) {
             const u32 e1 = one[i];
             if (!(e1 & LITF)) continue;
-            const u32 l1 = e1 & 15;
+            const u32 l1 = e_tot(e1);
             if (l1 + 1 > (u32)LIT_BITS) continue;
             const u32 e2 = one[i >> l1];                                  // the unknown bits above read as zero: valid only if the code found does not reach them
-            const u32 l2 = e2 & 15;
+            const u32 l2 = e_tot(e2);
             if (!(e2 & LITF) || l1 + l2 > (u32)LIT_BITS) continue;
             u32 bytes = (e1 >> 8 & 0xFF) | (e2 >> 8 & 0xFF) << 8, n = 2, bits = l1 + l2;
             const u32 e3 = one[i >> bits];
-            const u32 l3 = e3 & 15;
+            const u32 l3 = e_tot(e3);
             if ((e3 & LITF) && bits + l3 <= (u32)LIT_BITS) { bytes |= (e3 >> 8 & 0xFF) << 16; n = 3; bits += l3; }
-            lit[i] = bits | n << 4 | LITF | bytes << 8;
+            lit[i] = bits | n << 6 | bytes << 8;
         }
     }
 
@@ -352,12 +386,23 @@ struct Inflater {
                 const size_t in_fast = in_n - 32, out_fast = out_end - 320;
                 u64 b = bb; u32 c = bc; size_t i = ip;
 #define GZ_REFILL() do { u64 w_; memcpy(&w_, in + i, 8); b |= w_ << c; i += (63 - c) >> 3; c |= 56; } while (0)
-#define GZ_LOOKUP(e) do { e = lit[b & LM]; if ((e & 0xF0) == (K_SUB << 4)) { b >>= LIT_BITS; c -= LIT_BITS; e = lit[e_value(e) + (b & ((1u << e_extra(e)) - 1))]; } b >>= e & 15; c -= e & 15; } while (0)
-#define GZ_PUT(e) do { const u32 v_ = e >> 8; memcpy(out + op, &v_, 4); op += e >> 4 & 3; } while (0)
+// (b0: the buffer in front of the entry's bits — the extra bits of a length / distance are read from it beside the chain)
+#define GZ_IS_SUB(e) (((e) & (LITF | 7u << 8)) == (u32)K_SUB << 8)
+#define GZ_LOOKUP(e) do { e = lit[b & LM]; if (GZ_IS_SUB(e)) { b >>= LIT_BITS; c -= LIT_BITS; e = lit[e_value(e) + (b & ((1u << e_cb(e)) - 1))]; } b0 = b; b >>= (e & 63); c -= e & 63; } while (0)
+#define GZ_PUT(e) do { const u32 v_ = e >> 8; memcpy(out + op, &v_, 4); op += e >> 6 & 3; } while (0)
                 while (i <= in_fast && op <= out_fast) {
                     GZ_REFILL();
-                    u32 e;
-                    GZ_LOOKUP(e);
+                    u32 e; u64 b0;
+                    u32 len; size_t dd;
+                    const u64 f = fast[b & LM];
+                    if (((u32)f & (LITF | 7u << 8)) == (u32)K_PAIR << 8) {      // a short match in ONE lookup: length and distance code together, the distance's extra bits beside the chain
+                        b0 = b; b >>= (f & 63); c -= (u32)f & 63;
+                        len = (u32)f >> 11 & 511;
+                        dd = (size_t)(f >> 32) + (size_t)((b0 >> ((u32)f >> 20 & 31)) & ((1ull << ((u32)f >> 25 & 15)) - 1));
+                    } else {
+                    e = (u32)f;
+                    if (GZ_IS_SUB(e)) { b >>= LIT_BITS; c -= LIT_BITS; e = lit[e_value(e) + (b & ((1u << e_cb(e)) - 1))]; }
+                    b0 = b; b >>= (e & 63); c -= e & 63;
                     if (e & LITF) {                                    // up to three lookups per refill (3 x 15 bits), each up to three literals
                         GZ_PUT(e);
                         GZ_LOOKUP(e);
@@ -368,18 +413,17 @@ struct Inflater {
                         }
                         GZ_REFILL();                                   // (idempotent: the bits above c are the stream's own)
                     }
-                    const u32 kind = e >> 4 & 7;
+                    const u32 kind = e >> 8 & 7;
                     if (kind != K_BASE) { if (kind == K_EOB) { eob = true; break; } bb = b; bc = c; ip = i; return fail("invalid literal / length code"); }
-                    const u32 xb = e_extra(e);
-                    const u32 len = e_value(e) + (u32)(b & ((1u << xb) - 1));
-                    b >>= xb; c -= xb;                                 // (>= 36 bits are left on either way here: a distance takes at most 15 + 13)
-                    u32 d = dist[b & DM];
-                    if ((d & 0xF0) == (K_SUB << 4)) { b >>= DIST_BITS; c -= DIST_BITS; d = dist[e_value(d) + (b & ((1u << e_extra(d)) - 1))]; }
-                    b >>= d & 15; c -= d & 15;
-                    if ((d >> 4 & 15) != K_BASE) { bb = b; bc = c; ip = i; return fail("invalid distance code"); }
-                    const u32 db = e_extra(d);
-                    const size_t dd = e_value(d) + (size_t)(b & ((1u << db) - 1));
-                    b >>= db; c -= db;
+                    const u32 lcb = e_cb(e);                           // the length: base + the (tot - code) bits behind the code, read from the buffer as it was
+                    len = e_value(e) + (u32)((b0 >> lcb) & ((1u << ((e & 63) - lcb)) - 1));
+                    u32 d = dist[b & DM];                              // (>= 36 bits are left on either way here: a distance takes at most 15 + 13)
+                    if (GZ_IS_SUB(d)) { b >>= DIST_BITS; c -= DIST_BITS; d = dist[e_value(d) + (b & ((1u << e_cb(d)) - 1))]; }
+                    b0 = b; b >>= (d & 63); c -= d & 63;
+                    if ((d & LITF) || (d >> 8 & 7) != K_BASE) { bb = b; bc = c; ip = i; return fail("invalid distance code"); }
+                    const u32 dcb = e_cb(d);
+                    dd = e_value(d) + (size_t)((b0 >> dcb) & ((1ull << ((d & 63) - dcb)) - 1));
+                    }
                     if (dd > op - lo) { bb = b; bc = c; ip = i; return fail("distance reaches in front of the data"); }
                     u8* dst = out + op; const u8* src = dst - dd;
                     op += len;
@@ -394,6 +438,7 @@ struct Inflater {
                 }
 #undef GZ_REFILL
 #undef GZ_LOOKUP
+#undef GZ_IS_SUB
 #undef GZ_PUT
                 bb = b; bc = c; ip = i;
             }
@@ -404,14 +449,14 @@ struct Inflater {
                     need(32);                                          // as many as there are
                     u32 e = lit[bb & LM];
                     u32 used = 0;
-                    if ((e & 0xF0) == (K_SUB << 4)) { used = LIT_BITS; e = lit[e_value(e) + ((bb >> LIT_BITS) & ((1u << e_extra(e)) - 1))]; }
-                    used += e & 15;
+                    if (e_kind(e) == K_SUB) { used = LIT_BITS; e = lit[e_value(e) + ((bb >> LIT_BITS) & ((1u << e_cb(e)) - 1))]; }
+                    used += e_code_bits(e);
                     const u32 kind = e_kind(e);
                     if (kind == K_BAD || kind == K_SUB) return fail(used > bc ? "truncated deflate stream" : "invalid literal / length code");
                     if (used > bc) return fail("truncated deflate stream");
                     take(used);
                     if (kind == K_LIT) {
-                        u32 n = e >> 4 & 3, v = e >> 8;
+                        u32 n = e_nlit(e), v = e >> 8;
                         while (n && op < out_end) { out[op++] = (u8)v; v >>= 8; --n; }
                         if (n) { pend_nlit = n; pend_lit = v; op_io = op; return true; }      // chunk full: the rest comes first thing in the next call
                         continue;
@@ -423,9 +468,9 @@ struct Inflater {
                     need(32);
                     u32 d = dist[bb & DM];
                     used = 0;
-                    if ((d & 0xF0) == (K_SUB << 4)) { used = DIST_BITS; d = dist[e_value(d) + ((bb >> DIST_BITS) & ((1u << e_extra(d)) - 1))]; }
-                    used += d & 15;
-                    if ((d >> 4 & 15) != K_BASE) return fail(used > bc ? "truncated deflate stream" : "invalid distance code");
+                    if (e_kind(d) == K_SUB) { used = DIST_BITS; d = dist[e_value(d) + ((bb >> DIST_BITS) & ((1u << e_cb(d)) - 1))]; }
+                    used += e_code_bits(d);
+                    if (e_kind(d) != K_BASE) return fail(used > bc ? "truncated deflate stream" : "invalid distance code");
                     if (used > bc) return fail("truncated deflate stream");
                     take(used);
                     const u32 db = e_extra(d);

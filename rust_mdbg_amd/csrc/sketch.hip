@@ -22,6 +22,7 @@
 #include "bs_core.h"
 
 enum { FMT_ASCII = 0, FMT_PLANES = 1 };
+constexpr int SCAN_GRAN_LOG = 6, SCAN_GRAN = 1 << SCAN_GRAN_LOG;      // tiles per address of SketchArgs::block_sum
 struct TileRec;
 
 struct SketchArgs {
@@ -41,6 +42,10 @@ struct SketchArgs {
     u32* last_read;              // [n_tiles] read of the tile's last minimizer (LAST_NONE: the tile has none; LAST_IN_SLAB: look at the slab), so that
                                  // the gather need not chase the slab in front of it (one more dependent round trip per tile)
     u32* over_max;               // <- largest n_valid that did not fit its slab (0: none; the host then retries with larger slabs)
+    unsigned long long* block_sum;   // non-null: [launch-local tile / SCAN_GRAN] += n_valid — the first level of the gather's scan, accumulated by the tiles themselves (zeroed by
+                                 // tile_rec_kernel): one kernel less behind every tile launch.  SCAN_GRAN = 64 tiles per address, not the scan's 1,024: the ~1,500 tiles that
+                                 // are resident together finish at 137 M tiles/s, and ONE address takes 83 M atomics/s (MI355X_MICROARCH.md, "fanin") — with 1,024 tiles per
+                                 // address the tile kernel ran 10 % slower (profiles/r06_notes.md)
     const u64* t4;               // (2 << 2*BS_GS) x u64: {F, R} per 3-base group (bs_make_table)
     const u8* tile_flags;        // FMT_PLANES: nonzero = an exception falls into the tile's staged range (null: none)
     const u64* exc_pos; const u8* exc_val; u32 n_exc;
@@ -71,11 +76,12 @@ static_assert(sizeof(TileRec) == 48, "three 16-byte words");
 // bread[] and the records in ONE launch: thread t runs the searches for entries t and t + 2 side by side (two dependent chains of ~20
 // loads each in flight together; two kernels in a row were 10 + 6 us and a launch)
 // init: scalars the sketch starts from (three zeroed, one set), folded in here: one launch less in front of the tile kernel
-struct SketchInit { u64* zero[4]; u64* set_p; u64 set_v; };
+struct SketchInit { u64* zero[4]; u64* set_p; u64 set_v; u64* zero_arr; u32 zero_arr_n; };      // zero_arr: the block sums the tiles of the first launch add their counts to (SketchArgs::block_sum)
 __global__ void tile_rec_kernel(const u64* __restrict__ off, u32 n_reads, u64 n_bases, u32 n_tiles, u32* __restrict__ bread, TileRec* __restrict__ recs, SketchInit init,
                                 int64_t stride, int64_t halo) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) { for (int i = 0; i < 4; ++i) if (init.zero[i]) *init.zero[i] = 0; if (init.set_p) *init.set_p = init.set_v; }
+    if (t < init.zero_arr_n) init.zero_arr[t] = 0;
     if (t >= n_tiles + 2) return;
     auto first_pos = [&](u32 e) -> u64 {
         int64_t p = (int64_t)e * stride - halo;
@@ -273,6 +279,7 @@ __device__ inline void put_rec(const SketchArgs& a, Rec* slab, u32 rank, u64 has
 constexpr u32 LAST_NONE = 0xFFFFFFFFu, LAST_IN_SLAB = 0xFFFFFFFEu;
 __device__ inline void put_count(const SketchArgs& a, u32 gt, u32 n, bool last_known = false) {
     a.n_valid[gt] = n;
+    if (a.block_sum && n) atomicAdd(a.block_sum + ((gt - a.tile0) >> SCAN_GRAN_LOG), (unsigned long long)n);
     if (a.last_read && !(last_known && n)) a.last_read[gt] = n ? LAST_IN_SLAB : LAST_NONE;
     if (a.n_scan) a.n_scan[gt] = 0;
     if (n > a.slab_cap) atomicMax(a.over_max, n);
@@ -1031,6 +1038,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         tile_excl_scan<NW>(surv, S.misc, nv);
         if (tid == 0) {
             a.n_valid[gt] = nv; if (a.n_scan) a.n_scan[gt] = C;
+            if (a.block_sum && nv) atomicAdd(a.block_sum + ((gt - a.tile0) >> SCAN_GRAN_LOG), (unsigned long long)nv);
             if (a.last_read) a.last_read[gt] = nv ? LAST_IN_SLAB : LAST_NONE;
             if (C > a.slab_cap) atomicMax(a.over_max, C);
             if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; }
@@ -1077,6 +1085,7 @@ __global__ __launch_bounds__(256) void tile_scan_top_kernel(u32 n_blocks, u64* _
 }
 // self_base: block_base holds the plain block sums (at most 1024 blocks of 1024 tiles, no tile_scan_top launch): the workgroup adds up the
 // sums in front of its block itself (the gather's last wave then moves the running total on)
+// self_base == 2: block_base holds the sums of SCAN_GRAN-tile granules (the tiles added their counts up themselves, SketchArgs::block_sum): 1024 / SCAN_GRAN of them per workgroup
 __global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* __restrict__ n_valid, const u64* __restrict__ block_base, u64* __restrict__ tile_base,
                                                               u32 self_base, const u64* __restrict__ carry) {
     __shared__ u32 tmp[8];
@@ -1088,8 +1097,11 @@ __global__ __launch_bounds__(256) void tile_scan_final_kernel(u32 n, const u32* 
     u64 bb;
     if (self_base) {
         u64 x = 0;
+        if (self_base == 2) { const u32 ng = blockIdx.x * (1024 / SCAN_GRAN); for (u32 g = threadIdx.x; g < ng; g += 256) x += block_base[g]; }
+        else {
 #pragma unroll
-        for (u32 q = 0; q < 4; ++q) if (4 * threadIdx.x + q < blockIdx.x) x += block_base[4 * threadIdx.x + q];
+            for (u32 q = 0; q < 4; ++q) if (4 * threadIdx.x + q < blockIdx.x) x += block_base[4 * threadIdx.x + q];
+        }
         for (int d = 32; d; d >>= 1) x += __shfl_down(x, d, 64);
         if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = x;
         __syncthreads();
@@ -1415,13 +1427,17 @@ void launch_excl_scan_u32(const u32* v, u32 n, u64* scan_tmp, u64* out, u64* car
     hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
     hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, v, scan_tmp, out, 0u, carry);
 }
-void launch_gather(const GatherArgs& g, u64* scan_tmp, u64* tile_base, u64* carry, hipStream_t s) {
+// gran_sum (non-null): the sums of the launch's SCAN_GRAN-tile granules (the tiles added their counts up themselves, SketchArgs::block_sum): the scan is ONE launch then
+void launch_gather(const GatherArgs& g, u64* scan_tmp, u64* tile_base, u64* carry, hipStream_t s, const u64* gran_sum = nullptr) {
     if (!g.n) return;
     const u32 n = g.n, nb = (n + 1023) / 1024;
-    hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp);
-    const u32 self_base = nb <= 1024 ? 1u : 0u;     // up to 1,048,576 tiles (8.5 Gbases of wave tiles) per launch: two scan launches instead of three
-    if (!self_base) hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
-    hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp, tile_base, self_base, carry);
+    const u32 self_base = nb <= 1024 ? 1u : 0u;     // up to 1,048,576 tiles (34 Gbases) per launch: no scan of the block sums by a kernel of its own
+    if (gran_sum && self_base) hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, gran_sum, tile_base, 2u, carry);
+    else {
+        hipLaunchKernelGGL(tile_scan_sums_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp);
+        if (!self_base) hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
+        hipLaunchKernelGGL(tile_scan_final_kernel, dim3(nb), dim3(256), 0, s, n, g.n_valid + g.tile0, scan_tmp, tile_base, self_base, carry);
+    }
     GatherArgs a = g; a.tile_base = tile_base; a.carry = self_base ? carry : nullptr;
     if (a.tiles_per_wave > 1) { const u32 nw = (n + a.tiles_per_wave - 1) / a.tiles_per_wave; hipLaunchKernelGGL(gather_multi_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, a); }
     else hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, a);

@@ -244,6 +244,41 @@ void launch_owner_thresholds(double bound, u32 k, u32 world, u64* thr, hipStream
     if (world > 1) hipLaunchKernelGGL(owner_thresholds_kernel, dim3(1), dim3(64), 0, s, bound, k, world, thr);
 }
 
+// ---- owner codes --------------------------------------------------------------------------------------------------------------------------------------------
+// A window's owner is a function of the SMALLEST of its k hashes, and both owner functions with parameters (OwnerSpec::thr) are monotone in that value up to a final table
+// lookup: bin(v) = min(mulhi64(v, mul), OWNER_BINS - 1) for the measured table, rank(v) = number of thresholds <= v without one.  So
+// min over the window of code(v) = code(min over the window of v), and the sliding minimum runs on 16-bit CODES: the values are turned into codes once, the doubling rounds
+// (min over 2, 4, ... p <= k codes; a window of k is two overlapping stretches of p) move 2 bytes per element instead of 8 — round 3 ran them on the u64 hashes in 33 KB
+// of LDS per workgroup, and a kernel that also needs the hashes themselves (the insertion) could not afford them at all.  (No parameters — the value is hashed to a rank —
+// is not monotone: callers fall back to window_owner.)
+struct OwnerCodes { u64 mul; const u64* thr; u32 world; };      // mul != 0: bins of the measured table; else threshold ranks
+__device__ inline OwnerCodes owner_codes_of(OwnerSpec os) { OwnerCodes c; c.thr = os.thr; c.world = os.world; c.mul = os.thr ? os.thr[0] : 0; return c; }
+__device__ inline u16 owner_code(u64 v, const OwnerCodes& c) {
+    if (c.mul) { const u64 bin = __umul64hi(v, c.mul); return (u16)(bin < OWNER_BINS ? bin : OWNER_BINS - 1); }
+    const u64* const thr = c.thr + OWNER_THR_AT;
+    u32 lo = 0, hi = c.world - 1;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (thr[mid] <= v) lo = mid + 1; else hi = mid; }
+    return (u16)lo;
+}
+__device__ inline u32 owner_of_code(u16 code, const OwnerCodes& c) {
+    if (!c.mul) return code;
+    const u32 o = ((const u8*)(c.thr + OWNER_TAB_AT))[code];
+    return o < c.world ? o : c.world - 1;
+}
+// a, b: two LDS arrays of nv u16; value(t): the hash at span position t, valid(t): it exists.  Returns M with M[t] = smallest code among the p values from t on (p = the
+// largest power of two <= k): the code of the window starting at span position li is min(M[li], M[li + k - p]).  All 256 threads call it.
+template <class ValueFn, class ValidFn>
+__device__ inline const u16* span_min_codes(ValueFn value, ValidFn valid, u32 nv, u32 k, const OwnerCodes& c, u16* a, u16* b, u32& p) {
+    for (u32 t = threadIdx.x; t < nv; t += 256) a[t] = valid(t) ? owner_code(value(t), c) : (u16)0xFFFFu;
+    __syncthreads();
+    for (p = 1; 2 * p <= k; p *= 2) {
+        for (u32 t = threadIdx.x; t < nv; t += 256) { const u16 x = a[t], y = t + p < nv ? a[t + p] : (u16)0xFFFFu; b[t] = x < y ? x : y; }
+        __syncthreads();
+        u16* const sw = a; a = b; b = sw;
+    }
+    return a;
+}
+
 // find-or-claim for a whole wave: every lane calls it together, act = the lane has a window (its k values at w, window start = store index i, position li in a
 // list that is in window order where consecutive entries are consecutive windows of a read).  claimed: the lane created the key; found: it met its key in slot s.
 // The walk of upsert_slot is cut in two.  (1) Every lane walks to the first slot that is empty (claims it) or carries its fingerprint.  (2) The fingerprint
@@ -319,7 +354,7 @@ constexpr int OWN_SPAN = OWN_SPAN_V;
 __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const u64* __restrict__ mh, const u32* __restrict__ mread,
                                                                    const u64* __restrict__ roff, u64 i0, u64 i1, u32 slot0, u64 first_ordinal,
                                                                    u32* __restrict__ cap_err, const u64* __restrict__ i1_dev, u64 n_lim) {
-    extern __shared__ u64 sh_keys[];           // [OWN_SPAN + k] keys, then u16 list[OWN_SPAN], then the counter, then u8 cl[OWN_SPAN]
+    extern __shared__ u64 sh_keys[];           // [OWN_SPAN + k] keys, then u16 list[OWN_SPAN], then the counter, then u8 cl[OWN_SPAN], then (partitioned table) 2 x u16 codes[OWN_SPAN + k]
     if (cap_err[1]) return;
     // i1_dev: launched behind the sketch of the same batch before the host knew how many minimizers it has (i1 = an upper bound the grid was
     // sized for): the count comes from the device, workgroups behind it have nothing to do
@@ -334,12 +369,26 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     if (threadIdx.x == 0) *n_own = 0;
     if (T.claim) for (int u = threadIdx.x; u < OWN_SPAN / 8; u += 256) ((u64*)cl)[u] = 0;
     __syncthreads();
+    // partitioned table: whose window is it?  From the codes of the staged hashes (see "owner codes"), or — no owner parameters — from the k values themselves
+    const bool by_codes = T.own_world > 1 && T.own_thr != nullptr;
+    const u16* mc = nullptr; u32 pc = 1; OwnerCodes oc{};
+    if (by_codes) {
+        u16* const ca = (u16*)(cl + OWN_SPAN);
+        oc = owner_codes_of(OwnerSpec{T.own_world, T.own_thr});
+        const u32 n_st = (u32)(lim - b0);
+        mc = span_min_codes([&](u32 t) { return sh_keys[t]; }, [&](u32 t) { return t < n_st; }, OWN_SPAN + k - 1, k, oc, ca, ca + (OWN_SPAN + k), pc);
+    }
 #pragma unroll
     for (int u = 0; u < OWN_SPAN / 256; ++u) {
         const u32 li = u * 256 + threadIdx.x;
         const u64 i = b0 + li;
         bool mine = false;
-        if (i + k <= i1 && (T.own_world <= 1 || window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank)) {       // ownership first: it needs no further loads
+        bool own = i + k <= i1;
+        if (own && T.own_world > 1) {
+            if (by_codes) { const u16 x = mc[li], y = mc[li + k - pc]; own = owner_of_code(x < y ? x : y, oc) == T.own_rank; }
+            else own = window_owner(sh_keys + li, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank;
+        }
+        if (own) {                                                        // ownership first: it needs no further loads
             const u32 slot = mread[i];
             const u64 rs = roff[slot], re = roff[slot + 1];
             mine = re - rs > k && i + k <= re;
@@ -352,7 +401,7 @@ __global__ __launch_bounds__(256) void insert_windows_kernel(TableArgs T, const 
     }
     __syncthreads();
     const u32 n = *n_own;
-    if (threadIdx.x == 0 && n) atomicAdd((unsigned long long*)ctr_shard(T.own_inserted), (unsigned long long)n);
+    if (threadIdx.x == 0 && n && T.own_world > 1) atomicAdd((unsigned long long*)ctr_shard(T.own_inserted), (unsigned long long)n);      // (checked against the senders' counts: partitioned tables only)
     for (u32 j0 = 0; j0 < n; j0 += 256) {          // (the same trip count for every lane: upsert_wave is a wave-wide call)
         const u32 j = j0 + threadIdx.x;
         bool act = j < n;
@@ -399,28 +448,15 @@ __device__ inline bool window_starts_at(const u32* __restrict__ mread, const u64
 // of all the span's windows comes from LDS: the span's hashes are staged once and reduced by doubling (min over 2, 4, ... p <= k values; a
 // window of k is two overlapping stretches of p) — read from HBM window by window it was 35 loads each, 1.4 ms per 6.6 M windows.
 constexpr u32 OWNL_LDS_MAX_K = 1024;          // longer k: the plain loop (2 x (OWNL_SPAN + k) values have to fit the default 64 KB of dynamic LDS)
-// sh: two buffers of OWNL_SPAN + k - 1 values.  Returns M with M[t] = min of the p values from t on (p = largest power of two <= k), so that the
-// smallest hash of the window starting at span position li is min(M[li], M[li + k - p]).  All 256 threads call it.
-__device__ inline const u64* span_minima(const u64* __restrict__ mh, u64 b0, u64 i1, u32 k, u64* sh, u32& p) {
-    const u32 nv = OWNL_SPAN + k - 1;
-    u64* a = sh; u64* b = sh + nv;
-    for (u32 t = threadIdx.x; t < nv; t += 256) a[t] = b0 + t < i1 ? mh[b0 + t] : ~0ull;
-    __syncthreads();
-    for (p = 1; 2 * p <= k; p *= 2) {
-        for (u32 t = threadIdx.x; t < nv; t += 256) { const u64 x = a[t], y = t + p < nv ? a[t + p] : ~0ull; b[t] = x < y ? x : y; }
-        __syncthreads();
-        u64* const sw = a; a = b; b = sw;
-    }
-    return a;
-}
 // window minima of a batch counted per bin of the value range (hist[OWNER_BINS], added to): what the measured owner table is made from
 __global__ __launch_bounds__(256) void owner_bins_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1, u32 k, u64 mul,
                                                          unsigned long long* __restrict__ hist) {
-    extern __shared__ u64 sh_min[];
+    extern __shared__ u64 sh_min[];                   // k <= OWNL_LDS_MAX_K: two arrays of OWNL_SPAN + k - 1 codes (u16)
     const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
     const bool staged = k <= OWNL_LDS_MAX_K;
-    const u64* cur = sh_min; u32 p = 1;
-    if (staged) cur = span_minima(mh, b0, i1, k, sh_min, p);
+    OwnerCodes oc{}; oc.mul = mul;                    // (bins: the codes are the bins themselves)
+    const u16* cur = nullptr; u32 p = 1;
+    if (staged) { u16* const ca = (u16*)sh_min; cur = span_min_codes([&](u32 t) { return mh[b0 + t]; }, [&](u32 t) { return b0 + t < i1; }, OWNL_SPAN + k - 1, k, oc, ca, ca + (OWNL_SPAN + k), p); }
     const int lane = threadIdx.x & 63;
 #pragma unroll 1
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
@@ -428,11 +464,8 @@ __global__ __launch_bounds__(256) void owner_bins_kernel(const u64* __restrict__
         const u64 i = b0 + li;
         u32 bin = 0xFFFFFFFFu;
         if (window_starts_at(mread, roff, i, i1, k)) {
-            u64 m;
-            if (staged) { const u64 x = cur[li], y = cur[li + k - p]; m = x < y ? x : y; }
-            else { m = mh[i]; for (u32 j = 1; j < k; ++j) { const u64 x = mh[i + j]; m = x < m ? x : m; } }
-            const u64 q = __umul64hi(m, mul);
-            bin = q < OWNER_BINS ? (u32)q : OWNER_BINS - 1;
+            if (staged) { const u16 x = cur[li], y = cur[li + k - p]; bin = x < y ? x : y; }
+            else { u64 m = mh[i]; for (u32 j = 1; j < k; ++j) { const u64 x = mh[i + j]; m = x < m ? x : m; } bin = owner_code(m, oc); }
         }
         // one atomic per distinct bin of the wave (the heavy bins are hit by several lanes of every wave)
         for (u64 todo = __ballot(bin != 0xFFFFFFFFu); todo;) {
@@ -444,26 +477,31 @@ __global__ __launch_bounds__(256) void owner_bins_kernel(const u64* __restrict__
     }
 }
 void launch_owner_bins(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u64 mul, u64* hist, hipStream_t s) {
-    const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k - 1) * sizeof(u64) : 0;
+    const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k) * sizeof(u16) : 0;
     if (i1 > i0) hipLaunchKernelGGL(owner_bins_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), lds, s, mh, mread, roff, i0, i1, k, mul, (unsigned long long*)hist);
 }
 __global__ __launch_bounds__(256) void owner_list_count_kernel(const u64* __restrict__ mh, const u32* __restrict__ mread, const u64* __restrict__ roff, u64 i0, u64 i1,
                                                                u32 k, u32 world, const u64* thr, u32* __restrict__ blk_cnt, u8* __restrict__ owner_of) {
-    extern __shared__ u64 sh_min[];               // two buffers of OWNL_SPAN + k - 1 values (k <= OWNL_LDS_MAX_K)
+    extern __shared__ u64 sh_min[];               // owner parameters and k <= OWNL_LDS_MAX_K: two arrays of OWNL_SPAN + k - 1 owner codes (u16), see "owner codes"
     __shared__ u32 hist[OWNL_MAX_WORLD];
     if (threadIdx.x < world) hist[threadIdx.x] = 0;
     const u64 b0 = i0 + (u64)blockIdx.x * OWNL_SPAN;
-    const bool staged = k <= OWNL_LDS_MAX_K;
-    const u64* cur = sh_min; u32 p = 1;
-    if (staged) cur = span_minima(mh, b0, i1, k, sh_min, p); else __syncthreads();
     const OwnerSpec os{world, thr};
+    const bool staged = k <= OWNL_LDS_MAX_K && thr != nullptr && world > 1;
+    OwnerCodes oc{}; const u16* cur = nullptr; u32 p = 1;
+    if (staged) {
+        // the hashes are turned into codes as they are read: nothing but 2 x 2 bytes per element is staged (round 3 - 5: the u64 values, 33 KB of LDS per workgroup)
+        oc = owner_codes_of(os);
+        u16* const ca = (u16*)sh_min;
+        cur = span_min_codes([&](u32 t) { return mh[b0 + t]; }, [&](u32 t) { return b0 + t < i1; }, OWNL_SPAN + k - 1, k, oc, ca, ca + (OWNL_SPAN + k), p);
+    } else __syncthreads();
 #pragma unroll
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
         const u32 li = u * 256 + threadIdx.x;
         const u64 i = b0 + li;
         u32 o = 0xFFu;
         if (window_starts_at(mread, roff, i, i1, k)) {
-            if (staged) { const u64 x = cur[li], y = cur[li + k - p]; o = owner_of_min(x < y ? x : y, k, os); }
+            if (staged) { const u16 x = cur[li], y = cur[li + k - p]; o = owner_of_code(x < y ? x : y, oc); }
             else o = window_owner(mh + i, k, os);
             atomicAdd(&hist[o], 1u);
         }
@@ -478,7 +516,9 @@ __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __rest
                                                                u32 k, u32 world, const u64* thr, u32 slot0, const u64* __restrict__ blk_off, OwnerBases bases, u32* __restrict__ list,
                                                                const u8* __restrict__ owner_of, u32 direct_owner, u32* __restrict__ direct_dst) {
     // direct_owner (< world): that owner's bucket is not part of `list` (its bases entry is unused): it goes to direct_dst, the place the rank keeps its own
-    // share of its own batch (api.inc, owner_lists_impl) — until round 5 the bucket was written to the list and copied there (368 MB per 19.5-Gbase batch at one rank)
+    // share of its own batch (api.inc, owner_lists_impl) — until round 5 the bucket was written to the list and copied there (368 MB per 19.5-Gbase batch at one rank) —,
+    // or, direct_dst == null, NOWHERE: since round 6 the multi-GPU layer inserts a rank's own windows of its own batch with insert_windows_kernel, which finds them itself
+    // (owner codes of the hashes it stages anyway), so that bucket is neither written nor read nor cut into spans
     constexpr int NG = OWNL_SPAN / 64;
     __shared__ u32 grp[NG][OWNL_MAX_WORLD];
     for (int t = threadIdx.x; t < NG * (int)OWNL_MAX_WORLD; t += 256) ((u32*)grp)[t] = 0;
@@ -507,7 +547,7 @@ __global__ __launch_bounds__(256) void owner_list_write_kernel(const u64* __rest
 #pragma unroll
     for (int u = 0; u < OWNL_SPAN / 256; ++u) {
         const u32 o = own[u];
-        if (o == NONE) continue;
+        if (o == NONE || (o == direct_owner && !direct_dst)) continue;
         const u64 i = b0 + u * 256 + threadIdx.x;
         const u64 at = blk_off[(size_t)blockIdx.x * world + o] + grp[u * 4 + wv][o] + rank[u];
         uint2* const e = o == direct_owner ? (uint2*)direct_dst + at : (uint2*)list + (bases.b[o] + at);
@@ -595,7 +635,7 @@ __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T,
     const u64 h = key_hash_window(w, k, rev);
     bool claimed;
     const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
-    if (claimed) mread[i] = slot;
+    if (claimed) { mread[i] = slot; if (T.claim) T.claim[i] = 1; }      // (the batch's bytes of the claim map were zeroed in front of the launch: api.inc, insert_resident_impl)
     if (claimed || s == ~0ull) return;
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
@@ -617,14 +657,20 @@ __global__ __launch_bounds__(256) void list_segments_kernel(const u32* __restric
 __global__ __launch_bounds__(256) void insert_listed_span_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
                                                                  u64 m0, u64 m1, const u32* __restrict__ list, const u32* __restrict__ seg, u64 n, u32 slot0,
                                                                  u32 n_reads, u64 first_ordinal, u32* __restrict__ cap_err) {
-    extern __shared__ u64 sh_keys[];           // [OWNL_SPAN + k - 1]
+    extern __shared__ u64 sh_keys[];           // [OWNL_SPAN + k - 1] (+ one more, then u8 cl[OWNL_SPAN]: the span's claim bytes, T.claim)
     if (cap_err[1]) return;
     const u32 q = blockIdx.x, k = T.ks.k;
     const u32 s0 = seg[q], s1 = seg[q + 1];
-    if (s0 >= s1 || s1 > n) return;
     const u64 b0 = m0 + (u64)q * OWNL_SPAN;
+    u8* const cl = (u8*)(sh_keys + OWNL_SPAN + k);
+    const u64 span_n = m1 - b0 < (u64)OWNL_SPAN ? m1 - b0 : (u64)OWNL_SPAN;      // window starts of this span that exist
+    if (s0 >= s1 || s1 > n) {                      // nothing listed here: no window of this span created a key (every byte of a batch's claim map is written by somebody)
+        if (T.claim) for (u32 li = threadIdx.x; li < span_n; li += 256) T.claim[b0 + li] = 0;
+        return;
+    }
     const u64 lim = b0 + OWNL_SPAN + k - 1 < m1 ? b0 + OWNL_SPAN + k - 1 : m1;
     for (u64 t = b0 + threadIdx.x; t < lim; t += 256) sh_keys[t - b0] = mh[t];
+    if (T.claim) for (int u = threadIdx.x; u < OWNL_SPAN / 8; u += 256) ((u64*)cl)[u] = 0;
     __syncthreads();
     for (u32 base = s0; base < s1; base += 256) {
         const u32 j = base + threadIdx.x;
@@ -645,11 +691,15 @@ __global__ __launch_bounds__(256) void insert_listed_span_kernel(TableArgs T, co
         const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
         bool claimed, found;
         const u64 s = upsert_wave(T, ok, li, i, sh_keys + li, k, claimed, found);      // (a wave-wide call: no lane leaves the loop early)
-        if (claimed) mread[i] = slot;              // rep_ordinal() finds the representative's read through it; the rest of a listed batch's map is filled on demand
+        if (claimed) { mread[i] = slot; if (T.claim) cl[li] = 1; }      // (mread: rep_ordinal() finds the representative's read through it; the rest of a listed batch's map is filled on demand)
         if (found) {
             atomicAdd(&T.tab[s].count, 1u);
             push_ordinal(T, s, ord);
         }
+    }
+    if (T.claim) {                                 // the span's claim bytes, 64 consecutive bytes per wave and store
+        __syncthreads();
+        for (u32 li = threadIdx.x; li < span_n; li += 256) T.claim[b0 + li] = cl[li];
     }
 }
 u32 owner_list_spans(u64 n_minimizers) { return (u32)((n_minimizers + OWNL_SPAN - 1) / OWNL_SPAN); }
@@ -659,7 +709,7 @@ void launch_list_segments(const u32* list, u64 n, u32 n_spans, u32* seg, hipStre
     if (n && n_spans) hipLaunchKernelGGL(list_segments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, list, n, n_spans, seg);
 }
 void launch_owner_list_count(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u32* blk_cnt, u8* owner_of, hipStream_t s) {
-    const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k - 1) * sizeof(u64) : 0;
+    const size_t lds = k <= OWNL_LDS_MAX_K ? 2 * ((size_t)OWNL_SPAN + k) * sizeof(u16) : 0;
     if (i1 > i0) hipLaunchKernelGGL(owner_list_count_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), lds, s, mh, mread, roff, i0, i1, k, world, thr, blk_cnt, owner_of);
 }
 void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 k, u32 world, const u64* thr, u32 slot0, const u64* blk_off, const OwnerBases& bases, u32* list, const u8* owner_of, hipStream_t s,
@@ -670,7 +720,7 @@ void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u
 void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, const u32* seg, u64 n, u32 slot0,
                           u32 n_reads, u64 first_ordinal, u32* cap_err, hipStream_t s) {
     if (!n) return;
-    const size_t lds = ((size_t)OWNL_SPAN + T.ks.k) * sizeof(u64);
+    const size_t lds = ((size_t)OWNL_SPAN + T.ks.k) * sizeof(u64) + OWNL_SPAN;      // hashes + the span's claim bytes
     // few listed windows per span (a rank's share of a sketch at 4+ ranks): staging every span of the sketch would mostly fetch hashes nobody needs, and
     // a workgroup would work off a few dozen entries; the per-entry kernel reads each window's values where they lie
     u64 per_span_min = 150;
@@ -686,7 +736,7 @@ void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u
 bool listed_is_sparse(const TableArgs& T, u64 m0, u64 m1, u64 n) {
     u64 per_span_min = 150;
     { const char* v = getenv("MDBG_LISTED_SPAN_MIN"); if (v) per_span_min = strtoull(v, nullptr, 10); }
-    return n < (u64)owner_list_spans(m1 - m0) * per_span_min || ((size_t)OWNL_SPAN + T.ks.k) * sizeof(u64) > 64 * 1024;
+    return n < (u64)owner_list_spans(m1 - m0) * per_span_min || ((size_t)OWNL_SPAN + T.ks.k) * sizeof(u64) + OWNL_SPAN > 64 * 1024;
 }
 void launch_insert_listed_multi(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, const ListedBatch* d_batches, u32 n_batches, u64 total, u32* cap_err, hipStream_t s) {
     if (!total) return;
@@ -717,6 +767,53 @@ __global__ __launch_bounds__(256) void reserve_check_kernel(const u64* __restric
     }
 }
 
+// count_windows_kernel + reserve_check_kernel in ONE launch (the insertion launched behind the batch's own sketch: two 8-microsecond kernels in a row in front of every
+// insertion).  Every workgroup adds its reads' windows to *batch_windows and then to *done; the workgroup that brings *done to the grid size runs the check (the
+// others' additions are visible to it: device-scope atomics, a fence on both sides) and sets *done back to zero for the next launch.
+__global__ __launch_bounds__(1024) void count_reserve_kernel(const u64* __restrict__ roff, u32 slot0, u32 n_reads, u32 k, u64* __restrict__ batch_windows, u32* __restrict__ done,
+                                                             const u64* __restrict__ distinct_shards, u64* __restrict__ n_distinct, u64 cap, u32* __restrict__ too_small,
+                                                             const u64* __restrict__ carry, u64 store_cap, const u32* __restrict__ over_max) {
+    __shared__ u64 ws[16];
+    __shared__ u32 last;
+    u64 w = 0;
+    for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) { const u64 n = roff[slot0 + r + 1] - roff[slot0 + r]; if (n > k) w += n - k + 1; }
+    for (int d = 32; d; d >>= 1) w += __shfl_down(w, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0;
+        for (int i = 0; i < 16; ++i) t += ws[i];
+        if (t) atomicAdd((unsigned long long*)batch_windows, (unsigned long long)t);      // (at most 64 workgroups: two same-address atomics each, ~12 ns apiece)
+        __threadfence();
+        last = atomicAdd(done, 1u) + 1u == gridDim.x ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    u64 v = 0;
+    for (int i = threadIdx.x; i < CTR_SHARDS; i += 1024) v += distinct_shards[i];
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    __syncthreads();                                   // (ws is read above by thread 0 only, long ago; the barrier is for its reuse)
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 nd = 0;
+        for (int i = 0; i < 16; ++i) nd += ws[i];
+        *n_distinct = nd;
+        const u64 bw = __hip_atomic_load(batch_windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 n = nd + bw;
+        bool skip = n + n / 2 + 1024 > cap;                                                      // slots_for(), api.inc
+        if (carry) skip = skip || *carry > store_cap || *carry >= 0xFFFFFFF0ull || (over_max && *over_max);
+        *too_small = skip ? 1u : 0u;
+        *done = 0;
+    }
+}
+void launch_count_reserve(const u64* roff, u32 slot0, u32 n_reads, u32 k, u64* batch_windows, u32* done, const u64* distinct_shards, u64* n_distinct, u64 cap, u32* too_small,
+                          const u64* carry, u64 store_cap, const u32* over_max, hipStream_t s) {
+    hipLaunchKernelGGL(count_reserve_kernel, dim3(n_reads ? std::min<u32>(64u, (n_reads + 1023) / 1024) : 1), dim3(1024), 0, s, roff, slot0, n_reads, k, batch_windows, done, distinct_shards, n_distinct, cap,
+                       too_small, carry, store_cap, over_max);
+}
+
 // routed records (k canonical u64, ordinal, key hash) sitting in the arena at record index r0..
 __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0, u64 r1, u64* __restrict__ n_windows) {
     const u64 r = r0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -732,8 +829,16 @@ __global__ __launch_bounds__(256) void insert_records_kernel(TableArgs T, u64 r0
     (void)n_windows;
 }
 
-__global__ void clear_table_kernel(Slot* __restrict__ tab, u64 cap, u64* __restrict__ mx, u64 n_mx) {
+struct ZeroList { u64* p[6]; u64 n[6]; u64* set_p; u64 set_v; };
+// z: small regions zeroed by the same launch (mdbg_reset: the shards of the key counter and three scalars — a launch of their own until round 6)
+__global__ void clear_table_kernel(Slot* __restrict__ tab, u64 cap, u64* __restrict__ mx, u64 n_mx, ZeroList z) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
+    {
+        const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) for (u64 i = i0; i < z.n[r]; i += stride) z.p[r][i] = 0;
+        if (i0 == 0 && z.set_p) *z.set_p = z.set_v;
+    }
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) {
         uint4* p = (uint4*)(tab + i);
         p[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);     // word, m1
@@ -764,6 +869,7 @@ struct BatchTab {                 // batches sorted by first_ordinal (device cop
     const u64* first_ordinal; const u32* n_reads; const u32* slot0; const u64* rank_base; u32 n;
     const u32* by_slot0; const u64* by_slot_first;   // the same batches sorted by slot0 (= call order): slot -> read ordinal
     const u64* by_m0; const u64* by_m0_rank;         // the batches sorted by position in the store: first minimizer index and its dense rank
+    const u64* m0;                                   // in first_ordinal order: first minimizer index of the batch (dense index -> store index, claims_to_bits_kernel)
 };
 struct FinArgs {
     const Slot* tab; u64 cap; const u64* mx; u32 A; u32 casc; u32 k; u32 l;   // A: abundance filter; casc: ordinals tracked per slot (= A up to 8, else 1)
@@ -779,7 +885,9 @@ struct FinArgs {
     const u64* ath_override;                 // [Slot.pad - 1]: sighting whose metadata a node that wrapped its u16 abundance keeps (null: none)
     u64* bm_first; u64* bm_solid;            // bitmaps over dense ordered minimizer index
     u32 claims;                              // 1: by_first IS the insertion's claim map (TableArgs::claim) and dense index == store index: fin_mark only moves the marks of
-                                             // keys whose first sighting is not their claimer (keys seen once — most — need nothing)
+                                             // keys whose first sighting is not their claimer (keys seen once — most — need nothing).  2 (round 6): the same map where the
+                                             // dense order is NOT the store's (a partitioned table: the peers' regions lie between this rank's batches, batches out of
+                                             // ordinal order): the map is indexed by STORE index, claims_to_bits_kernel turns it into the dense bitmaps
     u8* by_first; u8* by_solid;              // the same as one BYTE per index (zeroed): fin_mark sets bytes with plain stores — 3.9 M device-scope atomics on the
                                              // bitmaps were most of its time —, bytes_to_bits_kernel packs them into the bitmaps
     const u32* pre_first; const u32* pre_solid;   // exclusive popcount prefix per 64-bit word
@@ -861,11 +969,14 @@ __global__ __launch_bounds__(1024) void fin_mark_kernel(FinArgs F) {
                 // stores into a 721 MB map were 10 ms of the human table's finalize (1.3 TB/s); 183 M of those keys are seen once and cost nothing here
                 // ONE map in this mode: bit 0 = first sighting, bit 1 = the key is solid (no second map to zero: 2.2 ms per finalize of the human table); with the batches in ordinal order — the mode's
                 // condition — a first sighting never moves forward
-                const u64 Dc = (u32)e[u].word;
+                // (F.claims == 2: the map is indexed by STORE index, the dense index of the claimer comes from the batch table)
+                const u64 ic = (u32)e[u].word;
+                const u64 Dc = F.claims == 2 ? dense_of_index(F, ic) : ic;
+                u64 at = ic;
                 D = Dc;
-                if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; } }
+                if (e[u].count) { u64 i, D1; decode_ordinal(F, e[u].m1, i, D1); if (D1 < Dc) { D = D1; at = i; F.by_first[ic] = 0; } }
                 // (a key seen again always rewrites its byte: its solid bit may have to GO — a u16 abundance that wrapped below minabund between two finalize calls, round-5 advice)
-                if (e[u].count || solid[u]) F.by_first[D] = solid[u] ? 3 : 1;
+                if (e[u].count || solid[u]) F.by_first[at] = solid[u] ? 3 : 1;
             } else {
             if (e[u].word & (1ull << 33)) { u64 i; const u64 ro = rep_ordinal(F, e[u].word); decode_ordinal(F, ro < e[u].m1 ? ro : e[u].m1, i, D); }   // routed record
             else {
@@ -952,12 +1063,14 @@ __global__ __launch_bounds__(1024) void fin_mark_claims_kernel(FinArgs F) {
             solid = F.A == 1 || (u16)count >= (u16)F.A;
             // the claimer's byte is set already (insert_windows_kernel); a key seen again may have an earlier sighting: move the mark there.  ONE map in this mode: bit 0 =
             // first sighting, bit 1 = the key is solid (see fin_mark_kernel)
-            const u64 Dc = (u32)e.word;
+            const u64 ic = (u32)e.word;                                    // store index of the claimer; F.claims == 2: the map is indexed by store index, not by dense index
+            const u64 Dc = F.claims == 2 ? dense_of_index(F, ic) : ic;
+            u64 at = ic;
             D = Dc;
-            if (e.count) { u64 i, D1; decode_ordinal(F, e.m1, i, D1); if (D1 < Dc) { D = D1; F.by_first[Dc] = 0; } }
+            if (e.count) { u64 i, D1; decode_ordinal(F, e.m1, i, D1); if (D1 < Dc) { D = D1; at = i; F.by_first[ic] = 0; } }
             // every listed slot (seen again, or solid) rewrites its byte: the solid bit is also CLEARED — solidity is (u16)count >= (u16)A, which turns false again when the
             // abundance wraps (count 65535 finalized as solid, more batches, count 65536 = u16 0, finalized again: round-5 advice; the byte-map path zeroes its maps per finalize)
-            F.by_first[D] = solid ? 3 : 1;
+            F.by_first[at] = solid ? 3 : 1;
         }
         const u64 mk = __ballot(solid);
         u32 base = 0;
@@ -972,10 +1085,13 @@ __global__ __launch_bounds__(1024) void fin_mark_claims_kernel(FinArgs F) {
     for (u32 t = threadIdx.x; t < ns; t += 1024) { F.solid_list[bbase + t] = b0 + sol_li[t]; F.solid_dense[bbase + t] = (u64)sol_D[t]; }
 }
 // bitmap word w <- bit i = (byte 64 w + i != 0), for both maps; one thread per word (four 16-byte loads per map).  by1 == null: ONE map whose bytes hold bit 0 = first
-// sighting, bit 1 = solid (the claim-map mode of fin_mark_kernel)
-__global__ __launch_bounds__(256) void bytes_to_bits_kernel(const u8* __restrict__ by0, const u8* __restrict__ by1, u64 n_words, u64* __restrict__ bm0, u64* __restrict__ bm1) {
-    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (w >= n_words) return;
+// sighting, bit 1 = solid (the claim-map mode of fin_mark_kernel).  Bits at or behind n_bits are cleared (the claim map's bytes behind the store's end are whatever
+// the allocation holds: masked here instead of being zeroed by a fill in front of every finalize).  block_sum (non-null): the popcounts of the workgroup's 1,024 words of
+// either bitmap — what popc_block_kernel would compute in a launch of its own: [blockIdx] and [n_blocks + blockIdx].
+__global__ __launch_bounds__(1024) void bytes_to_bits_kernel(const u8* __restrict__ by0, const u8* __restrict__ by1, u64 n_words, u64 n_bits, u64* __restrict__ bm0, u64* __restrict__ bm1,
+                                                             u32* __restrict__ block_sum, u32 n_blocks) {
+    __shared__ u32 ws[2][16];
+    const u64 w = (u64)blockIdx.x * 1024 + threadIdx.x;
     auto pack = [](const u8* p, u32 shift) -> u64 {
         u64 out = 0;
 #pragma unroll
@@ -987,10 +1103,49 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const u8* __restrict
         }
         return out;
     };
-    bm0[w] = pack(by0 + 64 * w, 0); bm1[w] = by1 ? pack(by1 + 64 * w, 0) : pack(by0 + 64 * w, 1);
+    u64 a = 0, b = 0;
+    if (w < n_words) {
+        a = pack(by0 + 64 * w, 0); b = by1 ? pack(by1 + 64 * w, 0) : pack(by0 + 64 * w, 1);
+        if (64 * w + 64 > n_bits) { const u64 keep = 64 * w >= n_bits ? 0ull : (1ull << (n_bits - 64 * w)) - 1ull; a &= keep; b &= keep; }
+        bm0[w] = a; bm1[w] = b;
+    }
+    if (!block_sum) return;
+    u32 v0 = (u32)__popcll(a), v1 = (u32)__popcll(b);
+    for (int d = 32; d; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = v0; ws[1][threadIdx.x >> 6] = v1; }
+    __syncthreads();
+    if (threadIdx.x < 2) { u32 t = 0; for (int i = 0; i < 16; ++i) t += ws[threadIdx.x][i]; block_sum[threadIdx.x * n_blocks + blockIdx.x] = t; }
 }
-void launch_bytes_to_bits(const u8* by0, const u8* by1, u64 n_words, u64* bm0, u64* bm1, hipStream_t s) {
-    if (n_words) hipLaunchKernelGGL(bytes_to_bits_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, by0, by1, n_words, bm0, bm1);
+// block_sum: null, or 2 * ceil(n_words / 1024) u32 (then launch_popc_prefix2 may skip its first kernel: have_block_sums)
+void launch_bytes_to_bits(const u8* by0, const u8* by1, u64 n_words, u64 n_bits, u64* bm0, u64* bm1, u32* block_sum, hipStream_t s) {
+    const u32 nb = (u32)((n_words + 1023) / 1024);
+    if (n_words) hipLaunchKernelGGL(bytes_to_bits_kernel, dim3(nb), dim3(1024), 0, s, by0, by1, n_words, n_bits, bm0, bm1, block_sum, nb);
+}
+// F.claims == 2: the claim map is indexed by STORE index, the bitmaps by dense ordered index (the batches in first-ordinal order): one wave per 64 dense indices — lane l reads
+// the byte of dense index 64 w + l at its batch's place in the store (consecutive lanes read consecutive bytes except across a batch boundary), two ballots are the two
+// bitmap words.  ~1 byte read per resident minimizer; the per-block popcounts are left to popc_block_kernel (a partitioned table merges the bitmaps over the ranks first).
+__global__ __launch_bounds__(256) void claims_to_bits_kernel(FinArgs F, u64 n_words, u64 n_bits, u64* __restrict__ bm0, u64* __restrict__ bm1) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 w0 = ((u64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;          // 16 words per wave
+    u32 bi = 0; u64 lo = 0, hi = 0, m0 = 0;                                    // the batch [lo, hi) of dense indices the lane looked at last
+    for (u64 w = w0; w < w0 + 16 && w < n_words; ++w) {
+        const u64 D = 64 * w + lane;
+        u8 b = 0;
+        if (D < n_bits) {
+            if (D < lo || D >= hi) {
+                u32 a = 0, z = F.bt.n - 1;
+                while (a < z) { const u32 mid = a + ((z - a + 1) >> 1); if (F.bt.rank_base[mid] <= D) a = mid; else z = mid - 1; }
+                bi = a; lo = F.bt.rank_base[bi]; hi = bi + 1 < F.bt.n ? F.bt.rank_base[bi + 1] : n_bits; m0 = F.bt.m0[bi];
+                // (batches without a minimizer share their rank base with the batch behind them: the search ends on the last of them, whose range [lo, hi) holds D)
+            }
+            b = F.by_first[m0 + (D - lo)];
+        }
+        const u64 w_first = __ballot(b & 1), w_solid = __ballot(b & 2);
+        if (lane == 0) { bm0[w] = w_first; bm1[w] = w_solid; }
+    }
+}
+void launch_claims_to_bits(const FinArgs& F, u64 n_words, u64 n_bits, u64* bm0, u64* bm1, hipStream_t s) {
+    if (n_words) hipLaunchKernelGGL(claims_to_bits_kernel, dim3((unsigned)((n_words + 63) / 64)), dim3(256), 0, s, F, n_words, n_bits, bm0, bm1);
 }
 // row of every listed solid slot (rank of its first sighting among the solid ones) -> order[row] = slot
 __global__ __launch_bounds__(256) void fin_order_kernel(FinArgs F, u64 n_solid, u64* __restrict__ order) {
@@ -1440,7 +1595,9 @@ __global__ __launch_bounds__(256) void sum_shards_kernel(const u64* __restrict__
 // What the host reads between the stages, in one launch: scalars[idx[j]] = sum of shard array j (up to three), then all n scalars -> pinned
 // host memory (was: the sum kernels, a copy kernel and the runtime's staging of a pageable destination in front of every host decision).
 // host[n] = seq is written last (system-scope fence in between): the host polls that word instead of waiting for the queue's completion signal
-struct PublishArgs { const u64* shards[3]; u32 idx[3]; u32 n_arrays; u64* scalars; u32 n; u32 zero_idx; u64* host; u64 seq; };      // zero_idx: scalar reset once it has been published (>= n: none)
+struct PublishArgs { const u64* shards[3]; u32 idx[3]; u32 n_arrays; u64* scalars; u32 n; u32 zero_idx; u64* host; u64 seq;      // zero_idx: scalar reset once it has been published (>= n: none)
+                     u64 zero_mask; u32 zero_arrays; };      // zero_mask: further scalars reset behind the copy (bit i: scalar i); zero_arrays: bit j: shard array j is zeroed once it has been summed
+                                                              // (the finalize counters are left clean for the next finalize: no zeroing launch in front of it)
 __global__ __launch_bounds__(1024) void publish_scalars_kernel(PublishArgs p) {
     __shared__ u64 ws[3][16];
     static_assert(CTR_SHARDS % 1024 == 0, "whole rounds");
@@ -1448,6 +1605,7 @@ __global__ __launch_bounds__(1024) void publish_scalars_kernel(PublishArgs p) {
         u64 v = 0;
 #pragma unroll
         for (int i = 0; i < CTR_SHARDS / 1024; ++i) v += p.shards[j][threadIdx.x + 1024 * i];
+        if ((p.zero_arrays >> j) & 1u) for (int i = 0; i < CTR_SHARDS / 1024; ++i) ((u64*)p.shards[j])[threadIdx.x + 1024 * i] = 0;      // (every entry is read and zeroed by the same thread)
         for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
         if ((threadIdx.x & 63) == 0) ws[j][threadIdx.x >> 6] = v;
     }
@@ -1456,7 +1614,7 @@ __global__ __launch_bounds__(1024) void publish_scalars_kernel(PublishArgs p) {
         u64 v = p.scalars[threadIdx.x];
         for (u32 j = 0; j < p.n_arrays; ++j) if (threadIdx.x == p.idx[j]) { v = 0; for (int q = 0; q < 16; ++q) v += ws[j][q]; p.scalars[threadIdx.x] = v; }
         __hip_atomic_store(p.host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (threadIdx.x == p.zero_idx) p.scalars[threadIdx.x] = 0;
+        if (threadIdx.x == p.zero_idx || ((p.zero_mask >> threadIdx.x) & 1ull)) p.scalars[threadIdx.x] = 0;
     }
     __threadfence_system();
     __syncthreads();
@@ -1470,20 +1628,21 @@ void launch_publish_scalars(const PublishArgs& p, hipStream_t s) {
 void launch_sum_shards(const u64* shards, u32 n_arrays, u64* out, hipStream_t s) {
     hipLaunchKernelGGL(sum_shards_kernel, dim3(n_arrays), dim3(256), 0, s, shards, out);
 }
-void launch_clear_table(Slot* tab, u64 cap, u64* mx, u64 n_mx, hipStream_t s) {
-    hipLaunchKernelGGL(clear_table_kernel, dim3(2048), dim3(256), 0, s, tab, cap, mx, n_mx);
+void launch_clear_table(Slot* tab, u64 cap, u64* mx, u64 n_mx, hipStream_t s, const ZeroList* z = nullptr) {
+    ZeroList none{};
+    hipLaunchKernelGGL(clear_table_kernel, dim3(2048), dim3(256), 0, s, tab, cap, mx, n_mx, z ? *z : none);
 }
 void launch_insert_windows(const TableArgs& T, const u64* mh, const u32* mread, const u64* roff, u64 i0, u64 i1, u32 slot0,
                            u64 first_ordinal, u64* n_windows, u32* cap_err, hipStream_t s, const u64* i1_dev = nullptr, u64 n_starts = 0) {
     if (i1 <= i0) return;
     (void)n_windows;
     const u64 n = n_starts ? n_starts : i1 - i0;          // n_starts: only the window starts [i0, i0 + n_starts) (a slice; i1 stays the end of the batch)
+    const size_t codes = T.own_world > 1 && T.own_thr ? 2 * ((size_t)OWN_SPAN + T.ks.k) * sizeof(u16) : 0;      // partitioned table: the owner codes of the staged hashes
     hipLaunchKernelGGL(insert_windows_kernel, dim3((unsigned)((n + OWN_SPAN - 1) / OWN_SPAN)), dim3(256),
-                       (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16 + OWN_SPAN, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err, i1_dev, n);
+                       (OWN_SPAN + T.ks.k) * sizeof(u64) + OWN_SPAN * sizeof(u16) + 16 + OWN_SPAN + codes, s, T, mh, mread, roff, i0, i1, slot0, first_ordinal, cap_err, i1_dev, n);
 }
 // Several small regions zeroed (and one scalar set) by ONE launch: the steps between the big kernels would otherwise be chains of
 // 5-microsecond fill kernels (ten of them in front of the sketch, five in front of finalize).
-struct ZeroList { u64* p[6]; u64 n[6]; u64* set_p; u64 set_v; };
 __global__ __launch_bounds__(256) void zero_regions_kernel(ZeroList z) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, stride = (u64)gridDim.x * blockDim.x;
 #pragma unroll
@@ -1545,11 +1704,12 @@ void launch_bitmap_totals(const u64* bm0, const u32* pre0, const u64* bm1, const
     hipLaunchKernelGGL(bitmap_totals_kernel, dim3(1), dim3(64), 0, s, bm0, pre0, bm1, pre1, n_words, out);
 }
 // block_tmp: 2 * ceil(n_words / 1024) u32
-void launch_popc_prefix2(const u64* bm0, const u64* bm1, u64 n_words, u32* block_tmp, u32* pre0, u32* pre1, hipStream_t s) {
+// have_block_sums: block_tmp holds the plain per-block popcounts already (launch_bytes_to_bits wrote them with the bitmaps)
+void launch_popc_prefix2(const u64* bm0, const u64* bm1, u64 n_words, u32* block_tmp, u32* pre0, u32* pre1, hipStream_t s, bool have_block_sums = false) {
     if (!n_words) return;
     const u32 nb = (u32)((n_words + 1023) / 1024);
     const u32 self_base = nb <= 1024 ? 1u : 0u;
-    hipLaunchKernelGGL(popc_block_kernel, dim3(nb), dim3(1024), 0, s, bm0, bm1, n_words, block_tmp, nb);
+    if (!have_block_sums) hipLaunchKernelGGL(popc_block_kernel, dim3(nb), dim3(1024), 0, s, bm0, bm1, n_words, block_tmp, nb);
     if (!self_base) hipLaunchKernelGGL(popc_scan_blocks_kernel, dim3(2), dim3(1024), 0, s, block_tmp, nb);
     hipLaunchKernelGGL(popc_prefix_kernel, dim3(nb), dim3(1024), 0, s, bm0, bm1, n_words, block_tmp, nb, self_base, pre0, pre1);
 }

@@ -183,6 +183,10 @@ class DistMdbg:
         self._chk(self.L.mdbg_dist_finalize(self.h, C.byref(nd), C.byref(row), C.byref(ng)))
         return nd, row.value, int(ng.value)
 
+    def set_timing(self, level):
+        """mdbg_set_timing on the layer's context (0: no HIP events, 1: tile kernel only, 2: stages too)"""
+        self._chk(self.L.mdbg_set_timing(C.c_void_p(self.L.mdbg_dist_ctx(self.h)), level))
+
     def nodes_digest(self, nd):
         """(sum, xor) over this rank's partition (a table of finalize()): the ranks' digests add / XOR up to the one-GPU table's (include/mdbg_hip.h, mdbg_nodes_digest)"""
         a, b = C.c_uint64(), C.c_uint64()

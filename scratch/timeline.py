@@ -18,6 +18,32 @@ if os.environ.get("MODE", "def") == "def":
         print("%8.3f ms  gap %7.3f  dur %7.3f  %s" % ((s - t0) / 1e6, (s - prev) / 1e6 if s > prev else 0.0, (e - s) / 1e6, n))
         busy += max(0, e - max(s, prev)); prev = max(prev, e)
     print("busy %.3f ms, idle %.3f ms" % (busy / 1e6, (rows[b][0] - t0 - busy) / 1e6))
+elif os.environ.get("MODE") == "dist":
+    # the last step that went through the multi-GPU layer: from the fin_emit in front of the last owner_list_count_kernel to the fin_emit behind it
+    ol = [i for i, r in enumerate(rows) if r[2].startswith("owner_list_count")]
+    fe = [i for i, r in enumerate(rows) if r[2].startswith("fin_emit")]
+    a = max([i for i in fe if i < ol[-1]] + [-1]) + 1
+    b = min([i for i in fe if i > ol[-1]])
+    seg = rows[a:b + 1]
+    t0 = seg[0][0]; busy = 0; gaps = []; prev_end = seg[0][0]
+    for s, e, n in seg:
+        if s > prev_end: gaps.append((s - prev_end, n, (s - t0) / 1e6))
+        busy += max(0, e - max(s, prev_end)); prev_end = max(prev_end, e)
+    span = prev_end - t0
+    print("last dist step: span %.2f ms, busy %.2f ms, idle %.2f ms in %d gaps, %d launches" % (span / 1e6, busy / 1e6, (span - busy) / 1e6, len(gaps), len(seg)))
+    for g, n, at in sorted(gaps, reverse=True)[:30]: print("gap %.3f ms before %s at %.2f ms" % (g / 1e6, n, at))
+    c = collections.Counter(); cn = collections.Counter()
+    for s, e, n in seg: c[n] += e - s; cn[n] += 1
+    for n, t in c.most_common(50): print("%-50s %4d x  %.3f ms" % (n, cn[n], t / 1e6))
+    ins = [i for i, r in enumerate(seg) if r[2].startswith("insert_")]
+    print("from the last insertion on (start, gap, dur in ms):")
+    prev = seg[ins[-1]][0]
+    for s, e, n in seg[ins[-1]:]:
+        print("  %8.3f gap %7.3f dur %7.3f  %s" % ((s - t0) / 1e6, (s - prev) / 1e6 if s > prev else 0.0, (e - s) / 1e6, n)); prev = max(prev, e)
+    print("the first chunk (start, gap, dur in ms):")
+    prev = seg[0][0]
+    for s, e, n in seg[:60]:
+        print("  %8.3f gap %7.3f dur %7.3f  %s" % ((s - t0) / 1e6, (s - prev) / 1e6 if s > prev else 0.0, (e - s) / 1e6, n)); prev = max(prev, e)
 else:
     nt = int(os.environ.get("TILES_PER_STEP", "0")) or (16 if len(sk) % 16 == 0 and len(sk) >= 32 else 8)
     i0 = sk[-nt]
