@@ -55,7 +55,8 @@ struct SketchArgs {
     u32 scheme, s;               // MDBG_SCHEME_SYNCMERS: s-mer length (0: every l-mer is a candidate); bound = floor(density * 4^l) then
     u32 force_slow;              // MDBG_FLAG_FORCE_GENERIC: every tile takes the generic exact walker
     u64* dbg;                    // diagnostic: per-tile phase timestamps [n_tiles][16] (null in production)
-    u32 stop_phase;              // diagnostic (MDBG_STOP_PHASE): tiles stop after this phase and report no minimizers (0: run everything)
+    u32 stop_phase;              // diagnostic (MDBG_STOP_PHASE): tiles stop after this phase and report no minimizers (0: run everything; 4 / 5: inside phase 4, after the
+                                 // exact evaluation + placement / after the rank scan)
 };
 
 // largest r in [lo, hi] with off[r] <= p
@@ -989,8 +990,10 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         }
         tile_sync<NW>();
         MDBG_STAMP(4);
+        if (MDBG_HOT(a.stop_phase == 4, false)) return 0u;            // (diagnostic: instruction counts of the exact evaluation + placement alone; uniform over the tile)
         const u32 left = count_words();
         MDBG_STAMP(5);
+        if (MDBG_HOT(a.stop_phase == 5, false)) return 0u;
 #pragma unroll
         for (int i = 0; i < NR; ++i) if ((keep_ok >> i) & 1u) {
             const u32 rank = rank_of(keep_e[i]);

@@ -1,0 +1,58 @@
+"""What ONE rank of an eight-rank step computes on its own batch, measured on one GPU (no peers, no exchange): a human shard (19.5 Gbases, k=35 l=14 d=0.003) sketched in two
+chunks, the owner lists for eight ranks, the insertion of the rank's own windows (one in eight, found by insert_windows_kernel itself), the partitioned finalize.  The figures
+feed the time budget of DESIGN.md 3.4; what is missing from a real rank's step is the peers' windows (7/8 of the rank's table: insert_listed_span_kernel at the same rate
+per window) and the exchange itself.
+usage: python scratch/measure_rank_w8.py [world] [genome_mb]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import rust_mdbg_amd as R
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+genome_mb = float(sys.argv[2]) if len(sys.argv) > 2 else 3000.0
+k, l, d, A = 35, 14, 0.003, 2
+shard_reads = int(genome_mb * 1e6 * 52.0 / 15000.0) // 8
+m = R.Mdbg(k, l, d, A, device=0)
+m.set_partition(W, 0)
+db, do, nb = m.synth_reads_device(seed=1, genome_len=int(genome_mb * 1e6), n_reads=shard_reads, mean_len=15000, sd_len=1500, min_len=8000, max_len=25000, err_ppm=1000, first_read=0)
+words = torch.zeros((nb + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+torch.cuda.synchronize()
+assert m.pack_device(db, nb, words.data_ptr()) == 0
+m.sync()
+
+
+def step():
+    t = {}
+    m.reset(0)
+    m.sync(); t0 = time.perf_counter()
+    m.ingest_packed_device(words.data_ptr(), do, shard_reads, nb, 0, sketch_only=True)
+    m.sync(); t["sketch"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cnt, _ = m.owner_lists(W)
+    m.sync(); t["owner_lists"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m.insert_resident()
+    m.sync(); t["insert_own"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    a, b, nw = m.finalize_begin()
+    m.sync(); t["finalize_begin"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nd, row, ng = m.finalize_end()
+    m.sync(); t["finalize_end"] = time.perf_counter() - t0
+    return t, cnt, int(nd.n), nw
+
+
+best = None
+for rep in range(4):
+    t, cnt, n_nodes, nw = step()
+    if rep and (best is None or sum(t.values()) < sum(best.values())):
+        best = t
+st = m.stats()
+print("W=%d shard %.2f Gbases, %d minimizers, windows per owner max/mean %.3f, own windows %d, nodes of this rank %d, bitmap words %d" % (
+    W, nb / 1e9, st["n_minimizers"], max(cnt) / (sum(cnt) / W), cnt[0], n_nodes, nw))
+print("ms per stage (host time around each call, best of 3):", {k_: round(v * 1e3, 3) for k_, v in best.items()}, "sum %.3f" % (sum(best.values()) * 1e3))
+print("library timers of the last pass:", {f: round(st[f], 3) for f in ("ms_sketch", "ms_sketch_tile", "ms_insert", "ms_finalize")})
