@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--watchdog-seconds", type=int, default=1500, help="a rank that is still running after this long dumps the tracebacks of all its threads to stderr and exits (a hang "
                     "in a collective would otherwise sit there until the caller's own limit, without a word); 0 = off")
     ap.add_argument("--no-scale-anchor", action="store_true", help="default N=1 run: skip the human data set's pass through this GPU after the timed region (scale_anchor_n1)")
+    ap.add_argument("--no-anchor-oracle", action="store_true", help="default N=1 run: skip the CPU oracle's pass over one shard of the human data set (scale_anchor_n1.shard_vs_oracle, ~30 s)")
     ap.add_argument("--plain", action="store_true", help="only the warm-up and the timed steps (no ASCII legs, no edge stage, no CPU leg): for profiler runs, where every launch should be one of the timed kind")
     ap.add_argument("--force-dist", action="store_true", help="use the routed multi-GPU path even with one rank")
     ap.add_argument("--dist-mode", choices=["replicate", "route"], default="replicate",
@@ -296,13 +297,13 @@ def human_shards(m, torch, np, genome_mb, coverage, shard_ids):
     return batches, keep, shard_reads, (d_bases, d_off0)
 
 
-def scale_anchor_n1(R, torch, np, device_index, minabund):
+def scale_anchor_n1(R, torch, np, device_index, minabund, oracle_shard=False):
     """The N=1 point of the 1 -> 8 curve measured in the DEFAULT N=1 run as well: the multi-GPU lines run BASELINE configs[3] (the same 156 Gbases at every N), the
     default N=1 line configs[2] — so the human data set goes through this one GPU once more here, after the timed region (about 3 s), and the curve's anchor sits in
     the same driver record as the headline."""
     k, l, d, gm, cov = 35, 14, 0.003, 3000.0, 52.0
     with R.Mdbg(k, l, d, minabund, device=device_index) as mh:
-        batches, keep, shard_reads, _ = human_shards(mh, torch, np, gm, cov, range(HUMAN_SHARDS))
+        batches, keep, shard_reads, last_ascii = human_shards(mh, torch, np, gm, cov, range(HUMAN_SHARDS))
 
         last = {}
 
@@ -323,11 +324,40 @@ def scale_anchor_n1(R, torch, np, device_index, minabund):
         st = mh.stats()
         total = sum(b[3] for b in batches)
         digest = hex_digest(mh.nodes_digest(last["nd"]))
+        shard_check = None
+        if oracle_shard and "scale_anchor_oracle" in os.environ.get("MDBG_BENCH_FAIL_SIDE", "").split(","):
+            shard_check = {"error": "forced by MDBG_BENCH_FAIL_SIDE"}
+        elif oracle_shard:
+            try:
+                # One shard of configs[3] (19.5 Gbases: the batch a rank of eight ingests per step) through the GPU alone and through the CPU oracle: node count, window count and
+                # the node-set digest must agree — the human PARAMETERS at full batch size against the oracle in the driver's own record (the whole data set would be 8 x this).
+                from oracle import oracle as O
+                g = HUMAN_SHARDS - 1                   # the shard generated last: its ASCII is still in the context's buffer
+                b_in, b_off, b_reads, b_bases, b_first = batches[g]
+                d_bases, d_off0 = last_ascii
+                mh.reset(0)
+                mh.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first)
+                nd1 = mh.finalize_device()
+                st1 = mh.stats()
+                gpu1 = (int(nd1.n), int(st1["n_windows"]), hex_digest(mh.nodes_digest(nd1)))
+                offs = mh.to_host(d_off0, (b_reads + 1) * 8, np.uint64)
+                bases = mh.to_host(d_bases, int(offs[-1]))
+                cores = os.cpu_count() or 1
+                t2 = time.perf_counter()
+                solid, wins, dg = O.count_digest_threaded(bases, offs, k, l, d, minabund, threads=cores)
+                dt2 = time.perf_counter() - t2
+                del bases
+                shard_check = {"what": "shard %d of the data set alone (%.1f Gbases): GPU node table vs the CPU oracle on the same reads" % (g, b_bases / 1e9), "nodes": int(solid), "windows": int(wins),
+                               "node_digest": hex_digest(dg), "gpu_nodes": gpu1[0], "gpu_windows": gpu1[1], "gpu_node_digest": gpu1[2], "cpu_seconds": dt2, "cores": cores,
+                               "cpu_gbases_per_s": b_bases / dt2 / 1e9, "matches_gpu": bool((int(solid), int(wins), hex_digest(dg)) == gpu1)}
+            except Exception as ex:          # (a side measurement of a side measurement: the anchor's timing above must not be lost to it)
+                shard_check = {"error": repr(ex)[:300]}
         del keep
     return {"what": "BASELINE.json configs[3] (synthetic human 3 Gb @52x, k=35 l=14 d=0.003): the workload of the N>1 lines of this script, streamed through THIS one GPU as "
                     "%d batches per step (= bench.py --gpus 1 --workload human), after the timed region" % HUMAN_SHARDS,
             "value": total / ms / 1e6, "unit": "Gbases/s", "ms_per_step": ms, "steps": steps, "total_bases": total,
-            "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": nodes, "node_digest": digest}}
+            "graph": {"minimizers": st["n_minimizers"], "windows": st["n_windows"], "distinct": st["n_distinct"], "nodes": nodes, "node_digest": digest},
+            "shard_vs_oracle": shard_check}
 
 
 def main():
@@ -714,9 +744,12 @@ def main():
         anchor1 = None
         if world == 1 and not routed and not human and not args.plain and not args.no_scale_anchor and (args.genome_mb, args.coverage, args.l, args.density) == (140.0, 50.0, 12, 0.002):
             try:
-                anchor1 = scale_anchor_n1(R, torch, np, device_index, args.minabund)
+                anchor1 = scale_anchor_n1(R, torch, np, device_index, args.minabund, oracle_shard=args.cpu_seconds > 0 and not args.no_anchor_oracle)
             except Exception as ex:      # (a side measurement: the headline above it must not be lost to it — e.g. a device shared with somebody else's 200 GB)
                 anchor1 = {"error": repr(ex)[:300]}
+            if (anchor1.get("shard_vs_oracle") or {}).get("matches_gpu") is False:
+                raise SystemExit("bench.py: one shard of configs[3]: the oracle finds %r, the GPU %r: no line printed" % (
+                    [anchor1["shard_vs_oracle"][f] for f in ("nodes", "windows", "node_digest")], [anchor1["shard_vs_oracle"][f] for f in ("gpu_nodes", "gpu_windows", "gpu_node_digest")]))
             if "graph" in anchor1:
                 w3 = [w for w in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counts.json")))["workloads"] if w.get("workload") == "human" and w["total_bases"] == anchor1["total_bases"]]
                 anchor1["checked_against_recorded_counts"] = bool(w3)

@@ -163,8 +163,9 @@ struct Inflater {
     u32 pend_lit = 0, pend_nlit = 0;            // literals of a packed entry cut by it
     u32 lit[LIT_TAB], dist[DIST_TAB];
     // the first lookup of the fast loop: lit[]'s primary entries, and where a length (its code and its extra bits) and the distance code behind it fit the index together
-    // a PAIR entry that decodes both — one load and one shift per match on the decoder's dependent chain instead of two and two (pack_pairs)
-    u64 fast[1 << LIT_BITS];
+    // a PAIR entry that decodes both — one load and one shift per match on the decoder's dependent chain instead of two and two (pack_pairs).  32-bit entries: with the
+    // 32 KiB of history the decoder's hot set (this table 8 KB, the distance table, the window) stays inside a 48-KB L1
+    u32 fast[1 << LIT_BITS];
     const char* err = nullptr;
 
     void start(const u8* p, size_t n, size_t at) { in = p; in_n = n; ip = at; bb = 0; bc = 0; st = HEADER; last = false; stored_left = 0; pend_len = pend_dist = 0; pend_lit = pend_nlit = 0; err = nullptr; }
@@ -312,27 +313,33 @@ struct Inflater {
         st = HUFF;
         return true;
     }
-    // PAIR entry: bits 0-5 all bits consumed (length code + distance code + distance extra bits), 8-10 = K_PAIR, 11-19 the length, 20-24 bits in front of the distance's
-    // extra bits, 25-28 their number, 32-47 the base distance.  Like pack_literals: the index bits above the length code read as the distance code only when that code does
-    // not reach beyond the index.
+    // PAIR entry: bits 0-5 all bits consumed (length code and extra bits + distance code + distance extra bits), 8-10 = K_PAIR, 11-18 the length - 3, 19-23 the distance
+    // SYMBOL (base and number of extra bits: dist_base / dist_xbits, two small tables read beside the chain), 24-27 the bits in front of the distance's extra bits.
+    // Like pack_literals: the index bits above the length read as the distance code only when that code does not reach beyond the index.
     enum { K_PAIR = 5 };
+    static const u16* dist_base_tab() { static const u16 t[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0, 0}; return t; }
+    static const u8* dist_xbits_tab() { static const u8 t[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0}; return t; }
     void pack_pairs() {
         constexpr u32 PM = (1u << LIT_BITS) - 1, DM = (1u << DIST_BITS) - 1;
         for (u32 i = 0; i <= PM; ++i) {
             const u32 e = lit[i];
-            u64 f = e;
+            u32 f = e;
             if (!(e & LITF) && (e >> 8 & 7) == K_BASE && (e & 63) < (u32)LIT_BITS) {             // a length whose code AND extra bits lie inside the index: it is known here
                 const u32 l1 = e & 63, lcb = e_cb(e);
                 const u32 len = e_value(e) + ((i >> lcb) & ((1u << (l1 - lcb)) - 1));
                 const u32 d = dist[(i >> l1) & DM];                                                   // (bits above the index read as zero)
                 if (!(d & LITF) && (d >> 8 & 7) == K_BASE && l1 + e_cb(d) <= (u32)LIT_BITS) {
-                    const u32 dcb = e_cb(d), dx = (d & 63) - dcb;
-                    f = (u64)(l1 + (d & 63)) | (u64)K_PAIR << 8 | (u64)len << 11 | (u64)(l1 + dcb) << 20 | (u64)dx << 25 | (u64)e_value(d) << 32;
+                    // the distance symbol from the entry's base and extra-bit count: symbols 0..3 have bases 1..4, behind them two symbols per extra-bit count x with
+                    // bases 1 + (2 << x) and 1 + (3 << x) (RFC 1951 3.2.5)
+                    const u32 dx = (d & 63) - e_cb(d), base = e_value(d);
+                    const u32 sym = dx ? 2 * dx + 2 + (((base - 1) >> dx) & 1u) : base - 1;
+                    f = (l1 + (d & 63)) | (u32)K_PAIR << 8 | (len - 3) << 11 | sym << 19 | (l1 + e_cb(d)) << 24;
                 }
             }
             fast[i] = f;
         }
     }
+
     // Primary entries of short literal codes take the literals that follow along: index bits above the first code that decide a second (and a
     // third) literal completely become part of the entry.  Works on a copy of the single-symbol entries, so a packed entry never feeds another.
     void pack_literals() {
@@ -384,6 +391,7 @@ struct Inflater {
             bool eob = false;
             if (in_n >= 32 && out_end >= 320) {
                 const size_t in_fast = in_n - 32, out_fast = out_end - 320;
+                const u16* const dbase = dist_base_tab(); const u8* const dxb = dist_xbits_tab();
                 u64 b = bb; u32 c = bc; size_t i = ip;
 #define GZ_REFILL() do { u64 w_; memcpy(&w_, in + i, 8); b |= w_ << c; i += (63 - c) >> 3; c |= 56; } while (0)
 // (b0: the buffer in front of the entry's bits — the extra bits of a length / distance are read from it beside the chain)
@@ -394,13 +402,14 @@ struct Inflater {
                     GZ_REFILL();
                     u32 e; u64 b0;
                     u32 len; size_t dd;
-                    const u64 f = fast[b & LM];
-                    if (((u32)f & (LITF | 7u << 8)) == (u32)K_PAIR << 8) {      // a short match in ONE lookup: length and distance code together, the distance's extra bits beside the chain
-                        b0 = b; b >>= (f & 63); c -= (u32)f & 63;
-                        len = (u32)f >> 11 & 511;
-                        dd = (size_t)(f >> 32) + (size_t)((b0 >> ((u32)f >> 20 & 31)) & ((1ull << ((u32)f >> 25 & 15)) - 1));
+                    const u32 f = fast[b & LM];
+                    if ((f & (LITF | 7u << 8)) == (u32)K_PAIR << 8) {      // a short match in ONE lookup: length and distance code together, the distance's base and extra bits beside the chain
+                        b0 = b; b >>= (f & 63); c -= f & 63;
+                        len = (f >> 11 & 255) + 3;
+                        const u32 sym = f >> 19 & 31;
+                        dd = (size_t)dbase[sym] + (size_t)((b0 >> (f >> 24 & 15)) & ((1ull << dxb[sym]) - 1));
                     } else {
-                    e = (u32)f;
+                    e = f;
                     if (GZ_IS_SUB(e)) { b >>= LIT_BITS; c -= LIT_BITS; e = lit[e_value(e) + (b & ((1u << e_cb(e)) - 1))]; }
                     b0 = b; b >>= (e & 63); c -= e & 63;
                     if (e & LITF) {                                    // up to three lookups per refill (3 x 15 bits), each up to three literals
@@ -529,6 +538,7 @@ struct GzIn {
     Inflater* inf = nullptr;
     Bytes win; size_t lo = 0, rd = 0, wr = 0;                         // window: history from lo, unread bytes [rd, wr)
     u32 crc = 0; u64 produced = 0;                                     // of the member being decoded
+    size_t mhist = 0;                                                  // fill(): bytes of the member's history that lie right in front of the write position (<= HIST)
     static constexpr size_t HIST = 32768, CHUNK = 1u << 20;
 
     ~GzIn() { delete inf; }
@@ -557,6 +567,7 @@ struct GzIn {
         inf->start(in, n, m.data);
         in_member = true; crc = 0; produced = 0;
         lo = wr;                                                       // a member has no history
+        mhist = 0;
         return true;
     }
     bool end_member() {
@@ -592,6 +603,22 @@ struct GzIn {
             if (got) return true;
             if (in_member) return fail("deflate stream made no progress");      // (chunk room is never zero here)
         }
+    }
+    // The same decoding STRAIGHT into a buffer of the caller's (no window, no copy out of it): base[pos .. end) is filled; base[pos - HIST .. pos) must hold the bytes
+    // delivered last (the caller carries them from buffer to buffer: GzAhead).  false: nothing more comes (end of the data, or an error: `bad`).  The read-ahead thread
+    // spent a tenth of its time copying every inflated byte out of the window (profiles/r06_notes.md).
+    bool fill(u8* base, size_t& pos, size_t end) {
+        while (pos < end) {
+            if (!in_member && !begin_member()) return false;
+            size_t op = pos;
+            if (!inf->run(base, pos - mhist, op, end)) return fail(inf->err);
+            const bool got = op > pos;
+            if (got) { crc = crc32(crc, base + pos, op - pos); produced += op - pos; mhist = std::min<size_t>(HIST, mhist + (op - pos)); }
+            pos = op;
+            if (inf->st == Inflater::END && !inf->pend_len && !end_member()) return false;
+            if (!got && in_member) return fail("deflate stream made no progress");
+        }
+        return true;
     }
     // BGZF: the next blocks (about CHUNK bytes of text per thread), every one inflated on its own into its place
     std::vector<Inflater*> pool;
@@ -662,11 +689,12 @@ struct GzIn {
 struct GzAhead {
     GzIn core;
     int SLOTS = 3; size_t PIECE = 4u << 20;                                        // how far ahead: set_depth before the first read
-    struct Slot { std::unique_ptr<u8[]> data; size_t n = 0; int state = 0; };           // state: 0 free, 1 filled, 2 last (n bytes, then the end), 3 error
+    struct Slot { std::unique_ptr<u8[]> data; size_t n = 0; int state = 0; };           // data: HIST bytes of headroom (the history the decoder looks back into), then the piece;
+                                                                                        // state: 0 free, 1 filled, 2 last (n bytes, then the end), 3 error
     std::vector<Slot> slot;
     void set_depth(int slots, size_t piece) { if (!started) { SLOTS = std::max(2, slots); PIECE = std::max<size_t>(piece, 1u << 16); } }
     std::mutex mu; std::condition_variable cv;
-    std::thread worker; bool stop = false, started = false;
+    std::thread worker; bool stop = false, started = false, direct = true; size_t n_filled = 0;      // direct: decided once, when the worker starts
     int cur = 0; size_t cur_rd = 0; bool finished = false, failed = false;         // consumer side
     ~GzAhead() {
         if (started) { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); worker.join(); }
@@ -674,13 +702,24 @@ struct GzAhead {
     }
     void start() {
         started = true;
+        direct = !(core.is_bgzf && core.threads > 1);
         slot.resize((size_t)SLOTS);
         worker = std::thread([this]() {
             for (int w = 0;; w = (w + 1) % SLOTS) {
                 Slot& s = slot[(size_t)w];
                 { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return stop || s.state == 0; }); if (stop) return; }
-                if (!s.data) s.data.reset(new u8[PIECE]);                       // (not zero-filled: touched when written)
-                const int r = core.read(s.data.get(), PIECE);                   // (short only at the end of the data)
+                constexpr size_t H = GzIn::HIST;
+                if (!s.data) s.data.reset(new u8[H + PIECE]);                   // (not zero-filled: touched when written)
+                int r;
+                if (!direct) r = core.read(s.data.get() + H, PIECE);            // BGZF: groups of blocks inflated by several threads into the core's window
+                else {
+                    // an ordinary stream: decoded straight into the slot; the 32 KiB in front of the piece are the end of the piece before
+                    if (n_filled) { const Slot& pv = slot[(size_t)((w + SLOTS - 1) % SLOTS)]; memcpy(s.data.get(), pv.data.get() + pv.n, H); }
+                    size_t pos = H;
+                    (void)core.fill(s.data.get(), pos, H + PIECE);
+                    r = core.bad ? -1 : (int)(pos - H);
+                }
+                ++n_filled;
                 { std::lock_guard<std::mutex> g(mu); s.n = r > 0 ? (size_t)r : 0; s.state = r < 0 ? 3 : (size_t)r < PIECE ? 2 : 1; }
                 cv.notify_all();
                 if (r < 0 || (size_t)r < PIECE) return;
@@ -696,7 +735,7 @@ struct GzAhead {
             { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return s.state != 0; }); st = s.state; }
             if (st == 3) { failed = true; break; }
             const size_t take = std::min(want - got, s.n - cur_rd);
-            memcpy(dst + got, s.data.get() + cur_rd, take); cur_rd += take; got += take;
+            memcpy(dst + got, s.data.get() + GzIn::HIST + cur_rd, take); cur_rd += take; got += take;
             if (cur_rd == s.n) {
                 if (st == 2) { finished = true; break; }
                 { std::lock_guard<std::mutex> g(mu); s.state = 0; }
