@@ -1,7 +1,8 @@
 """What ONE rank of an eight-rank step computes on its own batch, measured on one GPU (no peers, no exchange): a human shard (19.5 Gbases, k=35 l=14 d=0.003) sketched in two
 chunks, the owner lists for eight ranks, the insertion of the rank's own windows (one in eight, found by insert_windows_kernel itself), the partitioned finalize.  The figures
-feed the time budget of DESIGN.md 3.4; what is missing from a real rank's step is the peers' windows (7/8 of the rank's table: insert_listed_span_kernel at the same rate
-per window) and the exchange itself.
+feed the time budget of DESIGN.md 3.4.  Second part: the RECEIVER side of the same step — the seven peers' shards are sketched one after the other by a second context of this
+process, their owner lists taken, and rank 0 imports every peer's sketch (whole hashes, device-to-device copy standing in for the exchange) with the list of the windows it
+owns and inserts them: what a rank of eight spends on the 7/8 of its table that come from its peers.  Missing from a real rank's step: the exchange itself.
 usage: python scratch/measure_rank_w8.py [world] [genome_mb]"""
 import os
 import sys
@@ -56,3 +57,48 @@ print("W=%d shard %.2f Gbases, %d minimizers, windows per owner max/mean %.3f, o
     W, nb / 1e9, st["n_minimizers"], max(cnt) / (sum(cnt) / W), cnt[0], n_nodes, nw))
 print("ms per stage (host time around each call, best of 3):", {k_: round(v * 1e3, 3) for k_, v in best.items()}, "sum %.3f" % (sum(best.values()) * 1e3))
 print("library timers of the last pass:", {f: round(st[f], 3) for f in ("ms_sketch", "ms_sketch_tile", "ms_insert", "ms_finalize")})
+
+
+# ---- the receiver side: rank 0 inserts its windows of the seven peers' sketches --------------------------------------------------------------------------------
+import ctypes as C
+hip = C.CDLL("libamdhip64.so")
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+peer = R.Mdbg(k, l, d, A, device=0)
+m.reset(0)
+m.ingest_packed_device(words.data_ptr(), do, shard_reads, nb, 0, sketch_only=True)
+m.owner_lists(W)
+m.insert_resident()
+m.sync()
+t_sketch_peer = t_lists_peer = 0.0
+n_listed = 0
+t_commit = 0.0
+for r in range(1, W):
+    db2, do2, nb2 = peer.synth_reads_device(seed=1, genome_len=int(genome_mb * 1e6), n_reads=shard_reads, mean_len=15000, sd_len=1500, min_len=8000, max_len=25000, err_ppm=1000, first_read=r * shard_reads)
+    w2 = torch.zeros((nb2 + 31) // 32 + 2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    assert peer.pack_device(db2, nb2, w2.data_ptr()) == 0
+    peer.reset(0)
+    peer.ingest_packed_device(w2.data_ptr(), do2, shard_reads, nb2, r * shard_reads, sketch_only=True)
+    cnt2, d_lists = peer.owner_lists(W)
+    peer.sync()
+    bi = peer.last_batch()
+    t0 = time.perf_counter()
+    dh, dp, region = m.sketch_reserve(int(bi.n_minimizers))
+    assert hip.hipMemcpy(dh, bi.d_hashes, int(bi.n_minimizers) * 8, 3) == 0                       # (the exchange's stand-in)
+    m.sketch_commit_listed(region, int(bi.n_minimizers), bi.d_read_offsets, int(bi.n_reads), r * shard_reads, d_lists, cnt2[0])      # bucket 0 comes first in the lists
+    m.sync(); t_commit += time.perf_counter() - t0
+    n_listed += cnt2[0]
+    del w2
+m.sync(); t0 = time.perf_counter()
+m.insert_resident()
+m.sync(); t_ins = time.perf_counter() - t0
+t0 = time.perf_counter()
+a, b, nw = m.finalize_begin()
+m.sync(); t_fb = time.perf_counter() - t0
+t0 = time.perf_counter()
+nd, row, ng = m.finalize_end()
+m.sync(); t_fe = time.perf_counter() - t0
+st = m.stats()
+print("receiver: %d listed windows of %d peers inserted in %.3f ms (%.1f M windows/ms; library timer ms_insert %.3f incl. the own batch); finalize over the whole index space (%d bitmap words): "
+      "begin %.3f ms, end %.3f ms (no all-reduce, no position fetch), nodes of this rank %d, distinct keys %d" % (
+          n_listed, W - 1, t_ins * 1e3, n_listed / (t_ins * 1e3) / 1e6, st["ms_insert"], nw, t_fb * 1e3, t_fe * 1e3, int(nd.n), st["n_distinct"]))
