@@ -99,7 +99,6 @@ def test_config3_size_properties():
         got3 = {"minimizers": st3["n_minimizers"], "windows": st3["n_windows"], "distinct": st3["n_distinct"], "nodes": three["n_nodes"]}
         assert all(got3[f] == want["graph"][f] for f in got3)
         # ... and the recorded node digest (what bench.py compares with the oracle's in every run) is the digest of this very table, computed here in plain numpy
-        from oracle import oracle as O
         assert ["0x%016x" % v for v in O.nodes_digest(three["keys"], three["abundance"])] == want["graph"]["node_digest"]
         assert (st["n_minimizers"], st["n_windows"], st["n_distinct"]) == (st3["n_minimizers"], st3["n_windows"], st3["n_distinct"])
         # 5. multi-k on the resident sketches == a fresh context with that k
