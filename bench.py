@@ -38,6 +38,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+# stages of the multi-GPU layer's host timers (mdbg_dist_stage_name), in the library's order
+DIST_STAGES = ("sketch", "wait", "scatter", "commit", "owner_lists", "pack", "allgather", "reserve", "sync", "begin", "insert", "finalize_begin", "finalize_allreduce",
+               "finalize_end", "position_fetch")
+# what ONE rank of eight spends per step on configs[3], measured stage by stage on one GPU (profiles/r06_rank_w8.txt; m = measured, e = estimated: the two
+# collectives have never run here) — printed with every N > 1 line of the human workload so that a result can be set against it the same day
+BUDGET_8_RANKS_HUMAN = {
+    "source": "DESIGN.md 3.4, profiles/r06_rank_w8.txt (one MI355X, a human shard of 19.5 Gbases, the seven peers' sketches made by the same GPU)",
+    "sketch (tile kernel 4.9 + records, scan, gather)": [5.6, "m"], "owner_lists": [1.1, "m"], "pack": [0.9, "m"], "scatter": [0.9, "m"],
+    "insert (own 1.0 + 40.6 M listed windows 4.8)": [5.8, "m"], "finalize_begin": [0.85, "m"], "finalize_allreduce (2 x 90 MB)": [1.3, "e"],
+    "finalize_end incl. position_fetch 0.6": [1.3, "m + e"], "clear + host round trips": [0.9, "m"], "sum": [18.6, "= 4.5 x of 8 against 83.5 ms at N = 1"],
+    "wire": "1.41 GB into a rank per step; chunk 0 travels under chunk 1's tile kernel, chunk 1 under the insertion of chunk 0's arrivals: exposed = `wait`"}
 MULTIK = [10, 15, 20, 25, 30, 35, 40]      # utils/multik:69-78 (k from 10 to 40 in steps of 5)
 HUMAN_SHARDS = 8            # --workload human: the data set is held as the eight shards of BASELINE.json configs[3]
 
@@ -537,6 +548,8 @@ def main():
         runner.times = {}
     # the tile kernel's HIP-event time of EVERY timed step (the context's timers restart with each reset): host-side reads of a struct, no device sync
     tile_acc = {"ms_sketch_tile": 0.0, "n_sketch_tile_launches": 0, "n_sketch_tile_bases": 0}
+    if cdist is not None:
+        cdist.stage_ms(reset=True)          # the layer's host timers per stage restart with the timed region (mdbg_dist_stage_ms)
     t0 = time.perf_counter()
     n_nodes = 0
     for _ in range(args.steps):
@@ -587,7 +600,23 @@ def main():
             b_in = b_out = n_q = 0
         tmax = allreduce([b_in, int(cdist.last_local)], torch.int64, dist.ReduceOp.MAX)
         tsum = allreduce([b_in, int(cdist.last_local)], torch.int64)
-        exchange = {"mode": args.dist_exchange, "chunks_per_step": n_chunks * len(batches), "bytes_in_busiest_rank_per_step": int(tmax[0]), "bytes_in_mean_per_step": float(tsum[0]) / world,
+        # the layer's host time per stage of the timed steps (mdbg_dist_stage_ms): slowest rank per stage and mean over the ranks, per step — what the budget of DESIGN.md
+        # 3.4 is compared with, stage by stage
+        layer = None
+        try:
+            stg, n_rounds = cdist.stage_ms()
+        except Exception as ex:
+            print("bench.py: mdbg_dist_stage_ms failed on rank %d: %r" % (rank, ex), file=sys.stderr)
+            stg, n_rounds = {}, 0
+        names = list(DIST_STAGES)
+        vals = [float(stg.get(nm, 0.0)) / max(1, args.steps) for nm in names]
+        smax = allreduce(vals, torch.float64, dist.ReduceOp.MAX)
+        ssum = allreduce(vals, torch.float64)
+        layer = {"what": "host milliseconds per step and stage of the multi-GPU layer inside the timed region (the stages end in stream syncs or are host work); position_fetch is "
+                         "part of finalize_end; sketch includes the tile kernel of the rank's own chunks",
+                 "rounds_per_step": n_rounds / max(1, args.steps),
+                 "slowest_rank": {nm: round(float(v), 3) for nm, v in zip(names, smax)}, "mean": {nm: round(float(v) / world, 3) for nm, v in zip(names, ssum)}}
+        exchange = {"mode": args.dist_exchange, "layer_ms_per_step": layer, "budget_ms_per_step_8_ranks_human": BUDGET_8_RANKS_HUMAN if args.workload == "human" else None, "chunks_per_step": n_chunks * len(batches), "bytes_in_busiest_rank_per_step": int(tmax[0]), "bytes_in_mean_per_step": float(tsum[0]) / world,
                     "nodes_busiest_rank_over_mean": (float(tmax[1]) * world / float(tsum[1])) if int(tsum[1]) else None,
                     "transport": "host-staged over gloo (--comm host: DRY RUN, not RCCL)" if host_comm else "RCCL (grouped ncclSend / ncclRecv inside libmdbg_hip.so)"}
     anchor = None

@@ -112,6 +112,13 @@ int mdbg_dist_reset(mdbg_dist* d, uint32_t new_k);
  * (sketch rounds + position fetches), and the number of position queries it sent: what a link budget is made of.  Any pointer may be NULL. */
 int mdbg_dist_traffic(mdbg_dist* d, uint64_t* bytes_in, uint64_t* bytes_out, uint64_t* position_queries);
 
+/* Host milliseconds this rank spent per stage of its rounds (sketch, wait for the exchange, scatter, commit, owner lists, pack, size all-gather, reserve, sync, exchange
+ * begin, insertion) and of its finalize calls (begin, bitmap all-reduce, end, of which position fetch), summed since create or the last call with reset != 0; out[i] belongs to
+ * mdbg_dist_stage_name(i) (null from the first index that has no stage).  No counterpart in the reference (one process, src/main.rs:834): bench.py prints these beside the
+ * eight-rank budget of DESIGN.md 3.4 so that a multi-GPU result can be attributed to a stage. */
+int mdbg_dist_stage_ms(mdbg_dist* d, double* out, uint32_t n, uint64_t* n_rounds, int reset);
+const char* mdbg_dist_stage_name(uint32_t i);
+
 #ifdef __cplusplus
 }
 #endif

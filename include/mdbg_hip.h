@@ -400,6 +400,11 @@ typedef struct mdbg_synth_params {
 int mdbg_synth_reads_device(mdbg_ctx* ctx, const mdbg_synth_params* sp, uint64_t first_read,
                             const uint8_t** d_bases, const uint64_t** d_offsets, uint64_t* n_bases);
 
+/* Measurement hook (scratch/measure_rank_w8.py; no counterpart in the reference): milliseconds the multi-GPU layer's sender (out[0]) and receiver (out[1]) spend on the
+ * segments of the batch registered last for `world` ranks; counts / d_lists as mdbg_owner_lists returned them, `skip` = the bucket that ships nothing;
+ * out[2] = list entries, out[3] = hashes packed. */
+int mdbg_dbg_segments_ms(mdbg_ctx* ctx, uint32_t world, uint32_t skip, const uint64_t* counts, const uint32_t* d_lists, double* out);
+
 #ifdef __cplusplus
 }
 #endif

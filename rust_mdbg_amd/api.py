@@ -83,7 +83,7 @@ EXPORTS = ["mdbg_abi_version", "mdbg_build_flags", "mdbg_create", "mdbg_destroy"
            "mdbg_set_partition", "mdbg_sketch_view", "mdbg_ingest_sketch", "mdbg_finalize_begin", "mdbg_finalize_end",
            "mdbg_store_reserve", "mdbg_sketch_reserve", "mdbg_sketch_commit", "mdbg_last_batch", "mdbg_owner_counts", "mdbg_graph_edges", "mdbg_graph_edges_device",
            "mdbg_ingest_batch_packed", "mdbg_ingest_batch_packed_device", "mdbg_sketch_packed_device", "mdbg_pack_device", "mdbg_query_batch", "mdbg_owner_lists", "mdbg_sketch_commit_listed", "mdbg_mark", "mdbg_rewind", "mdbg_set_lmer_filter",
-           "mdbg_release_cached_memory", "mdbg_host_alloc", "mdbg_host_free", "mdbg_host_is_pinned"]
+           "mdbg_release_cached_memory", "mdbg_host_alloc", "mdbg_host_free", "mdbg_host_is_pinned", "mdbg_dbg_segments_ms"]
 
 
 def lib_path():

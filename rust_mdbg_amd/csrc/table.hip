@@ -70,6 +70,24 @@ __device__ inline u64 key_hash_fn(ElemFn elem, u32 k) {
 __device__ inline u64 key_hash_window(const u64* __restrict__ w, u32 k, bool rev) {
     return key_hash_fn([&](u32 j) { return rev ? w[k - 1 - j] : w[j]; }, k);
 }
+// The same hash of a window that lies in HBM, with the window's smallest value as a by-product: sixteen values per round trip (the loop of key_hash_fn fetches four, waits,
+// mixes: nine dependent round trips at k = 35, and the owner check's loop another k) — the per-entry insertion of listed windows spent its time waiting on those chains.
+__device__ inline u64 key_hash_window_hbm(const u64* __restrict__ w, u32 k, bool rev, u64& smallest) {
+    u64 h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
+    const u64* const p = rev ? w + (k - 1) : w;
+    const long st = rev ? -1 : 1;
+    u64 mn = ~0ull;
+    for (u32 j0 = 0; j0 < k; j0 += 16) {
+        u64 v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const u32 j = j0 + t < k ? j0 + t : k - 1; v[t] = p[st * (long)j]; }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (j0 + t < k) { h[t & 3] = (h[t & 3] ^ v[t]) * HMUL; h[t & 3] ^= h[t & 3] >> 29; mn = v[t] < mn ? v[t] : mn; }      // (j0 is a multiple of 4: position j feeds chain j mod 4, as key_hash_fn)
+    }
+    smallest = mn;
+    return fmix64(h[0] ^ rol64(h[1], 17) ^ rol64(h[2], 31) ^ rol64(h[3], 47));
+}
 __device__ inline u64 key_hash_canon(const u64* __restrict__ key, u32 k) {
     return key_hash_fn([&](u32 j) { return key[j]; }, k);
 }
@@ -292,10 +310,15 @@ __device__ inline const u16* span_min_codes(ValueFn value, ValidFn valid, u32 nv
 // streamed in 256-Mbase batches), rare when one launch inserts dozens of copies that race for the claim (the benchmark's 50x batches: no gain there; an
 // experiment that compared 16 bytes of every representative — not exact, never shipped: profiles/r05_x_shortcmp.txt — bounds what links can give at -18 % / -22 %).
 // A lane that fails either way walks on with full comparisons like upsert_slot.
+__device__ inline u64 upsert_wave_h(const TableArgs& T, bool act, u32 li, u64 i, const u64* w, u32 k, bool rev, u64 h, bool& claimed, bool& found);
 __device__ inline u64 upsert_wave(const TableArgs& T, bool act, u32 li, u64 i, const u64* w, u32 k, bool& claimed, bool& found) {
-    const int lane = threadIdx.x & 63;
     bool rev = false; u64 h = 0;
     if (act) { rev = window_reversed(w, k); h = key_hash_window(w, k, rev); }
+    return upsert_wave_h(T, act, li, i, w, k, rev, h, claimed, found);
+}
+// (rev, h: the window's orientation and key hash, computed by the caller)
+__device__ inline u64 upsert_wave_h(const TableArgs& T, bool act, u32 li, u64 i, const u64* w, u32 k, bool rev, u64 h, bool& claimed, bool& found) {
+    const int lane = threadIdx.x & 63;
     const u64 fp = (h >> 34) & T.fp_mask;
     const u64 myword_lo = ((u64)rev << 32) | (u64)(u32)i;
     auto eq = [&](u64 word) { return same_key_window(T.ks, word, w, rev); };
@@ -567,32 +590,78 @@ __device__ inline u32 seg_bucket_of(const SegBuckets& B, u64 j) {
     while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (B.start[mid] <= j) lo = mid; else hi = mid - 1; }
     return lo;
 }
-__global__ __launch_bounds__(256) void seg_add_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, u32* __restrict__ add) {
-    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    u32 a = k;
-    const u32 b = seg_bucket_of(B, j);
-    if (b == B.skip) a = 0;
-    else if (j && B.start[b] != j) { const u32 d = list[j].x - list[j - 1].x; if (d < k) a = d; }
-    add[j] = a;
+// hashes entry j adds (b: its bucket)
+__device__ inline u32 seg_add_of(const uint2* __restrict__ list, u64 j, u32 k, const SegBuckets& B, u32& b) {
+    b = seg_bucket_of(B, j);
+    if (b == B.skip) return 0;
+    if (j && B.start[b] != j) { const u32 d = list[j].x - list[j - 1].x; if (d < k) return d; }
+    return k;
 }
-// pack (to_store = 0): payload[pre[j] ..) <- the last add[j] hashes of window j read from the store; scatter (to_store = 1): the other way
-__global__ __launch_bounds__(256) void seg_copy_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, const u32* __restrict__ add, const u64* __restrict__ pre,
+// The counts are never stored: a pass over the list sums them per SEG_BLOCK entries (tile_scan_top_kernel turns the sums into bases), the copy pass derives them again
+// and scans them inside its workgroup.  (Rounds 3 - 5 wrote a u32 count and a u64 prefix per entry and read both back: 1.98 ms per side for the 46 M entries of a
+// 19.5-Gbase batch at eight ranks, 1.20 with the copy kernel below alone, profiles/r06_rank_w8.txt.)
+constexpr u32 SEG_BLOCK = 4096;          // list entries per workgroup of the segment passes (one base per block: the single-workgroup scan of the bases stays short)
+__global__ __launch_bounds__(256) void seg_sums_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, u64* __restrict__ block_sum) {
+    __shared__ u32 ws[4];
+    u32 v = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_BLOCK / 256; ++q) { const u64 j = (u64)blockIdx.x * SEG_BLOCK + q * 256 + threadIdx.x; u32 b; if (j < n) v += seg_add_of(list, j, k, B, b); }
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = (u64)ws[0] + ws[1] + ws[2] + ws[3];
+}
+// out[b] = first payload index of bucket b, out[B.n] = total (one workgroup per value; block_base: the scanned sums, total: the scan's carry)
+__global__ __launch_bounds__(256) void seg_pick_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, const u64* __restrict__ block_base, const u64* __restrict__ total,
+                                                       u64* __restrict__ out) {
+    __shared__ u32 ws[4];
+    const u32 bq = blockIdx.x;
+    const u64 j1 = bq < B.n ? B.start[bq] : n;
+    if (j1 >= n) { if (threadIdx.x == 0) out[bq] = total[0]; return; }
+    const u64 j0 = j1 - j1 % SEG_BLOCK;
+    u32 v = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_BLOCK / 256; ++q) { const u64 j = j0 + q * 256 + threadIdx.x; u32 b; if (j < j1) v += seg_add_of(list, j, k, B, b); }
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[bq] = block_base[j0 / SEG_BLOCK] + ws[0] + ws[1] + ws[2] + ws[3];
+}
+// pack (to_store = 0): payload[prefix of j ..) <- the last (count of j) hashes of window j read from the store; scatter (to_store = 1): the other way.
+// A workgroup takes SEG_BLOCK consecutive entries, 256 at a time: their parts of the payload are one contiguous stretch, which its threads walk element by element (the entry
+// of an element: a search among the 256 prefixes in LDS) — every load and store of the payload side is coalesced, the store side runs along the windows' runs.  (Rounds
+// 3 - 5: one thread per entry copying its values in a loop: a run's first window copies k values, the others one or two — every wave waited for its run heads, 8 bytes
+// per lane and round trip.)
+__global__ __launch_bounds__(256) void seg_copy_kernel(const uint2* __restrict__ list, u64 n, u32 k, SegBuckets B, const u64* __restrict__ block_base,
                                                        u64* __restrict__ store, u64* __restrict__ payload, u64 payload_n, u32 to_store) {
-    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const u32 a = add[j], b = seg_bucket_of(B, j);
-    if ((u64)list[j].x + k > B.lim[b] || pre[j] + a > payload_n) return;             // (a wrong list: reported by the size check of the round / the count check of the insertion)
-    u64* const h = store + B.base[b] + list[j].x + (k - a);
-    u64* const p = payload + pre[j];
-    if (to_store) for (u32 t = 0; t < a; ++t) h[t] = p[t];
-    else for (u32 t = 0; t < a; ++t) p[t] = h[t];
-}
-__global__ void seg_pick_kernel(const u64* __restrict__ pre, const u32* __restrict__ add, u64 n, SegBuckets B, u64* __restrict__ out) {      // out[b] = first payload index of bucket b, out[n] = total
-    const u32 b = threadIdx.x;
-    if (b > B.n) return;
-    const u64 j = b < B.n ? B.start[b] : n;
-    out[b] = j < n ? pre[j] : (n ? pre[n - 1] + add[n - 1] : 0);
+    __shared__ u32 lpre[256];
+    __shared__ u64 laddr[256];
+    __shared__ u32 tmp[8];
+    u64 P0 = block_base[blockIdx.x];
+#pragma unroll 1
+    for (int q = 0; q < SEG_BLOCK / 256; ++q) {
+        const u64 j = (u64)blockIdx.x * SEG_BLOCK + q * 256 + threadIdx.x;
+        u32 a = 0, b = 0, x = 0;
+        if (j < n) { a = seg_add_of(list, j, k, B, b); x = list[j].x; }
+        u32 T;
+        const u32 excl = block_excl_scan_256(a, tmp, T);          // (its barriers also keep this round's LDS writes behind the last round's reads)
+        u64 at = ~0ull;
+        if (j < n && !((u64)x + k > B.lim[b] || P0 + excl + a > payload_n)) at = B.base[b] + x + (k - a);      // (a wrong list: reported by the size check of the round / the count check of the insertion)
+        lpre[threadIdx.x] = j < n ? excl : 0xFFFFFFFFu;
+        laddr[threadIdx.x] = at;
+        __syncthreads();
+        for (u32 e = threadIdx.x; e < T; e += 256) {
+            u32 lo = 0, hi = 255;                      // the last entry whose prefix is <= e (entries that add nothing share their prefix with the one behind them)
+#pragma unroll
+            for (int st = 0; st < 8; ++st) { const u32 mid = (lo + hi + 1) >> 1; if (lpre[mid] <= e) lo = mid; else hi = mid - 1; }
+            const u64 src = laddr[lo];
+            if (src == ~0ull) continue;
+            u64* const h = store + src + (e - lpre[lo]);
+            u64* const pp = payload + P0 + e;
+            if (to_store) *h = *pp; else *pp = *h;
+        }
+        P0 += T;
+    }
 }
 __device__ inline bool listed_check(u64 j) { return (((u32)j * 0x9E3779B1u) >> 28) == 0; }      // one list entry in 16
 // inserts exactly the listed windows of the batch whose minimizers start at m0 (keys are read from the resident store)
@@ -639,6 +708,64 @@ __global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T,
     if (claimed || s == ~0ull) return;
     atomicAdd(&T.tab[s].count, 1u);
     push_ordinal(T, s, ord);
+}
+// The per-entry insertion since round 6.  insert_listed_windows_kernel above waits on chains of dependent loads: four values per round trip of its hash loop (nine round
+// trips at k = 35), k more for the owner check that one lane in 16 makes (and every wave has such a lane): ~90 us per workgroup at full occupancy, 5.4 M windows/ms on a
+// rank of eight (profiles/r06_rank_w8.txt) against 11 M for the local kernel, whose values lie in LDS.  Here a window is read ONCE, sixteen values per round trip: hash
+// and smallest value together (so EVERY entry's owner is re-derived, not one in 16), and the walk is upsert_wave's: a bucket of the owner lists is sorted by window start
+// and a rank's windows come in runs, so neighbouring lanes hold neighbouring windows, confirm each other as links, and their loads fall into the same cache lines.
+__global__ __launch_bounds__(256) void insert_listed_entries_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
+                                                                    u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
+                                                                    u32* __restrict__ cap_err, const ListedBatch* __restrict__ multi, u32 n_multi) {
+    if (cap_err[1]) return;
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 k = T.ks.k;
+    bool ok = j < n;
+    u64 i = 0, rs = 0; u32 slot = 0;
+    u64 jl = j;
+    if (multi) {
+        // the batch of the wave's FIRST entry, searched once per wave on scalar loads; a lane behind the next batch's start (a wave across a boundary) searches for itself
+        const u64 jw0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+        u64 jw = ((u64)__builtin_amdgcn_readfirstlane((u32)(jw0 >> 32)) << 32) | (u64)__builtin_amdgcn_readfirstlane((u32)jw0);
+        if (jw >= n) jw = n - 1;
+        u32 lo = 0, hi = n_multi - 1;
+        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (multi[mid].start <= jw) lo = mid; else hi = mid - 1; }
+        if (ok && multi[lo + 1].start <= j) {          // (multi[n_multi] is the closing entry: start = n)
+            hi = n_multi - 1;
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (multi[mid].start <= j) lo = mid; else hi = mid - 1; }
+        }
+        const ListedBatch b = multi[lo];
+        m0 = b.m0; m1 = b.m1; list = b.list; slot0 = b.slot0; n_reads = b.n_reads; first_ordinal = b.first_ordinal; jl = j - b.start;
+    }
+    if (ok) {
+        const uint2 e = ((const uint2*)list)[jl];
+        i = m0 + e.x; slot = slot0 + e.y; ok = e.y < n_reads && i + k <= m1;
+    }
+    const u64* const w = mh + i;
+    bool rev = false; u64 h = 0;
+    if (ok) {                                      // a wrong list is caught by the count check
+        // one round trip: the read's offsets and the window's two ends (the orientation is decided by them unless they are equal)
+        const u64 w_first = w[0], w_last = w[k - 1];
+        rs = roff[slot]; const u64 re = roff[slot + 1];
+        ok = i >= rs && re - rs > k && i + k <= re;
+        if (ok) {
+            rev = w_first != w_last ? w_first > w_last : window_reversed(w, k);
+            u64 smallest;
+            h = key_hash_window_hbm(w, k, rev, smallest);
+            ok = owner_of_min(smallest, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank;      // a sender that disagrees about the owner function: the count check fails
+        }
+    }
+    wave_count_add(ok, T.own_inserted);
+    const u64 win = i - rs;
+    if (ok && win > WIN_MASK) { *cap_err = 1; ok = false; }
+    const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
+    bool claimed, found;
+    const u64 s = upsert_wave_h(T, ok, (u32)i, i, w, k, rev, h, claimed, found);      // (li = the store index: consecutive windows of a read are consecutive indices; no lane leaves early)
+    if (claimed) { mread[i] = slot; if (T.claim) T.claim[i] = 1; }      // (the batch's bytes of the claim map were zeroed in front of the launch: api.inc, insert_resident_impl)
+    if (found) {
+        atomicAdd(&T.tab[s].count, 1u);
+        push_ordinal(T, s, ord);
+    }
 }
 // The lists are written span by span (owner_list_write_kernel: the entries of one OWNL_SPAN of window starts are contiguous, in any order
 // inside it), so the receiver can work span-wise too: seg[q] = first list entry of span q or later (seg[] is pre-filled with n).
@@ -717,6 +844,12 @@ void launch_owner_list_write(const u64* mh, const u32* mread, const u64* roff, u
     if (i1 > i0) hipLaunchKernelGGL(owner_list_write_kernel, dim3((unsigned)((i1 - i0 + OWNL_SPAN - 1) / OWNL_SPAN)), dim3(256), 0, s, mh, mread, roff, i0, i1, k, world, thr, slot0, blk_off, bases, list, owner_of, direct_owner, direct_dst);
 }
 // list: n pairs (window start, read), seg: launch_list_segments of it
+// (95 registers = five waves per SIMD; forced to six or eight — 12 / 84 bytes of scratch — the kernel is slower: 5.87 / 7.00 against 5.48 ms per 46 M windows)
+static void launch_listed_entries(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
+                                  u32* cap_err, const ListedBatch* multi, u32 n_multi, hipStream_t s) {
+    hipLaunchKernelGGL(insert_listed_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err, multi, n_multi);
+}
+static bool listed_old_kernel() { static const bool v = getenv("MDBG_LISTED_OLD") && atoi(getenv("MDBG_LISTED_OLD")); return v; }      // A/B: the per-entry kernel of rounds 3 - 5
 void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, const u32* seg, u64 n, u32 slot0,
                           u32 n_reads, u64 first_ordinal, u32* cap_err, hipStream_t s) {
     if (!n) return;
@@ -728,9 +861,11 @@ void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u
     const bool sparse = n < (u64)owner_list_spans(m1 - m0) * per_span_min;
     if (seg && lds <= 64 * 1024 && !sparse)
         hipLaunchKernelGGL(insert_listed_span_kernel, dim3(owner_list_spans(m1 - m0)), dim3(256), lds, s, T, mh, mread, roff, m0, m1, list, seg, n, slot0, n_reads, first_ordinal, cap_err);
-    else       // very long k: the span does not fit the default LDS window, every window reads its values from HBM
+    else if (listed_old_kernel())
         hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err,
                            (const ListedBatch*)nullptr, 0u);
+    else       // (also very long k: the span does not fit the default LDS window, every window reads its values from HBM)
+        launch_listed_entries(T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err, nullptr, 0u, s);
 }
 // true: launch_insert_listed would take the per-entry kernel for this batch (then several such batches can share one launch, launch_insert_listed_multi)
 bool listed_is_sparse(const TableArgs& T, u64 m0, u64 m1, u64 n) {
@@ -740,8 +875,10 @@ bool listed_is_sparse(const TableArgs& T, u64 m0, u64 m1, u64 n) {
 }
 void launch_insert_listed_multi(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, const ListedBatch* d_batches, u32 n_batches, u64 total, u32* cap_err, hipStream_t s) {
     if (!total) return;
-    hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, 0ull, 0ull, (const u32*)nullptr, total, 0u, 0u, 0ull, cap_err,
-                       d_batches, n_batches);
+    if (listed_old_kernel())
+        hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, 0ull, 0ull, (const u32*)nullptr, total, 0u, 0u, 0ull, cap_err,
+                           d_batches, n_batches);
+    else launch_listed_entries(T, mh, mread, roff, 0ull, 0ull, nullptr, total, 0u, 0u, 0ull, cap_err, d_batches, n_batches, s);
 }
 
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch
@@ -1122,30 +1259,43 @@ void launch_bytes_to_bits(const u8* by0, const u8* by1, u64 n_words, u64 n_bits,
     if (n_words) hipLaunchKernelGGL(bytes_to_bits_kernel, dim3(nb), dim3(1024), 0, s, by0, by1, n_words, n_bits, bm0, bm1, block_sum, nb);
 }
 // F.claims == 2: the claim map is indexed by STORE index, the bitmaps by dense ordered index (the batches in first-ordinal order): one wave per 64 dense indices — lane l reads
-// the byte of dense index 64 w + l at its batch's place in the store (consecutive lanes read consecutive bytes except across a batch boundary), two ballots are the two
-// bitmap words.  ~1 byte read per resident minimizer; the per-block popcounts are left to popc_block_kernel (a partitioned table merges the bitmaps over the ranks first).
+// its bytes at its batch's place in the store (consecutive lanes read consecutive bytes except across a batch boundary).  ~1 byte read per resident minimizer; the per-block popcounts are left to popc_block_kernel (a partitioned table merges the bitmaps over the ranks first).
 __global__ __launch_bounds__(256) void claims_to_bits_kernel(FinArgs F, u64 n_words, u64 n_bits, u64* __restrict__ bm0, u64* __restrict__ bm1) {
-    const u32 lane = threadIdx.x & 63;
-    const u64 w0 = ((u64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;          // 16 words per wave
+    // a lane takes EIGHT dense indices (one byte of either bitmap): one 8-byte load where the eight lie in one batch (all but the groups across a batch boundary), its eight
+    // bits 0 and eight bits 1 gathered by a multiplication, stored as a byte: a wave reads 512 bytes and writes 64 + 64 per round.  (Until round 6 a lane read one byte and
+    // two ballots made the words: 64 bytes per wave and load, 1.2 ms of a rank-of-eight's finalize, which runs over the WHOLE index space.)
     u32 bi = 0; u64 lo = 0, hi = 0, m0 = 0;                                    // the batch [lo, hi) of dense indices the lane looked at last
-    for (u64 w = w0; w < w0 + 16 && w < n_words; ++w) {
-        const u64 D = 64 * w + lane;
-        u8 b = 0;
+    auto locate = [&](u64 D) {
+        if (D >= lo && D < hi) return;
+        u32 a = 0, z = F.bt.n - 1;
+        while (a < z) { const u32 mid = a + ((z - a + 1) >> 1); if (F.bt.rank_base[mid] <= D) a = mid; else z = mid - 1; }
+        bi = a; lo = F.bt.rank_base[bi]; hi = bi + 1 < F.bt.n ? F.bt.rank_base[bi + 1] : n_bits; m0 = F.bt.m0[bi];
+        // (batches without a minimizer share their rank base with the batch behind them: the search ends on the last of them, whose range [lo, hi) holds D)
+    };
+    const u64 n_groups = n_words * 8;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const u64 g = ((u64)blockIdx.x * 4 + u) * 256 + threadIdx.x;          // (consecutive lanes: consecutive groups)
+        if (g >= n_groups) break;
+        const u64 D = 8 * g;
+        u64 x = 0;
         if (D < n_bits) {
-            if (D < lo || D >= hi) {
-                u32 a = 0, z = F.bt.n - 1;
-                while (a < z) { const u32 mid = a + ((z - a + 1) >> 1); if (F.bt.rank_base[mid] <= D) a = mid; else z = mid - 1; }
-                bi = a; lo = F.bt.rank_base[bi]; hi = bi + 1 < F.bt.n ? F.bt.rank_base[bi + 1] : n_bits; m0 = F.bt.m0[bi];
-                // (batches without a minimizer share their rank base with the batch behind them: the search ends on the last of them, whose range [lo, hi) holds D)
+            locate(D);
+            if (D + 8 <= hi) {                          // eight bytes at any alignment: the two aligned words around them (the second one is the next lane's first: a hit)
+                const u8* const p = F.by_first + m0 + (D - lo);
+                const u32 o = (u32)((uintptr_t)p & 7u) * 8u;
+                const u64* const q = (const u64*)(p - (o >> 3));
+                x = q[0];
+                if (o) x = (x >> o) | (q[1] << (64u - o));
             }
-            b = F.by_first[m0 + (D - lo)];
+            else for (u32 t = 0; t < 8 && D + t < n_bits; ++t) { locate(D + t); x |= (u64)F.by_first[m0 + (D + t - lo)] << (8 * t); }
         }
-        const u64 w_first = __ballot(b & 1), w_solid = __ballot(b & 2);
-        if (lane == 0) { bm0[w] = w_first; bm1[w] = w_solid; }
+        ((u8*)bm0)[g] = (u8)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+        ((u8*)bm1)[g] = (u8)((((x >> 1) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
     }
 }
 void launch_claims_to_bits(const FinArgs& F, u64 n_words, u64 n_bits, u64* bm0, u64* bm1, hipStream_t s) {
-    if (n_words) hipLaunchKernelGGL(claims_to_bits_kernel, dim3((unsigned)((n_words + 63) / 64)), dim3(256), 0, s, F, n_words, n_bits, bm0, bm1);
+    if (n_words) hipLaunchKernelGGL(claims_to_bits_kernel, dim3((unsigned)((n_words * 8 + 1023) / 1024)), dim3(256), 0, s, F, n_words, n_bits, bm0, bm1);
 }
 // row of every listed solid slot (rank of its first sighting among the solid ones) -> order[row] = slot
 __global__ __launch_bounds__(256) void fin_order_kernel(FinArgs F, u64 n_solid, u64* __restrict__ order) {
@@ -1752,14 +1902,17 @@ void launch_wrap_scan_listed(const TableArgs& T, const u64* mh, const u64* roff,
                              const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {
     if (n) hipLaunchKernelGGL(wrap_scan_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, w_start, w_fill, occ);
 }
-void launch_seg_add(const u32* list, u64 n, u32 k, const SegBuckets& B, u32* add, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(seg_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint2*)list, n, k, B, add);
+// counts and prefix of the list's segments: scan_tmp[n / SEG_BLOCK + 2] <- payload index of every SEG_BLOCK-entry block's first entry, carry[0] (zero on entry) <- total,
+// picks[B.n + 1] <- first payload index of every bucket and the total.  launch_seg_copy then packs / scatters with scan_tmp.
+void launch_seg_prefix(const u32* list, u64 n, u32 k, const SegBuckets& B, u64* scan_tmp, u64* carry, u64* picks, hipStream_t s) {
+    if (!n) return;
+    const u32 nb = (u32)((n + SEG_BLOCK - 1) / SEG_BLOCK);
+    hipLaunchKernelGGL(seg_sums_kernel, dim3(nb), dim3(256), 0, s, (const uint2*)list, n, k, B, scan_tmp);
+    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(256), 0, s, nb, scan_tmp, carry);
+    hipLaunchKernelGGL(seg_pick_kernel, dim3(B.n + 1), dim3(256), 0, s, (const uint2*)list, n, k, B, scan_tmp, carry, picks);
 }
-void launch_seg_copy(const u32* list, u64 n, u32 k, const SegBuckets& B, const u32* add, const u64* pre, u64* store, u64* payload, u64 payload_n, bool to_store, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(seg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint2*)list, n, k, B, add, pre, store, payload, payload_n, to_store ? 1u : 0u);
-}
-void launch_seg_pick(const u64* pre, const u32* add, u64 n, const SegBuckets& B, u64* out, hipStream_t s) {
-    hipLaunchKernelGGL(seg_pick_kernel, dim3(1), dim3(128), 0, s, pre, add, n, B, out);
+void launch_seg_copy(const u32* list, u64 n, u32 k, const SegBuckets& B, const u64* scan_tmp, u64* store, u64* payload, u64 payload_n, bool to_store, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(seg_copy_kernel, dim3((unsigned)((n + SEG_BLOCK - 1) / SEG_BLOCK)), dim3(256), 0, s, (const uint2*)list, n, k, B, scan_tmp, store, payload, payload_n, to_store ? 1u : 0u);
 }
 void launch_wrap_scan_records(const TableArgs& T, u64 n_records, const u32* w_start, u32* w_fill, u64* occ, hipStream_t s) {
     if (n_records) hipLaunchKernelGGL(wrap_scan_records_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, T, n_records, w_start, w_fill, occ);

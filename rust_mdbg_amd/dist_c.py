@@ -141,6 +141,8 @@ class DistMdbg:
         L.mdbg_dist_set_exchange.argtypes = [C.c_void_p, C.c_uint32]
         L.mdbg_dist_destroy.argtypes = [C.c_void_p]
         L.mdbg_dist_traffic.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mdbg_dist_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint64), C.c_int]
+        L.mdbg_dist_stage_name.argtypes = [C.c_uint32]; L.mdbg_dist_stage_name.restype = C.c_char_p
         self.comm = self.rccl = self.host_comm = None
         if transport == "host":
             self.host_comm = HostStagedComm(dist, rank, world)
@@ -201,6 +203,18 @@ class DistMdbg:
         a, b, q = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.L.mdbg_dist_traffic(self.h, C.byref(a), C.byref(b), C.byref(q)))
         return int(a.value), int(b.value), int(q.value)
+
+    def stage_ms(self, reset=False):
+        """-> ({stage: host ms of this rank since create / the last reset}, rounds)"""
+        out = (C.c_double * 32)(); nr = C.c_uint64()
+        self._chk(self.L.mdbg_dist_stage_ms(self.h, out, 32, C.byref(nr), 1 if reset else 0))
+        d = {}
+        for i in range(32):
+            nm = self.L.mdbg_dist_stage_name(i)
+            if not nm:
+                break
+            d[nm.decode()] = float(out[i])
+        return d, int(nr.value)
 
     def close(self):
         if self.h:

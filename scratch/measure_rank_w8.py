@@ -59,20 +59,25 @@ print("ms per stage (host time around each call, best of 3):", {k_: round(v * 1e
 print("library timers of the last pass:", {f: round(st[f], 3) for f in ("ms_sketch", "ms_sketch_tile", "ms_insert", "ms_finalize")})
 
 
-# ---- the receiver side: rank 0 inserts its windows of the seven peers' sketches --------------------------------------------------------------------------------
+# ---- the segments of this batch: what the layer's sender packs for seven peers, and what a receiver scatters (the same volume comes in as goes out) --------------------
 import ctypes as C
+m.reset(0)
+m.ingest_packed_device(words.data_ptr(), do, shard_reads, nb, 0, sketch_only=True)
+cnt, d_lists = m.owner_lists(W)
+out = (C.c_double * 4)()
+cc = (C.c_uint64 * W)(*cnt)
+m.L.mdbg_dbg_segments_ms.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_double)]
+rc = m.L.mdbg_dbg_segments_ms(m.h, W, 0, cc, d_lists, out)
+print("segments [MDBG_SEG_OLD=%s]: rc %d, %d list entries (own bucket of %d ships nothing), %d hashes packed (%.2f per shipped window, %.1f %% of the sketch): sender %.3f ms (counts, prefix, "
+      "one host round trip, pack), receiver %.3f ms (counts, prefix, scatter)" % (os.environ.get("MDBG_SEG_OLD", "-"), rc, int(out[2]), cnt[0], int(out[3]), out[3] / max(1, out[2] - cnt[0]),
+                                                                                 100.0 * out[3] / st["n_minimizers"], out[0], out[1]), flush=True)
+
+# ---- the receiver side: rank 0 inserts its windows of the seven peers' sketches --------------------------------------------------------------------------------
 hip = C.CDLL("libamdhip64.so")
 hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 peer = R.Mdbg(k, l, d, A, device=0)
-m.reset(0)
-m.ingest_packed_device(words.data_ptr(), do, shard_reads, nb, 0, sketch_only=True)
-m.owner_lists(W)
-m.insert_resident()
-m.sync()
-t_sketch_peer = t_lists_peer = 0.0
-n_listed = 0
-t_commit = 0.0
-for r in range(1, W):
+peers = []
+for r in range(1, W):          # the peers' sketches and lists are made once and kept (device copies of what the exchange would deliver)
     db2, do2, nb2 = peer.synth_reads_device(seed=1, genome_len=int(genome_mb * 1e6), n_reads=shard_reads, mean_len=15000, sd_len=1500, min_len=8000, max_len=25000, err_ppm=1000, first_read=r * shard_reads)
     w2 = torch.zeros((nb2 + 31) // 32 + 2, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
@@ -82,23 +87,43 @@ for r in range(1, W):
     cnt2, d_lists = peer.owner_lists(W)
     peer.sync()
     bi = peer.last_batch()
+    nm, nr = int(bi.n_minimizers), int(bi.n_reads)
+    hs = torch.empty(nm, dtype=torch.int64, device="cuda"); ro = torch.empty(nr + 1, dtype=torch.int64, device="cuda"); ls = torch.empty(cnt2[0], dtype=torch.int64, device="cuda")
+    assert hip.hipMemcpy(hs.data_ptr(), bi.d_hashes, nm * 8, 3) == 0
+    assert hip.hipMemcpy(ro.data_ptr(), bi.d_read_offsets, (nr + 1) * 8, 3) == 0
+    assert hip.hipMemcpy(ls.data_ptr(), d_lists, cnt2[0] * 8, 3) == 0              # bucket 0 comes first in the lists
+    peers.append((r, nm, nr, hs, ro, ls, cnt2[0]))
+    del w2, db2, do2
+peer.close()
+
+
+def receive():
+    m.reset(0)
+    m.ingest_packed_device(words.data_ptr(), do, shard_reads, nb, 0, sketch_only=True)
+    m.owner_lists(W)
+    n_listed = 0
+    for r, nm, nr, hs, ro, ls, c0 in peers:
+        dh, dp, region = m.sketch_reserve(nm)
+        assert hip.hipMemcpy(dh, hs.data_ptr(), nm * 8, 3) == 0                       # (the exchange's stand-in)
+        m.sketch_commit_listed(region, nm, ro.data_ptr(), nr, r * shard_reads, ls.data_ptr(), c0)
+        n_listed += c0
+    hip.hipDeviceSynchronize()                                                     # (hipMemcpy device-to-device returns before the copy has run: without this the copies ran under the insertion)
+    m.sync(); t0 = time.perf_counter()
+    m.insert_resident()                                                            # the rank's own windows and the listed ones in one round, as in a step of the multi-GPU layer
+    m.sync(); t_ins = time.perf_counter() - t0
     t0 = time.perf_counter()
-    dh, dp, region = m.sketch_reserve(int(bi.n_minimizers))
-    assert hip.hipMemcpy(dh, bi.d_hashes, int(bi.n_minimizers) * 8, 3) == 0                       # (the exchange's stand-in)
-    m.sketch_commit_listed(region, int(bi.n_minimizers), bi.d_read_offsets, int(bi.n_reads), r * shard_reads, d_lists, cnt2[0])      # bucket 0 comes first in the lists
-    m.sync(); t_commit += time.perf_counter() - t0
-    n_listed += cnt2[0]
-    del w2
-m.sync(); t0 = time.perf_counter()
-m.insert_resident()
-m.sync(); t_ins = time.perf_counter() - t0
-t0 = time.perf_counter()
-a, b, nw = m.finalize_begin()
-m.sync(); t_fb = time.perf_counter() - t0
-t0 = time.perf_counter()
-nd, row, ng = m.finalize_end()
-m.sync(); t_fe = time.perf_counter() - t0
-st = m.stats()
-print("receiver: %d listed windows of %d peers inserted in %.3f ms (%.1f M windows/ms; library timer ms_insert %.3f incl. the own batch); finalize over the whole index space (%d bitmap words): "
-      "begin %.3f ms, end %.3f ms (no all-reduce, no position fetch), nodes of this rank %d, distinct keys %d" % (
-          n_listed, W - 1, t_ins * 1e3, n_listed / (t_ins * 1e3) / 1e6, st["ms_insert"], nw, t_fb * 1e3, t_fe * 1e3, int(nd.n), st["n_distinct"]))
+    a, b, nw = m.finalize_begin()
+    m.sync(); t_fb = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nd, row, ng = m.finalize_end()
+    m.sync(); t_fe = time.perf_counter() - t0
+    return n_listed, t_ins, t_fb, t_fe, nw, int(nd.n)
+
+
+for rep in range(3):               # (the first pass grows the table; the later ones find it large enough, as every step after a job's first does)
+    n_listed, t_ins, t_fb, t_fe, nw, n_nodes = receive()
+    st = m.stats()
+    print("receiver pass %d [MDBG_LISTED_SPAN_MIN=%s MDBG_LISTED_WAVE=%s]: own windows + %d listed windows of %d peers inserted in %.3f ms (library timer ms_insert %.3f); finalize over the whole "
+          "index space (%d bitmap words): begin %.3f ms, end %.3f ms (no all-reduce, no position fetch), nodes of this rank %d, distinct keys %d" % (
+              rep, os.environ.get("MDBG_LISTED_SPAN_MIN", "-"), os.environ.get("MDBG_LISTED_WAVE", "-"), n_listed, W - 1, t_ins * 1e3, st["ms_insert"], nw, t_fb * 1e3, t_fe * 1e3, n_nodes,
+              st["n_distinct"]), flush=True)
