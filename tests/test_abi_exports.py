@@ -123,7 +123,8 @@ def test_dist_header_symbols_and_c_example_link(tmp_path):
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
     syms = sorted(set(re.findall(r"\b(mdbg_(?:dist|comm)_[a-z_0-9]+)\s*\(", h)))
     assert syms == ["mdbg_comm_rccl", "mdbg_dist_create", "mdbg_dist_ctx", "mdbg_dist_destroy", "mdbg_dist_finalize", "mdbg_dist_ingest_batch_device",
-                    "mdbg_dist_ingest_batch_packed_device", "mdbg_dist_reset", "mdbg_dist_set_exchange", "mdbg_dist_set_pipeline", "mdbg_dist_traffic"]
+                    "mdbg_dist_ingest_batch_packed_device", "mdbg_dist_reset", "mdbg_dist_set_exchange", "mdbg_dist_set_pipeline", "mdbg_dist_stage_ms", "mdbg_dist_stage_name",
+                    "mdbg_dist_traffic"]
     L = api.load_library()
     for s in syms:
         assert hasattr(L, s), s
