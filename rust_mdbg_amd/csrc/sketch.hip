@@ -749,97 +749,153 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         if (n_rs <= RS_CAP) { for (u32 i = tid; i < n_rs; i += TT) mark_start(i ? (int64_t)S.rs_rel[i] : S.rs0); }
         else for (u32 r = rl + tid; r <= rh_ && r < a.n_reads; r += TT) mark_start((int64_t)a.offsets[r] - raw0);
         tile_sync<NW>();
-        // One thread per stretch of the owned END positions [e_lo, H).  Stretches are whole numbers of 32 positions and the look-back is a
-        // multiple of 32, and every lane runs the same number of iterations (positions in front of the stream or behind the stretch are
-        // idle ones): the iteration index `it` and (p mod 32) are the same in every lane, so word loads, bitmap flushes and the slot of
-        // the window that an iteration writes are uniform.  The window of the last w s-mer hashes lives in WMAX registers, slot =
-        // it mod WMAX (the loop is unrolled WMAX times: static register indices, nothing is shifted), and the rules of the reference's deque
-        // are evaluated branch-free from the window's minimum and the age of its rightmost occurrence:
-        //   the tracked s-mer leaves -> rightmost minimum (the rescan from the back);  a strictly smaller s-mer arrives -> the new one;
-        //   else unchanged;   first full window of a read -> leftmost minimum;   while the state is not known to be the reference's: a
-        //   unique minimum -> tracked = it, whatever happened before (the leftmost occurrence is only looked for in these two cases).
-        //   (A first version kept the hashes in an LDS ring and branched like the reference: every rare branch was taken by SOME lane
-        //   in nearly every iteration — 90 Gbases/s at 2 workgroups per CU, bound by LDS latency.)
-        const u32 n_own = H > e_lo ? H - e_lo : 0u, R = ((n_own + TT - 1) / TT + 31u) & ~31u;
-        const u32 a0 = e_lo + (u32)tid * R < H ? e_lo + (u32)tid * R : H, b0 = a0 + R < H ? a0 + R : H;
+        // The machine as a SCAN (round 6; until round 5 one thread ran the reference's machine over a stretch of ~94 positions after 32 positions of
+        // look-back: ~280 VALU per window).  The tracked s-mer of a window is always an occurrence of the window's smallest hash; which one, among
+        // equal ones, is history: T(p) = T(p - 1) while that s-mer is still inside the window, else the RIGHTMOST occurrence (the rescan from the back);
+        // a window whose minimum is UNIQUE pins T whatever happened before (a strictly smaller arrival is such a window), and so does a read's first
+        // full window (the LEFTMOST occurrence).  So T(p) is a function of T(p - 1) that is CONSTANT at every anchor (unique minimum, first window) and
+        // at every window without a full l-mer behind it — with s = 4 nine windows in ten are anchors.  A lane takes G consecutive windows: it builds
+        // the w + G - 1 s-mer hashes it needs from the bit planes itself (registers, nothing staged), finds every window's rightmost and leftmost minimum
+        // (one unsigned min each over hash << 6 | index), runs the G steps once without a predecessor, and takes its predecessor's result from the lane
+        // below (a lane without an anchor — rare — waits for it: a fixed-point loop over the wave, usually zero rounds).  A wave owns a contiguous
+        // quarter of the tile's positions and walks it in rounds of 64 G positions, the carry from round to round in a scalar; one look-back round in
+        // front of the quarter warms the carry up.  A window of an owned position whose state is still unknown then (no anchor in 512 positions: a
+        // tandem repeat) sends the tile to the generic machine.
+        constexpr int SG = 8;                              // windows per lane and round
+        constexpr int NH = WMAX + SG - 1;                  // s-mer hashes of a lane: END positions p0 - (w - 1) .. p0 + SG - 1
+        constexpr int32_t UNK = INT32_MIN;
         // s <= 4: the s-mer hash comes from a table (second half of t3: 256 x u16, filled here)
         const bool use_lut = sm != 0 && sm <= 4;
         u16* const lut = (u16*)S_t3 + 256;
-        const u32 e_lo_s = (u32)__builtin_amdgcn_readfirstlane((int)e_lo);      // a0 = e_lo + tid * R, R and the look-back multiples of 32: p mod 32 = (e_lo + it) mod 32 in every lane
         if (use_lut) lut[tid] = (u16)sync_hash32((u32)tid & smask, smask);
         tile_sync<NW>();
         {
-            // first look-back: l positions until every s-mer of the window comes from bases behind the start, and some windows to meet a unique
-            // minimum in (with s = 4 about nine windows in ten have one)
-            for (u32 look = (l + 16u + 31u) & ~31u;; look *= 4) {
-                const int32_t q0 = (int32_t)a0 - (int32_t)look;        // may lie in front of the stream: idle iterations
-                bool conv = false, restart = false, mine = false;      // conv: the machine's state equals the reference's; mine: I reached my stretch without it
-                u32 xs0 = 0, xs1 = 0, lp = 0, cnt = 0, warm = 0, ta = 0, mvp = 0;
-                u32 win[WMAX];
+            const u32 n_own = H > e_lo ? H - e_lo : 0u;
+            const u32 Qw = (((n_own + NW - 1) / NW) + (64u * SG - 1u)) & ~(64u * SG - 1u);      // owned positions per wave: whole rounds
+            const u32 wv_s = (u32)__builtin_amdgcn_readfirstlane(wv);
+            const u32 Awv = e_lo + wv_s * Qw, Bwv = Awv + Qw < H ? Awv + Qw : H;                   // the wave's owned positions [Awv, Bwv)
+            int32_t carry = UNK;
+            bool need_slow = false;
+            auto word64 = [](u32 x, u32 y, u32 z, u32 r) -> u64 {      // 64 positions from bit r of word x on (MSB first)
+                const u32 hi = r ? (x << r) | (y >> (32u - r)) : x, lo = r ? (y << r) | (z >> (32u - r)) : y;
+                return (u64)hi << 32 | lo;
+            };
+            if (Awv < H) for (int32_t rd = -1; (int64_t)Awv + (int64_t)rd * (64 * SG) < (int64_t)Bwv; ++rd) {
+                const int32_t p0 = (int32_t)Awv + rd * (64 * SG) + lane * SG;       // my windows end at p0 .. p0 + SG - 1
+                const int32_t qb = p0 - (int32_t)(l - 1);                            // the first base I look at
+                const int32_t wi = qb >> 5; const u32 rr = (u32)qb & 31u;           // (arithmetic shift: floor, also in front of the stream)
+                u32 pl1[3], pl0[3], stw[3];
 #pragma unroll
-                for (int j = 0; j < WMAX; ++j) win[j] = 0;
-                u32 P0 = 0, P1 = 0, ST = 0, cbits = 0;
-                const u32 n_it = look + R;                             // the same for every lane
-                for (u32 it0 = 0; it0 < n_it && !restart; it0 += WMAX) {
-#pragma unroll
-                    for (int u = 0; u < WMAX; ++u) {
-                        const u32 it = it0 + (u32)u;
-                        const int32_t p = q0 + (int32_t)it;
-                        const bool live = p >= 0 && (u32)p < b0 && a0 < b0;      // (idle: in front of the stream, behind my stretch, or no stretch at all)
-                        const u32 pm = (e_lo_s + it) & 31u;             // = p mod 32, a scalar
-                        if (pm == 0u || it == 0) {
-                            const bool in = p >= 0 && (u32)p < (u32)(RW + 4) * 32u;
-                            const u32* dw = S.dense + 2 * (DPAD + (in ? (u32)p >> 5 : 0u));
-                            P1 = in ? dw[1] : 0u; P0 = in ? dw[0] ^ P1 : 0u;      // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
-                            ST = in ? S.dstart[(u32)p >> 5] : 0u;
-                        }
-                        const u32 sh = 31u - pm;
-                        if (live && ((ST >> sh) & 1u)) { lp = 0; cnt = 0; xs0 = xs1 = 0; conv = true; }      // a read starts here: exact state
-                        if (it == look && a0 < b0 && !conv) mine = true;         // (uniform iteration; the wave agrees on the restart at the end of the block)
-                        const u32 c = ((P1 >> sh) & 1u) << 1 | ((P0 >> sh) & 1u);
-                        lp += live ? 1u : 0u; warm += live ? 1u : 0u;
-                        bool cand = false;
-                        if (sm == 0) { cand = live && lp >= l; conv = conv || warm > l; }      // no tracked minimum: l genuine bases are all the state there is
-                        else {
-                            xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;      // (idle iterations only precede or follow the live ones: what they shift in is shifted out again before an s-mer counts)
-                            const bool push = live && lp >= sm;
-                            const u32 key = xs0 < xs1 ? xs0 : xs1;
-                            const u32 hs = use_lut ? (u32)lut[key & 255u] : sync_hash32(key, smask);
-                            cnt += push ? 1u : 0u;
-                            // the window holds hash << 5; OR-ing the age in makes ONE unsigned minimum find the smallest hash and, among
-                            // equal ones, the youngest (= rightmost) occurrence (s <= 13: 26 hash bits + 5 age bits)
-                            win[u] = hs << 5;                          // (slots written by idle iterations are never inside a full window: cnt counts consecutive pushes)
-                            u32 best = hs << 5;
-#pragma unroll
-                            for (int j = 1; j < WMAX; ++j) { const u32 kj = win[(u - j + WMAX) % WMAX] | (u32)j; best = kj < best ? kj : best; }
-                            const u32 mv = best >> 5, rm = best & 31u;
-                            const bool valid = push && cnt >= w, first = push && cnt == w;
-                            u32 lm = rm; bool uniq = false;
-                            if (!conv || first) {                      // rare: warm-up, or the first full window of a read
-#pragma unroll
-                                for (int j = 1; j < WMAX; ++j) { const u32 v = win[(u - j + WMAX) % WMAX] >> 5; lm = v == mv ? (u32)j : lm; }
-                                uniq = lm == rm;
-                            }
-                            const u32 older = ta + 1;
-                            const u32 ta_new = first ? lm : ((uniq || older >= w) ? rm : (hs < mvp ? 0u : older));
-                            ta = push ? ta_new : ta; mvp = push ? mv : mvp;
-                            conv = conv || (valid && uniq && warm > l);     // every s-mer of the window comes from bases behind my start: a unique minimum pins the state
-                            cand = valid && ta == w - t;
-                        }
-                        // candidate plane coordinate x = p + BS_B - 1; the bits of one word are collected and written once
-                        const u32 x = (u32)p + BS_B - 1;
-                        const u32 xm = (pm + BS_B - 1) & 31u;
-                        if (cand && live && !mine && (u32)p >= a0) cbits |= 0x80000000u >> xm;
-                        if (xm == 31u || it + 1 == n_it) { if (cbits) atomicOr(&S.c.cand[x >> 5], cbits); cbits = 0; }
-                    }
-                    restart = __any((int)mine) != 0;                   // leave together (the wave's control flow stays uniform)
+                for (int j = 0; j < 3; ++j) {
+                    const int32_t D = wi + j;
+                    const bool in = D >= -DPAD && D < RW + 4;
+                    const u32* dw = S.dense + 2 * (DPAD + (in ? D : 0));
+                    pl1[j] = in ? dw[1] : 0u; pl0[j] = in ? dw[0] ^ pl1[j] : 0u;      // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
+                    stw[j] = D >= 0 && D < RW + 4 ? S.dstart[D] : 0u;
                 }
-                if (!restart) break;
-                // somebody reached its stretch unconverged: everybody looks further back (rare); nothing further back in the staged stream: the
-                // tile takes the generic machine
-                if (mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 2048u)) S.misc[9] = 1;
-                if (__any((int)(mine && ((int32_t)a0 - (int32_t)look <= 0 || look >= 2048u)))) break;
+                u64 W1 = word64(pl1[0], pl1[1], pl1[2], rr), W0 = word64(pl0[0], pl0[1], pl0[2], rr), WS = word64(stw[0], stw[1], stw[2], rr);
+                // lp: bases of the read up to here (saturating; a start in front of my view: "many"), exact: counted from a read start I saw
+                u32 lp = qb > 0 ? 64u : 0u; bool exact = false;
+                u32 vmask = 0, fmask = 0;                  // per window: a full l-mer of one read ends here; it is the read's first
+                if (sm == 0) {
+                    // no tracked minimum: l genuine bases are all the state there is (src/read.rs:319-333)
+                    for (u32 i = 0; i < l - 1 + SG; ++i) {
+                        const int32_t q = qb + (int32_t)i;
+                        const bool live = q >= 0 && (u32)q < H;
+                        if (live && ((WS >> (63u - i)) & 1ull)) lp = 0;
+                        lp += live ? 1u : 0u;
+                        if (i >= l - 1 && live && lp >= l) vmask |= 1u << (i - (l - 1));
+                    }
+                    if (rd >= 0) {
+                        u64 cb = 0;
+                        const u32 x0c = (u32)p0 + BS_B - 1;
+#pragma unroll
+                        for (int jj = 0; jj < SG; ++jj) if (((vmask >> jj) & 1u) && (u32)(p0 + jj) < Bwv) cb |= 0x8000000000000000ull >> ((x0c & 31u) + (u32)jj);
+                        if ((u32)(cb >> 32)) atomicOr(&S.c.cand[x0c >> 5], (u32)(cb >> 32));
+                        if ((u32)cb) atomicOr(&S.c.cand[(x0c >> 5) + 1], (u32)cb);
+                    }
+                    continue;
+                }
+                u32 xs0 = 0, xs1 = 0;
+                // warm-up: the s - 1 bases in front of the first s-mer I need
+                for (u32 i = 0; i + 1 < sm; ++i) {
+                    const int32_t q = qb + (int32_t)i;
+                    const bool live = q >= 0 && (u32)q < H;
+                    if (live && ((WS >> (63u - i)) & 1ull)) { lp = 0; exact = true; }
+                    lp += live ? 1u : 0u;
+                    const u32 c = (u32)((W1 >> (63u - i)) & 1ull) << 1 | (u32)((W0 >> (63u - i)) & 1ull);
+                    xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
+                }
+                W1 <<= (sm - 1); W0 <<= (sm - 1); WS <<= (sm - 1);          // position qh = p0 - (w - 1) in bit 63: static bit indices from here on
+                const int32_t qh = p0 - (int32_t)(w - 1);
+                u32 h6[NH];                               // hash << 6 of the s-mer ending at qh + ii
+#pragma unroll
+                for (int ii = 0; ii < NH; ++ii) {
+                    const int32_t q = qh + ii;
+                    const bool live = q >= 0 && (u32)q < H;
+                    if (live && ((WS >> (63 - ii)) & 1ull)) { lp = 0; exact = true; }
+                    lp += live ? 1u : 0u;
+                    const u32 c = (u32)((W1 >> (63 - ii)) & 1ull) << 1 | (u32)((W0 >> (63 - ii)) & 1ull);
+                    xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
+                    const u32 key = xs0 < xs1 ? xs0 : xs1;
+                    h6[ii] = (use_lut ? (u32)lut[key & 255u] : sync_hash32(key, smask)) << 6;      // (an s-mer that is not one — lp < s — is never inside a window that counts)
+                    if (ii >= WMAX - 1) {
+                        if (live && lp >= l) vmask |= 1u << (ii - (WMAX - 1));
+                        if (live && exact && lp == l) fmask |= 1u << (ii - (WMAX - 1));
+                    }
+                }
+                // every window's rightmost and leftmost minimum (as END positions) and whether they are the same one
+                int32_t Rp[SG], Lp[SG]; u32 umask = 0;
+#pragma unroll
+                for (int jj = 0; jj < SG; ++jj) {
+                    u32 br = h6[jj] | (u32)(63 - jj), bl = h6[jj] | (u32)jj;
+#pragma unroll
+                    for (int d = 1; d < WMAX; ++d) {
+                        const u32 er = h6[jj + d] | (u32)(63 - jj - d), el = h6[jj + d] | (u32)(jj + d);
+                        br = er < br ? er : br; bl = el < bl ? el : bl;
+                    }
+                    const u32 ri = 63u - (br & 63u), li = bl & 63u;
+                    Rp[jj] = qh + (int32_t)ri; Lp[jj] = qh + (int32_t)li;
+                    umask |= ri == li ? 1u << jj : 0u;
+                }
+                // the SG steps from a given state in front of my first window; rec: collect the candidates
+                auto run = [&](int32_t T, bool rec, u32& cbits, bool& unk) -> int32_t {
+#pragma unroll
+                    for (int jj = 0; jj < SG; ++jj) {
+                        const int32_t p = p0 + jj;
+                        const bool v = (vmask >> jj) & 1u, f = (fmask >> jj) & 1u, u = (umask >> jj) & 1u;
+                        const bool left = T != UNK && T < p - (int32_t)(WMAX - 1);
+                        T = !v ? UNK : f ? Lp[jj] : (u || left) ? Rp[jj] : T;
+                        if (rec && v && (u32)p < Bwv) { if (T == UNK) unk = true; else if ((u32)(p - T) == w - t) cbits |= 1u << jj; }
+                    }
+                    return T;
+                };
+                u32 cb_ = 0; bool unk_ = false;
+                int32_t Tout = run(UNK, false, cb_, unk_);
+                const bool indep = vmask != (1u << SG) - 1u || (vmask & (fmask | umask)) != 0u;      // my result does not depend on what comes in
+                int32_t Tin;
+                for (;;) {
+                    Tin = __shfl_up(Tout, 1, 64); if (lane == 0) Tin = carry;
+                    bool chg = false;
+                    if (!indep) { const int32_t tn = run(Tin, false, cb_, unk_); chg = tn != Tout; Tout = tn; }
+                    if (!__any((int)chg)) break;
+                }
+                carry = __builtin_amdgcn_readlane(Tout, 63);
+                if (rd >= 0) {
+                    u32 cbits = 0; bool unk = false;
+                    (void)run(Tin, true, cbits, unk);
+                    need_slow = need_slow || unk;
+                    if (cbits) {
+                        const u32 x0c = (u32)p0 + BS_B - 1;       // candidate plane coordinate of my first window
+                        u64 cb = 0;
+#pragma unroll
+                        for (int jj = 0; jj < SG; ++jj) if ((cbits >> jj) & 1u) cb |= 0x8000000000000000ull >> ((x0c & 31u) + (u32)jj);
+                        if ((u32)(cb >> 32)) atomicOr(&S.c.cand[x0c >> 5], (u32)(cb >> 32));
+                        if ((u32)cb) atomicOr(&S.c.cand[(x0c >> 5) + 1], (u32)cb);
+                    }
+                }
             }
+            if (need_slow) S.misc[9] = 1;
         }
         tile_sync<NW>();
         if (S.misc[9]) { tile_sync<NW>(); run_slow_tile(); return; }
