@@ -761,138 +761,268 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         // quarter of the tile's positions and walks it in rounds of 64 G positions, the carry from round to round in a scalar; one look-back round in
         // front of the quarter warms the carry up.  A window of an owned position whose state is still unknown then (no anchor in 512 positions: a
         // tandem repeat) sends the tile to the generic machine.
-        constexpr int SG = 8;                              // windows per lane and round
+#ifndef MDBG_SYNC_SG
+#define MDBG_SYNC_SG 16
+#endif
+        constexpr int SG = MDBG_SYNC_SG;                   // windows per lane and round (8 or 16: a lane's view is 64 positions: l - 1 + SG of them are used)
         constexpr int NH = WMAX + SG - 1;                  // s-mer hashes of a lane: END positions p0 - (w - 1) .. p0 + SG - 1
-        constexpr int32_t UNK = INT32_MIN;
-        // s <= 4: the s-mer hash comes from a table (second half of t3: 256 x u16, filled here)
+        // s <= 4: the s-mer hash comes from a table (second half of t3: 256 x u16, filled here) indexed by the s bits of plane 1 and the s bits of plane 0 ^ plane 1
+        // as they lie in the stream — the table's builder de-interleaves the index, forms the s-mer and its reverse complement and hashes the smaller: a hash costs two
+        // bit-field extracts, a shift-or and a 2-byte LDS read, no rolling registers
         const bool use_lut = sm != 0 && sm <= 4;
         u16* const lut = (u16*)S_t3 + 256;
-        if (use_lut) lut[tid] = (u16)sync_hash32((u32)tid & smask, smask);
+        u32* const lut32 = (u32*)S.c.list;                // 256 words on top of the candidate list, which is written behind this phase
+        static_assert(sizeof(S.c.list) >= 256 * 4 && offsetof(TileLds<NW>, c) % 4 == 0 && (sizeof(S.c.cand) + sizeof(S.c.cpre)) % 4 == 0, "the packed s-mer table fits the candidate list");
+        if (use_lut) {
+            const u32 ia = (u32)tid >> sm, ib = (u32)tid & ((1u << sm) - 1u);
+            u32 fw = 0, rc = 0;
+            for (u32 j = 0; j < sm; ++j) {                 // base j of the s-mer (0 = first): its code's two bits are bit (s - 1 - j) of either half of the index
+                const u32 c = ((ia >> (sm - 1 - j)) & 1u) << 1 | ((ib >> (sm - 1 - j)) & 1u);
+                fw |= c << (2 * (sm - 1 - j)); rc |= (3u - c) << (2 * j);
+            }
+            const u32 hv = sync_hash32(fw < rc ? fw : rc, smask);
+            lut[tid] = (u16)hv;
+            lut32[tid] = (hv << 6) * 0x10001u;             // both halves hash << 6 (at most 14 bits: s <= 4): the packed form of the common rounds below
+        }
         tile_sync<NW>();
         {
             const u32 n_own = H > e_lo ? H - e_lo : 0u;
             const u32 Qw = (((n_own + NW - 1) / NW) + (64u * SG - 1u)) & ~(64u * SG - 1u);      // owned positions per wave: whole rounds
             const u32 wv_s = (u32)__builtin_amdgcn_readfirstlane(wv);
             const u32 Awv = e_lo + wv_s * Qw, Bwv = Awv + Qw < H ? Awv + Qw : H;                   // the wave's owned positions [Awv, Bwv)
-            int32_t carry = UNK;
+            int32_t carry = 4096;                           // (UNKI below: nothing known in front of the look-back round)
             bool need_slow = false;
             auto word64 = [](u32 x, u32 y, u32 z, u32 r) -> u64 {      // 64 positions from bit r of word x on (MSB first)
                 const u32 hi = r ? (x << r) | (y >> (32u - r)) : x, lo = r ? (y << r) | (z >> (32u - r)) : y;
                 return (u64)hi << 32 | lo;
             };
+            const u32 fm = sm ? (1u << sm) - 1u : 0u;
+            // bit jj of bits: window p0 + jj is a candidate -> candidate plane (coordinate x = p + BS_B - 1, MSB first)
+            auto put_cands = [&](u32 bits, int32_t p0_) {
+                if (!bits) return;
+                const u32 x0c = (u32)p0_ + BS_B - 1;
+                const u64 cb = ((u64)__brev(bits) << 32) >> (x0c & 31u);
+                if ((u32)(cb >> 32)) atomicOr(&S.c.cand[x0c >> 5], (u32)(cb >> 32));
+                if ((u32)cb) atomicOr(&S.c.cand[(x0c >> 5) + 1], (u32)cb);
+            };
             if (Awv < H) for (int32_t rd = -1; (int64_t)Awv + (int64_t)rd * (64 * SG) < (int64_t)Bwv; ++rd) {
                 const int32_t p0 = (int32_t)Awv + rd * (64 * SG) + lane * SG;       // my windows end at p0 .. p0 + SG - 1
-                const int32_t qb = p0 - (int32_t)(l - 1);                            // the first base I look at
+                const int32_t qb = p0 - (int32_t)(l - 1);                            // the first base I look at = view index 0 (bit 63)
                 const int32_t wi = qb >> 5; const u32 rr = (u32)qb & 31u;           // (arithmetic shift: floor, also in front of the stream)
                 u32 pl1[3], pl0[3], stw[3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < 3; ++j) {              // (clamped indices, results masked: six loads in flight, no branches)
                     const int32_t D = wi + j;
-                    const bool in = D >= -DPAD && D < RW + 4;
-                    const u32* dw = S.dense + 2 * (DPAD + (in ? D : 0));
-                    pl1[j] = in ? dw[1] : 0u; pl0[j] = in ? dw[0] ^ pl1[j] : 0u;      // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
-                    stw[j] = D >= 0 && D < RW + 4 ? S.dstart[D] : 0u;
+                    const int32_t Dc = D < -DPAD ? -DPAD : D > RW + 3 ? RW + 3 : D, Ds = D < 0 ? 0 : D > RW + 3 ? RW + 3 : D;
+                    const uint2 dw = *(const uint2*)(S.dense + 2 * (DPAD + Dc));
+                    const u32 st = S.dstart[Ds];
+                    pl1[j] = D == Dc ? dw.y : 0u; pl0[j] = D == Dc ? dw.x ^ dw.y : 0u;      // the reference's codes (A 0, C 1, G 2, T 3) = (plane 1, plane 0 ^ plane 1)
+                    stw[j] = D == Ds ? st : 0u;
                 }
-                u64 W1 = word64(pl1[0], pl1[1], pl1[2], rr), W0 = word64(pl0[0], pl0[1], pl0[2], rr), WS = word64(stw[0], stw[1], stw[2], rr);
-                // lp: bases of the read up to here (saturating; a start in front of my view: "many"), exact: counted from a read start I saw
-                u32 lp = qb > 0 ? 64u : 0u; bool exact = false;
-                u32 vmask = 0, fmask = 0;                  // per window: a full l-mer of one read ends here; it is the read's first
+                const u64 W1 = word64(pl1[0], pl1[1], pl1[2], rr), W0 = word64(pl0[0], pl0[1], pl0[2], rr), WS = word64(stw[0], stw[1], stw[2], rr);
+                // which of my windows hold a full l-mer of one read (every base of it in the stream, no read start behind its first base), and which are a read's first:
+                // mask arithmetic on the view — the masks themselves are the same in every lane
+                const int32_t n_mine = (int32_t)Bwv - p0;   // my windows that are owned positions of this wave: the first n_mine
+                const u32 own = n_mine >= SG ? (1u << SG) - 1u : n_mine <= 0 ? 0u : (1u << n_mine) - 1u;
+                const int32_t i_hi = (int32_t)H - qb;      // view indices [max(0, -qb), i_hi) are positions of the stream
+                const u64 LIVE = (qb <= -64 ? 0ull : qb < 0 ? ~0ull >> (u32)(-qb) : ~0ull) & (i_hi >= 64 ? ~0ull : i_hi <= 0 ? 0ull : ~(~0ull >> (u32)i_hi));
+                // (AND over runs of l positions by doubling: view index j of andrun(V, n) = V[j] & ... & V[j + n - 1])
+                auto andrun = [](u64 V, u32 n) -> u64 {
+                    if (n == 0) return ~0ull;
+                    u32 pw = 1;
+                    for (; 2 * pw <= n; pw *= 2) V &= V << pw;
+                    return V & (V << (n - pw));
+                };
+                u32 vmask = (1u << SG) - 1u, fmask = 0;   // (nearly every round: no edge of the stream and no read start in any lane's view)
+                const bool rare = __any((int)(LIVE != ~0ull || WS != 0ull)) != 0;      // an edge of the stream or a read start in some lane's view
+                if (rare) {
+                    const u64 OKW = andrun(LIVE, l) & andrun(~(WS << 1), l - 1);       // every base in the stream, no read start behind the first one
+                    vmask = __brev((u32)(OKW >> 32)) & ((1u << SG) - 1u);              // bit jj: window jj (view index jj = bit 63 - jj)
+                    fmask = vmask & __brev((u32)(WS >> 32));
+                }
                 if (sm == 0) {
                     // no tracked minimum: l genuine bases are all the state there is (src/read.rs:319-333)
-                    for (u32 i = 0; i < l - 1 + SG; ++i) {
-                        const int32_t q = qb + (int32_t)i;
-                        const bool live = q >= 0 && (u32)q < H;
-                        if (live && ((WS >> (63u - i)) & 1ull)) lp = 0;
-                        lp += live ? 1u : 0u;
-                        if (i >= l - 1 && live && lp >= l) vmask |= 1u << (i - (l - 1));
-                    }
-                    if (rd >= 0) {
-                        u64 cb = 0;
-                        const u32 x0c = (u32)p0 + BS_B - 1;
+                    if (rd >= 0) put_cands(vmask & own, p0);
+                    continue;
+                }
+                if (use_lut && !rare) {
+                    // The common round (s <= 4; every window of every lane holds a full l-mer, no read starts): both minima at once.  hash << 6 | index fits 16 bits, so a
+                    // register holds the rightmost encoding (63 - index) in its high half and the leftmost one in its low half and v_pk_min_u16 serves both; the table
+                    // delivers the hash in both halves.  thr[jj]: the tracked s-mer is replaced at window jj when its index is smaller — jj itself (it has left), or
+                    // "any" at a window with a unique minimum.
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    auto pkmin = [](u32 x, u32 y) -> u32 { return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(us2, x), __builtin_bit_cast(us2, y))); };
+                    constexpr int32_t ANY = 1 << 20;
+                    const u64 Z1 = W1 >> (14u - sm), Z0 = W0 >> (14u - sm);      // the s-mer ending at index ii: its last bit at bit 50 - ii (a word index: 4 x the table index)
+                    u32 e[NH];
 #pragma unroll
-                        for (int jj = 0; jj < SG; ++jj) if (((vmask >> jj) & 1u) && (u32)(p0 + jj) < Bwv) cb |= 0x8000000000000000ull >> ((x0c & 31u) + (u32)jj);
-                        if ((u32)(cb >> 32)) atomicOr(&S.c.cand[x0c >> 5], (u32)(cb >> 32));
-                        if ((u32)cb) atomicOr(&S.c.cand[(x0c >> 5) + 1], (u32)cb);
+                    for (int ii = 0; ii < NH; ++ii) {
+                        const u32 ka = (u32)(Z1 >> (48 - ii)) & (fm << 2), kb = (u32)(Z0 >> (48 - ii)) & (fm << 2);
+                        e[ii] = *(const u32*)((const char*)lut32 + (ka << sm | kb)) | ((u32)(63 - ii) << 16 | (u32)ii);
+                    }
+                    u32 m[SG];
+                    if constexpr (WMAX > 2) {
+                        constexpr int B = WMAX - 1;       // blocks of w - 1 indices: a window is the tail of one block and the head of the next, down to its last index
+                        u32 sx[NH], px[NH];
+#pragma unroll
+                        for (int i = NH - 1; i >= 0; --i) sx[i] = (i % B == B - 1 || i == NH - 1) ? e[i] : pkmin(e[i], sx[(i + 1) % NH]);
+#pragma unroll
+                        for (int i = 0; i < NH; ++i) px[i] = i % B == 0 ? e[i] : pkmin(e[i], px[(i + NH - 1) % NH]);
+#pragma unroll
+                        for (int jj = 0; jj < SG; ++jj) m[jj] = pkmin(sx[jj], px[jj + B]);
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < SG; ++jj) { u32 x = e[jj]; for (int d = 1; d < WMAX; ++d) x = pkmin(x, e[jj + d]); m[jj] = x; }
+                    }
+                    int32_t val[SG], thr[SG]; bool indep = false;
+#pragma unroll
+                    for (int jj = 0; jj < SG; ++jj) {
+                        const u32 ri = 63u - ((m[jj] >> 16) & 63u), li = m[jj] & 63u;
+                        val[jj] = (int32_t)ri; thr[jj] = ri == li ? ANY : jj; indep = indep || ri == li;
+                    }
+                    int32_t T = 4096; u32 cbits = 0;      // (4096: unknown / nothing tracked, UNKI below)
+#pragma unroll
+                    for (int jj = 0; jj < SG; ++jj) { T = T < thr[jj] ? val[jj] : T; cbits |= T == jj + (int32_t)t - 1 ? 1u << jj : 0u; }
+                    int32_t Tout = T;
+                    auto shift_in = [&](int32_t to) -> int32_t { int32_t x = __shfl_up(to, 1, 64); if (lane == 0) x = carry; return x == 4096 ? 4096 : x - SG; };
+                    int32_t Tin = shift_in(Tout);
+                    if (__any((int)!indep)) {
+                        for (;;) {
+                            bool chg = false;
+                            if (!indep) { int32_t tt = Tin;
+#pragma unroll
+                                for (int jj = 0; jj < SG; ++jj) tt = tt < thr[jj] ? val[jj] : tt;
+                                chg = tt != Tout; Tout = tt; }
+                            if (!__any((int)chg)) break;
+                            Tin = shift_in(Tout);
+                        }
+                    }
+                    carry = __builtin_amdgcn_readlane(Tout, 63);
+                    if (rd >= 0) {
+                        // my windows in front of the first one with a unique minimum started from "unknown": once more from what came in, as far as any lane needs it
+                        bool alive = true; int32_t tt = Tin;
+                        need_slow = need_slow || (Tin == 4096 && thr[0] != ANY && (own & 1u));
+#pragma unroll
+                        for (int jj = 0; jj < SG; ++jj) {
+                            alive = alive && thr[jj] != ANY;
+                            if (!__any((int)alive)) break;
+                            tt = alive && tt < jj ? val[jj] : tt;
+                            cbits |= alive && tt == jj + (int32_t)t - 1 ? 1u << jj : 0u;
+                        }
+                        put_cands(cbits & own, p0);
                     }
                     continue;
                 }
-                u32 xs0 = 0, xs1 = 0;
-                // warm-up: the s - 1 bases in front of the first s-mer I need
-                for (u32 i = 0; i + 1 < sm; ++i) {
-                    const int32_t q = qb + (int32_t)i;
-                    const bool live = q >= 0 && (u32)q < H;
-                    if (live && ((WS >> (63u - i)) & 1ull)) { lp = 0; exact = true; }
-                    lp += live ? 1u : 0u;
-                    const u32 c = (u32)((W1 >> (63u - i)) & 1ull) << 1 | (u32)((W0 >> (63u - i)) & 1ull);
-                    xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
-                }
-                W1 <<= (sm - 1); W0 <<= (sm - 1); WS <<= (sm - 1);          // position qh = p0 - (w - 1) in bit 63: static bit indices from here on
-                const int32_t qh = p0 - (int32_t)(w - 1);
-                u32 h6[NH];                               // hash << 6 of the s-mer ending at qh + ii
+                u32 h6[NH];                               // hash << 6 of the s-mer ending at p0 - (w - 1) + ii (garbage where no s-mer is: never inside a window that counts)
+                if (use_lut) {
+                    const u64 Y1 = W1 >> (16u - sm), Y0 = W0 >> (16u - sm);      // the s-mer ending at qh + ii = view indices [ii, ii + s): its last bit now lies at bit 48 - ii
 #pragma unroll
-                for (int ii = 0; ii < NH; ++ii) {
-                    const int32_t q = qh + ii;
-                    const bool live = q >= 0 && (u32)q < H;
-                    if (live && ((WS >> (63 - ii)) & 1ull)) { lp = 0; exact = true; }
-                    lp += live ? 1u : 0u;
-                    const u32 c = (u32)((W1 >> (63 - ii)) & 1ull) << 1 | (u32)((W0 >> (63 - ii)) & 1ull);
-                    xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
-                    const u32 key = xs0 < xs1 ? xs0 : xs1;
-                    h6[ii] = (use_lut ? (u32)lut[key & 255u] : sync_hash32(key, smask)) << 6;      // (an s-mer that is not one — lp < s — is never inside a window that counts)
-                    if (ii >= WMAX - 1) {
-                        if (live && lp >= l) vmask |= 1u << (ii - (WMAX - 1));
-                        if (live && exact && lp == l) fmask |= 1u << (ii - (WMAX - 1));
+                    for (int ii = 0; ii < NH; ++ii) {
+                        const u32 ka = (u32)(Y1 >> (48 - ii)) & fm, kb = (u32)(Y0 >> (48 - ii)) & fm;
+                        h6[ii] = (u32)lut[ka << sm | kb] << 6;
+                    }
+                } else {
+                    u32 xs0 = 0, xs1 = 0;
+                    for (u32 i = 0; i + 1 < sm; ++i) {        // the s - 1 bases in front of the first s-mer I need
+                        const u32 c = (u32)((W1 >> (63u - i)) & 1ull) << 1 | (u32)((W0 >> (63u - i)) & 1ull);
+                        xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
+                    }
+                    const u64 V1 = W1 << (sm - 1), V0 = W0 << (sm - 1);      // position qh in bit 63: static bit indices from here on
+#pragma unroll
+                    for (int ii = 0; ii < NH; ++ii) {
+                        const u32 c = (u32)((V1 >> (63 - ii)) & 1ull) << 1 | (u32)((V0 >> (63 - ii)) & 1ull);
+                        xs0 = (xs0 << 2 | c) & smask; xs1 = xs1 >> 2 | (3u - c) << sshift;
+                        h6[ii] = sync_hash32(xs0 < xs1 ? xs0 : xs1, smask) << 6;
                     }
                 }
-                // every window's rightmost and leftmost minimum (as END positions) and whether they are the same one
-                int32_t Rp[SG], Lp[SG]; u32 umask = 0;
+                // every window's rightmost and leftmost minimum (as END positions) and whether they are the same one: one unsigned min each over hash << 6 | index
+                // (rightmost: 63 - index).  WMAX > SG: every window straddles the indices SG - 1 | SG — suffix minima up to SG - 1, prefix minima from SG, one min per window
+                // val[jj]: what the tracked s-mer becomes at window jj when it changes, as an index of my hashes (the s-mer ending at qh + index): the leftmost minimum at a
+                // read's first window, else the rightmost; K: the windows that FIX the state whatever came in (unique minimum, first window, no full l-mer: UNKI)
+                constexpr int32_t UNKI = 4096;            // "unknown / nothing tracked" in index coordinates (no index compares equal or smaller)
+                int32_t val[SG]; u32 K = ~vmask;
+                {
+                    u32 br[SG], bl[SG];
+                    if constexpr (WMAX > 2) {
+                        // blocks of w - 1 indices: a window (w indices) is the tail of one block and the head of the next, down to its last index: suffix minima inside
+                        // every block, prefix minima inside every block, one min per window and side — 4 mins per hash instead of 2 (w - 1) per window
+                        constexpr int B = WMAX - 1;
+                        u32 sr[NH], sl[NH], pr[NH], pl[NH];
 #pragma unroll
-                for (int jj = 0; jj < SG; ++jj) {
-                    u32 br = h6[jj] | (u32)(63 - jj), bl = h6[jj] | (u32)jj;
+                        for (int i = NH - 1; i >= 0; --i) {
+                            const u32 er = h6[i] | (u32)(63 - i), el = h6[i] | (u32)i;
+                            const bool edge = i % B == B - 1 || i == NH - 1;
+                            sr[i] = edge ? er : (er < sr[(i + 1) % NH] ? er : sr[(i + 1) % NH]); sl[i] = edge ? el : (el < sl[(i + 1) % NH] ? el : sl[(i + 1) % NH]);
+                        }
 #pragma unroll
-                    for (int d = 1; d < WMAX; ++d) {
-                        const u32 er = h6[jj + d] | (u32)(63 - jj - d), el = h6[jj + d] | (u32)(jj + d);
-                        br = er < br ? er : br; bl = el < bl ? el : bl;
+                        for (int i = 0; i < NH; ++i) {
+                            const u32 er = h6[i] | (u32)(63 - i), el = h6[i] | (u32)i;
+                            const bool edge = i % B == 0;
+                            pr[i] = edge ? er : (er < pr[(i + NH - 1) % NH] ? er : pr[(i + NH - 1) % NH]); pl[i] = edge ? el : (el < pl[(i + NH - 1) % NH] ? el : pl[(i + NH - 1) % NH]);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < SG; ++jj) {      // window jj = indices [jj, jj + B]
+                            const u32 a_ = sr[jj], b_ = pr[jj + B]; br[jj] = a_ < b_ ? a_ : b_;
+                            const u32 c_ = sl[jj], d_ = pl[jj + B]; bl[jj] = c_ < d_ ? c_ : d_;
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < SG; ++jj) {
+                            u32 x = h6[jj] | (u32)(63 - jj), y = h6[jj] | (u32)jj;
+#pragma unroll
+                            for (int d = 1; d < WMAX; ++d) { const u32 er = h6[jj + d] | (u32)(63 - jj - d), el = h6[jj + d] | (u32)(jj + d); x = er < x ? er : x; y = el < y ? el : y; }
+                            br[jj] = x; bl[jj] = y;
+                        }
                     }
-                    const u32 ri = 63u - (br & 63u), li = bl & 63u;
-                    Rp[jj] = qh + (int32_t)ri; Lp[jj] = qh + (int32_t)li;
-                    umask |= ri == li ? 1u << jj : 0u;
-                }
-                // the SG steps from a given state in front of my first window; rec: collect the candidates
-                auto run = [&](int32_t T, bool rec, u32& cbits, bool& unk) -> int32_t {
 #pragma unroll
                     for (int jj = 0; jj < SG; ++jj) {
-                        const int32_t p = p0 + jj;
-                        const bool v = (vmask >> jj) & 1u, f = (fmask >> jj) & 1u, u = (umask >> jj) & 1u;
-                        const bool left = T != UNK && T < p - (int32_t)(WMAX - 1);
-                        T = !v ? UNK : f ? Lp[jj] : (u || left) ? Rp[jj] : T;
-                        if (rec && v && (u32)p < Bwv) { if (T == UNK) unk = true; else if ((u32)(p - T) == w - t) cbits |= 1u << jj; }
+                        const u32 ri = 63u - (br[jj] & 63u), li = bl[jj] & 63u;
+                        const bool v = (vmask >> jj) & 1u, f = (fmask >> jj) & 1u;
+                        K |= (ri == li || f) ? 1u << jj : 0u;
+                        val[jj] = !v ? UNKI : (int32_t)(f ? li : ri);
                     }
-                    return T;
+                }
+                // the steps from the state T in front of window `from` on (T: index of the tracked s-mer among my hashes, UNKI: unknown): window jj holds the indices
+                // [jj, jj + w - 1] — the tracked one has left when T < jj —, and is a candidate when T is its index jj + t - 1.  cb / ub: bit jj = candidate / state unknown
+                auto step = [&](int jj, int32_t& T, u32& cb, u32& ub) {
+                    T = (((K >> jj) & 1u) || T < jj) ? val[jj] : T;
+                    cb |= T == jj + (int32_t)t - 1 ? 1u << jj : 0u; ub |= T == UNKI ? 1u << jj : 0u;
                 };
-                u32 cb_ = 0; bool unk_ = false;
-                int32_t Tout = run(UNK, false, cb_, unk_);
-                const bool indep = vmask != (1u << SG) - 1u || (vmask & (fmask | umask)) != 0u;      // my result does not depend on what comes in
-                int32_t Tin;
-                for (;;) {
-                    Tin = __shfl_up(Tout, 1, 64); if (lane == 0) Tin = carry;
-                    bool chg = false;
-                    if (!indep) { const int32_t tn = run(Tin, false, cb_, unk_); chg = tn != Tout; Tout = tn; }
-                    if (!__any((int)chg)) break;
+                int32_t T = UNKI; u32 cbits = 0, ubits = 0;
+#pragma unroll
+                for (int jj = 0; jj < SG; ++jj) step(jj, T, cbits, ubits);
+                int32_t Tout = T;                          // (exact unless none of my windows fixes the state)
+                const bool indep = (K & ((1u << SG) - 1u)) != 0u;
+                auto shift_in = [&](int32_t to) -> int32_t {      // the state behind the lane below me (the round before, for lane 0), in MY index coordinates
+                    int32_t x = __shfl_up(to, 1, 64); if (lane == 0) x = carry;
+                    return x == UNKI ? UNKI : x - SG;
+                };
+                int32_t Tin = shift_in(Tout);
+                if (__any((int)!indep)) {
+                    // a lane without a fixing window (rare: eight windows with tied minima) passes on what comes in: until nothing changes any more
+                    for (;;) {
+                        bool chg = false;
+                        if (!indep) { int32_t tt = Tin; u32 c2 = 0, u2 = 0;
+#pragma unroll
+                            for (int jj = 0; jj < SG; ++jj) step(jj, tt, c2, u2);
+                            chg = tt != Tout; Tout = tt; }
+                        if (!__any((int)chg)) break;
+                        Tin = shift_in(Tout);
+                    }
                 }
                 carry = __builtin_amdgcn_readlane(Tout, 63);
                 if (rd >= 0) {
-                    u32 cbits = 0; bool unk = false;
-                    (void)run(Tin, true, cbits, unk);
-                    need_slow = need_slow || unk;
-                    if (cbits) {
-                        const u32 x0c = (u32)p0 + BS_B - 1;       // candidate plane coordinate of my first window
-                        u64 cb = 0;
+                    // my windows in front of the first fixing one took their state from UNKI: once more with what came in, as far as any lane of the wave needs it
+                    const u32 k8 = K & ((1u << SG) - 1u);
+                    const u32 dep = k8 ? (k8 & (0u - k8)) - 1u : (1u << SG) - 1u;      // my windows in front of the first fixing one (all of them valid: a window without a full l-mer fixes)
+                    if (Tin != UNKI && dep) {
+                        int32_t tt = Tin; u32 c2 = 0, u2 = 0;
 #pragma unroll
-                        for (int jj = 0; jj < SG; ++jj) if ((cbits >> jj) & 1u) cb |= 0x8000000000000000ull >> ((x0c & 31u) + (u32)jj);
-                        if ((u32)(cb >> 32)) atomicOr(&S.c.cand[x0c >> 5], (u32)(cb >> 32));
-                        if ((u32)cb) atomicOr(&S.c.cand[(x0c >> 5) + 1], (u32)cb);
+                        for (int jj = 0; jj < SG; ++jj) { if (!__any((int)((dep >> jj) & 1u))) break; if ((dep >> jj) & 1u) step(jj, tt, c2, u2); }
+                        cbits |= c2 & dep; ubits = (ubits & ~dep) | (u2 & dep);
                     }
+                    need_slow = need_slow || (ubits & vmask & own) != 0u;
+                    put_cands(cbits & vmask & own, p0);
                 }
             }
             if (need_slow) S.misc[9] = 1;
@@ -903,7 +1033,7 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
     tile_sync<NW>();
     // the (unordered) candidate list: every thread expands the bitmap words 4 tid .. 4 tid + 3.  (Round 2 and the first version of this
     // round appended to the list inside the filter loop: one LDS fetch-add and a bit loop per step, 12 times per wave instead of once.)
-    {
+    auto expand_list = [&]() {
         const uint4 cw = *(const uint4*)(S.c.cand + WPT * tid);
         const u32 w5[5] = {cw.x, cw.y, cw.z, cw.w, tid == TT - 1 ? S.c.cand[RW] : 0u};       // the last thread also takes word RW
         const u32 c = bs_popc(cw.x) + bs_popc(cw.y) + bs_popc(cw.z) + bs_popc(cw.w) + bs_popc(w5[4]);
@@ -925,7 +1055,8 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
                 }
             }
         }
-    }
+    };
+    expand_list();
     tile_sync<NW>();
     MDBG_STAMP(3);
     if (MDBG_HOT(a.stop_phase == 3, false)) { if (tid == 0) a.n_valid[gt] = 0; return; }
@@ -1072,6 +1203,39 @@ __global__ __launch_bounds__(64 * NW * TPW, SCHEME ? 5 : 6) void sketch_bs_kerne
         // one pass and evaluated the survivors again to write them; a first version of this round ran the two-stage rounds of the fast
         // path over stretches of the bitmap: 0.43 Tbases/s at d = 0.1, most of it spent at ~100 barriers per tile.
         tile_sync<NW>();
+        if constexpr (SCHEME == 1) {
+            // Syncmers: one position in w is a candidate (2,700 of a tile's 24,500 at l = 12 s = 4), and the density bound then keeps a few per cent of them.  Written
+            // like the dense settings of the density scheme — every candidate a 16-byte slot of the slab, the rejected ones as holes — that was 43 KB per tile to HBM
+            // and back through the gather: the kernel's longest phase at a quarter of its instructions.  So the candidates are first thinned out where they lie: every
+            // thread takes its own words of the bitmap (no word is shared: plain stores), evaluates the exact hash of each candidate and drops the failures; what is left
+            // mostly fits the list and goes the way of the sparse settings (survivors only, at their ranks).
+            {
+                const uint4 cw = *(const uint4*)(S.c.cand + WPT * tid);
+                u32 w5[5] = {cw.x, cw.y, cw.z, cw.w, tid == TT - 1 ? S.c.cand[RW] : 0u};
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    u32 w = w5[i], keep = w;
+                    while (w) {
+                        const u32 b = (u32)__clz(w), bit = 0x80000000u >> b; w &= ~bit;
+                        if (exact((u32)(32 * (WPT * tid + i)) + b - (BS_B - 1)) > a.bound) keep &= ~bit;
+                    }
+                    w5[i] = keep;
+                }
+                *(uint4*)(S.c.cand + WPT * tid) = make_uint4(w5[0], w5[1], w5[2], w5[3]);
+                if (tid == TT - 1) S.c.cand[RW] = w5[4];
+                if (tid == 0) S.misc[17] = 0;
+            }
+            tile_sync<NW>();
+            expand_list();
+            tile_sync<NW>();
+            const u32 n2 = S.misc[17];
+            if (n2 <= QCAP) {
+                const u32 nv = n2 ? process_list(n2) : 0;
+                if (tid == 0) { put_count(a, gt, nv, true); if (a.dbg) { a.dbg[(size_t)gt * 16 + 9] = n_cand; a.dbg[(size_t)gt * 16 + 10] = nv; } }
+                return;
+            }
+            tile_sync<NW>();
+        }
         const u32 C = count_words();
         const u32 per = (C + TT - 1) / TT;
         const u32 r0 = (u32)tid * per < C ? (u32)tid * per : C, r1 = r0 + per < C ? r0 + per : C;
