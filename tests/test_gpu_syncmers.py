@@ -80,3 +80,29 @@ def test_gpu_syncmer_graph_vs_oracle():
         got = m.finalize()
     from test_gpu_parity import assert_nodes_equal
     assert_nodes_equal(got, exp)
+
+
+@pytest.mark.parametrize("l,s,d", [(5, 5, 1.0), (6, 5, 1.0), (9, 3, 0.5), (12, 4, 1.0), (20, 4, 0.3), (31, 1, 0.2), (31, 13, 1.0), (17, 9, 0.5), (12, 0, 0.3), (16, 8, 1.0)])
+@pytest.mark.parametrize("hpc", [False, True])
+def test_gpu_syncmer_scan_edges(l, s, d, hpc):
+    """the scan formulation of the window-minimum machine (round 6) where its carries travel: thousands of short reads (read starts in every lane's view, first windows, reads
+    shorter than l), tandem repeats of every period up to 9 and of lengths on either side of the look-back round (tied minima over hundreds of windows: the fix-up pass, the
+    fixed-point loop over a wave, the fallback to the byte-wise machine), one base repeated (homopolymer compression leaves a single base), window sizes 1, 2, 7 .. 31"""
+    import random
+    import rust_mdbg_amd as R
+    rnd = random.Random(1000 * l + s)
+    reads = rand_reads(31 * l + s, 1500, 0, 3 * l + 40)                     # short reads back to back
+    reads += rand_reads(7 * l + s, 60, 200, 700, hp=0.1)
+    for period in range(1, 10):
+        unit = bytes(rnd.choice(b"ACGT") for _ in range(period))
+        for ln in (40, 300, 1100, 2500, 9000):
+            reads.append(rand_reads(period * 100 + ln, 1, 50, 50)[0] + (unit * (ln // period + 1))[:ln] + rand_reads(period * 100 + ln + 1, 1, 80, 80)[0])
+    reads.append(b"ACGGT" * 5000 + rand_reads(3, 1, 40000, 40000)[0] + b"TTGCA" * 300 + b"AG" * 700)
+    rnd.shuffle(reads)
+    b, o = O.concat_reads(reads)
+    exp = O.sketch(b, o, l, d, hpc, syncmer_s=s)
+    assert exp["err"] == 0 and len(exp["hashes"]) > 100
+    with R.Mdbg(5, l, d, 2, reads_already_hpc=hpc, syncmer_s=s) as m:
+        got = m.sketch(b, o)
+    for f in ("off", "hashes", "pos"):
+        assert np.array_equal(got[f], exp[f]), f
