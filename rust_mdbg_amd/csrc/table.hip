@@ -669,51 +669,12 @@ __device__ inline bool listed_check(u64 j) { return (((u32)j * 0x9E3779B1u) >> 2
 // and a closing entry); the per-batch arguments then come from the table.  (At 8 ranks and two chunks per step a rank inserts from 16 listed batches:
 // 16 launches of ~0.4 M windows each.)
 struct ListedBatch { u64 start, m0, m1, first_ordinal; const u32* list; u32 slot0, n_reads; };
-__global__ __launch_bounds__(256) void insert_listed_windows_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
-                                                                    u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
-                                                                    u32* __restrict__ cap_err, const ListedBatch* __restrict__ multi, u32 n_multi) {
-    if (cap_err[1]) return;
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 k = T.ks.k;
-    bool ok = j < n;
-    u64 i = 0, rs = 0; u32 slot = 0;
-    u64 jl = j;
-    if (ok && multi) {
-        u32 lo = 0, hi = n_multi - 1;
-        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (multi[mid].start <= j) lo = mid; else hi = mid - 1; }
-        const ListedBatch b = multi[lo];
-        m0 = b.m0; m1 = b.m1; list = b.list; slot0 = b.slot0; n_reads = b.n_reads; first_ordinal = b.first_ordinal; jl = j - b.start;
-    }
-    if (ok) {
-        const uint2 e = ((const uint2*)list)[jl];
-        i = m0 + e.x; slot = slot0 + e.y; ok = e.y < n_reads && i + k <= m1;
-    }
-    if (ok) {                                      // a wrong list is caught by the count check
-        rs = roff[slot]; const u64 re = roff[slot + 1];
-        // (ownership is re-derived for one entry in 16: it costs the window's k values once more, and a sender that disagrees about the owner function
-        // — the one realistic fault: parameters or the measured table differing between ranks — is wrong for millions of entries, not for one)
-        ok = i >= rs && re - rs > k && i + k <= re && (!listed_check(j) || window_owner(mh + i, k, OwnerSpec{T.own_world, T.own_thr}) == T.own_rank);
-    }
-    wave_count_add(ok, T.own_inserted);
-    if (!ok) return;
-    const u64 win = i - rs;
-    if (win > WIN_MASK) { *cap_err = 1; return; }
-    const u64 ord = ((first_ordinal + (slot - slot0)) << WIN_BITS) | win;
-    const u64* w = mh + i;
-    const bool rev = window_reversed(w, k);
-    const u64 h = key_hash_window(w, k, rev);
-    bool claimed;
-    const u64 s = upsert_slot(T, h, ((u64)rev << 32) | (u64)(u32)i, [&](u64 word) { return same_key_window(T.ks, word, w, rev); }, claimed);
-    if (claimed) { mread[i] = slot; if (T.claim) T.claim[i] = 1; }      // (the batch's bytes of the claim map were zeroed in front of the launch: api.inc, insert_resident_impl)
-    if (claimed || s == ~0ull) return;
-    atomicAdd(&T.tab[s].count, 1u);
-    push_ordinal(T, s, ord);
-}
-// The per-entry insertion since round 6.  insert_listed_windows_kernel above waits on chains of dependent loads: four values per round trip of its hash loop (nine round
-// trips at k = 35), k more for the owner check that one lane in 16 makes (and every wave has such a lane): ~90 us per workgroup at full occupancy, 5.4 M windows/ms on a
-// rank of eight (profiles/r06_rank_w8.txt) against 11 M for the local kernel, whose values lie in LDS.  Here a window is read ONCE, sixteen values per round trip: hash
-// and smallest value together (so EVERY entry's owner is re-derived, not one in 16), and the walk is upsert_wave's: a bucket of the owner lists is sorted by window start
-// and a rank's windows come in runs, so neighbouring lanes hold neighbouring windows, confirm each other as links, and their loads fall into the same cache lines.
+// The per-entry kernel.  Its predecessor (rounds 3 - 5) waited on chains of dependent loads: four values per round trip of its hash loop (nine round trips at k = 35), k more
+// for the owner check that one lane in 16 made (and every wave has such a lane): ~90 us per workgroup at full occupancy, 5.4 M windows/ms on a rank of eight
+// (profiles/r06_rank_w8_ab.txt) against 10.8 M for the local kernel, whose values lie in LDS.  Here a window is read ONCE, sixteen values per round trip: hash and smallest
+// value together (so EVERY entry's owner is re-derived, not one in 16), the batch of a wave's entries is found once per wave, and the walk is upsert_wave's: a bucket of the
+// owner lists is sorted by window start and a rank's windows come in runs, so neighbouring lanes hold neighbouring windows, confirm each other as links, and their loads fall
+// into the same cache lines.  8.4 M windows/ms.
 __global__ __launch_bounds__(256) void insert_listed_entries_kernel(TableArgs T, const u64* __restrict__ mh, u32* __restrict__ mread, const u64* __restrict__ roff,
                                                                     u64 m0, u64 m1, const u32* __restrict__ list, u64 n, u32 slot0, u32 n_reads, u64 first_ordinal,
                                                                     u32* __restrict__ cap_err, const ListedBatch* __restrict__ multi, u32 n_multi) {
@@ -849,7 +810,6 @@ static void launch_listed_entries(const TableArgs& T, const u64* mh, u32* mread,
                                   u32* cap_err, const ListedBatch* multi, u32 n_multi, hipStream_t s) {
     hipLaunchKernelGGL(insert_listed_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err, multi, n_multi);
 }
-static bool listed_old_kernel() { static const bool v = getenv("MDBG_LISTED_OLD") && atoi(getenv("MDBG_LISTED_OLD")); return v; }      // A/B: the per-entry kernel of rounds 3 - 5
 void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, u64 m0, u64 m1, const u32* list, const u32* seg, u64 n, u32 slot0,
                           u32 n_reads, u64 first_ordinal, u32* cap_err, hipStream_t s) {
     if (!n) return;
@@ -861,9 +821,6 @@ void launch_insert_listed(const TableArgs& T, const u64* mh, u32* mread, const u
     const bool sparse = n < (u64)owner_list_spans(m1 - m0) * per_span_min;
     if (seg && lds <= 64 * 1024 && !sparse)
         hipLaunchKernelGGL(insert_listed_span_kernel, dim3(owner_list_spans(m1 - m0)), dim3(256), lds, s, T, mh, mread, roff, m0, m1, list, seg, n, slot0, n_reads, first_ordinal, cap_err);
-    else if (listed_old_kernel())
-        hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err,
-                           (const ListedBatch*)nullptr, 0u);
     else       // (also very long k: the span does not fit the default LDS window, every window reads its values from HBM)
         launch_listed_entries(T, mh, mread, roff, m0, m1, list, n, slot0, n_reads, first_ordinal, cap_err, nullptr, 0u, s);
 }
@@ -875,10 +832,7 @@ bool listed_is_sparse(const TableArgs& T, u64 m0, u64 m1, u64 n) {
 }
 void launch_insert_listed_multi(const TableArgs& T, const u64* mh, u32* mread, const u64* roff, const ListedBatch* d_batches, u32 n_batches, u64 total, u32* cap_err, hipStream_t s) {
     if (!total) return;
-    if (listed_old_kernel())
-        hipLaunchKernelGGL(insert_listed_windows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, T, mh, mread, roff, 0ull, 0ull, (const u32*)nullptr, total, 0u, 0u, 0ull, cap_err,
-                           d_batches, n_batches);
-    else launch_listed_entries(T, mh, mread, roff, 0ull, 0ull, nullptr, total, 0u, 0u, 0ull, cap_err, d_batches, n_batches, s);
+    launch_listed_entries(T, mh, mread, roff, 0ull, 0ull, nullptr, total, 0u, 0u, 0ull, cap_err, d_batches, n_batches, s);
 }
 
 // Device-side twin of table_reserve(): flags the batch when the table is too small for it, so that the host can launch

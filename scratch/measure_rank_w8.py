@@ -68,8 +68,8 @@ out = (C.c_double * 4)()
 cc = (C.c_uint64 * W)(*cnt)
 m.L.mdbg_dbg_segments_ms.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_double)]
 rc = m.L.mdbg_dbg_segments_ms(m.h, W, 0, cc, d_lists, out)
-print("segments [MDBG_SEG_OLD=%s]: rc %d, %d list entries (own bucket of %d ships nothing), %d hashes packed (%.2f per shipped window, %.1f %% of the sketch): sender %.3f ms (counts, prefix, "
-      "one host round trip, pack), receiver %.3f ms (counts, prefix, scatter)" % (os.environ.get("MDBG_SEG_OLD", "-"), rc, int(out[2]), cnt[0], int(out[3]), out[3] / max(1, out[2] - cnt[0]),
+print("segments: rc %d, %d list entries (own bucket of %d ships nothing), %d hashes packed (%.2f per shipped window, %.1f %% of the sketch): sender %.3f ms (counts, prefix, "
+      "one host round trip, pack), receiver %.3f ms (counts, prefix, scatter)" % (rc, int(out[2]), cnt[0], int(out[3]), out[3] / max(1, out[2] - cnt[0]),
                                                                                  100.0 * out[3] / st["n_minimizers"], out[0], out[1]), flush=True)
 
 # ---- the receiver side: rank 0 inserts its windows of the seven peers' sketches --------------------------------------------------------------------------------
@@ -123,7 +123,7 @@ def receive():
 for rep in range(3):               # (the first pass grows the table; the later ones find it large enough, as every step after a job's first does)
     n_listed, t_ins, t_fb, t_fe, nw, n_nodes = receive()
     st = m.stats()
-    print("receiver pass %d [MDBG_LISTED_SPAN_MIN=%s MDBG_LISTED_WAVE=%s]: own windows + %d listed windows of %d peers inserted in %.3f ms (library timer ms_insert %.3f); finalize over the whole "
+    print("receiver pass %d [MDBG_LISTED_SPAN_MIN=%s]: own windows + %d listed windows of %d peers inserted in %.3f ms (library timer ms_insert %.3f); finalize over the whole "
           "index space (%d bitmap words): begin %.3f ms, end %.3f ms (no all-reduce, no position fetch), nodes of this rank %d, distinct keys %d" % (
-              rep, os.environ.get("MDBG_LISTED_SPAN_MIN", "-"), os.environ.get("MDBG_LISTED_WAVE", "-"), n_listed, W - 1, t_ins * 1e3, st["ms_insert"], nw, t_fb * 1e3, t_fe * 1e3, n_nodes,
+              rep, os.environ.get("MDBG_LISTED_SPAN_MIN", "-"), n_listed, W - 1, t_ins * 1e3, st["ms_insert"], nw, t_fb * 1e3, t_fe * 1e3, n_nodes,
               st["n_distinct"]), flush=True)
