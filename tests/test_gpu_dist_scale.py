@@ -106,6 +106,27 @@ def test_four_ranks_at_bench_parameters_equal_one_context(whole):
     assert max(sizes) < 1.05 * (sum(sizes) / W), sizes
 
 
+def test_eight_ranks_thin_lists_equal_one_context():
+    """eight ranks at the human parameters (k = 35 l = 14 d = 0.003): a rank's share of a peer's sketch is ~130 windows per span of 2,048 — the per-entry insertion
+    (insert_listed_entries_kernel, several batches per launch), segment passes over many 4,096-entry blocks with bucket boundaries inside them, and the claim map gathered
+    across eight batches' boundaries (claims_to_bits_kernel) — against ONE context that sees the same reads under the same ordinals"""
+    import rust_mdbg_amd as R
+    W, k, l, d, n_reads = 8, 35, 14, 0.003, 30000
+    genome = 12_000_000 * W
+
+    def feed(rank, gen):
+        db, do, nb = gen.synth_reads_device(seed=11, genome_len=genome, n_reads=n_reads, first_read=rank * n_reads)
+        return db, do, n_reads, nb, rank * n_reads
+    parts = _run_ranks(W, k, l, d, 2, feed, chunks=2, whole=False)
+    with R.Mdbg(k, l, d, 2, device=0) as one, R.Mdbg(k, l, d, 2, device=0) as gen:
+        for r in range(W):
+            db, do, nb = gen.synth_reads_device(seed=11, genome_len=genome, n_reads=n_reads, first_read=r * n_reads)
+            one.ingest_device(db, do, n_reads, nb, r * n_reads)
+        ref = one.finalize()
+    assert ref["n_nodes"] > 50000
+    _assert_partitions_equal(parts, ref)
+
+
 @pytest.mark.parametrize("whole,chunks", [(False, 1), (False, 3), (True, 1)])
 def test_wrapped_abundances_across_ranks(whole, chunks):
     """every k-min-mer of a repeated unit occurs ~84,000 times, spread over the reads of both ranks: the reference's u16 abundance wraps and its entry describes
