@@ -754,10 +754,26 @@ def main():
                 rh["what"] = ("the tile kernel of the timed region on the same packed reads with reads_already_hpc = 1 (no homopolymer compression: phase 2 is skipped, the "
                               "dense stream is the raw text); what the compaction costs, as a measurement")
             return rh
-        roof_hpc = None
+        def syncmer_leg():
+            # SURVEY.md 8 row f4 (--syncmers -s, src/read.rs:215-352; the reference's default s = 4, src/main.rs:438): the same packed reads sketched under the syncmer scheme,
+            # l = 12 s = 4 d = 0.05 — the tile kernel's syncmer instantiation (phase 3: the window-minimum machine as a scan), HIP events around its launches
+            with R.Mdbg(args.k, 12, 0.05, args.minabund, syncmer_s=4, device=device_index) as ms_:
+                b_in, b_off, b_reads, b_bases, b_first = batches[0]
+                for _ in range(3):
+                    ms_.reset(0)
+                    ms_.ingest_packed_device(b_in, b_off, b_reads, b_bases, b_first, sketch_only=True)
+                sts = ms_.stats()
+            if not sts["n_sketch_tile_launches"]:
+                return None
+            ms_k = sts["ms_sketch_tile"] / sts["n_sketch_tile_launches"]
+            return {"l": 12, "s": 4, "density": 0.05, "kernel_ms": ms_k, "kernel_gbases_per_s": sts["n_sketch_tile_bases"] / sts["n_sketch_tile_launches"] / (ms_k * 1e-3) / 1e9,
+                    "sketch_ms": sts["ms_sketch"], "minimizers_per_base": sts["n_minimizers"] / max(1, sts["n_bases"]),
+                    "what": "the batch of the timed region sketched under --syncmers (l = 12, s = 4, d = 0.05): tile kernel alone, and the whole sketch stage (kernel + scan + gather)"}
+        roof_hpc = sync_leg = None
         if packed and not routed and not human and not args.plain:
             roof_ascii, ascii_in = side("ascii_in", ascii_leg, (None, None))
             roof_hpc = side("roofline_hpc_input", hpc_leg)
+            sync_leg = side("syncmers", syncmer_leg)
             local_step()      # the table the edge stage and the baseline below refer to (not a side measurement: the counts below come from it)
 
         def edge_leg():
@@ -842,7 +858,7 @@ def main():
                           "bases_per_gpu": n_bases, "batches_per_step": len(batches), "total_bases": total_bases, "input_format": args.input, "plain": bool(args.plain),
                           "input": "2-bit packed (two 32-bit planes per 32 bases) resident in HBM" if packed else "ASCII resident in HBM", "parallelism": par,
                           "comm": None if not routed else ("host-staged over gloo: DRY RUN, not RCCL" if host_comm else "rccl")},
-               "roofline": roof, "roofline_ascii": roof_ascii, "roofline_hpc_input": roof_hpc, "ascii_in": ascii_in,
+               "roofline": roof, "roofline_ascii": roof_ascii, "roofline_hpc_input": roof_hpc, "syncmers": sync_leg, "ascii_in": ascii_in,
                "value_ascii_in": ascii_in["value"] if ascii_in else None, "ms_per_step_ascii_in": ascii_in["ms_per_step"] if ascii_in else None, "pack_ms": pack_ms,
                "cpu_baseline": cpu, "multik_graph_gbases_per_s": multik_graph_rate, "multik_graphs_per_s": (len(MULTIK) * args.steps / dt) if args.multik else None,
                "stage_ms_last_step": {"sketch": st["ms_sketch"], "sketch_bs_kernel": st["ms_sketch_tile"], "insert": st["ms_insert"], "finalize": st["ms_finalize"],

@@ -46,6 +46,8 @@ def test_bench_default_line_carries_the_ascii_leg():
     h = j["roofline_hpc_input"]          # round 6: the same launch with reads_already_hpc = 1 (README.md:134: the condition of the published timings)
     assert h["avg_launch_ms"] > 0 and h["minimizers_per_base"] > j["graph"]["minimizers"] / j["config"]["bases_per_gpu"] and 0 < h["frac"] < 1
     assert "valu_util" not in j["roofline"]
+    sy = j["syncmers"]                   # row f4: the same reads under --syncmers -s 4 (the tile kernel's syncmer instantiation)
+    assert sy["l"] == 12 and sy["s"] == 4 and sy["kernel_gbases_per_s"] > 0 and sy["sketch_ms"] >= sy["kernel_ms"] > 0 and 0.001 < sy["minimizers_per_base"] < 0.02
 
 
 @pytest.mark.gpu
@@ -106,11 +108,11 @@ def test_bench_one_rank_through_the_rccl_transport():
 def test_bench_prints_its_line_when_side_measurements_fail():
     """everything measured beside the headline (recorded profiles, the ASCII leg, the edge stage, the CPU leg, the anchors) may fail: the line is still
     printed, with the failure named under side_errors"""
-    every = "pmc_traffic,issue_roofline,sq_counters,ascii_in,roofline_hpc_input,edges_after_timed_region,cpu_baseline,n1_same_workload,no_exchange_anchor"
+    every = "pmc_traffic,issue_roofline,sq_counters,ascii_in,roofline_hpc_input,syncmers,edges_after_timed_region,cpu_baseline,n1_same_workload,no_exchange_anchor"
     j = _bench("--gpus", "1", "--genome-mb", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "5", "--no-scale-anchor", MDBG_BENCH_FAIL_SIDE=every)
     assert j["value"] > 0 and j["graph"]["nodes"] > 1000 and j["roofline"]["frac"] > 0
-    assert set(j["side_errors"]) == {"pmc_traffic", "issue_roofline", "sq_counters", "ascii_in", "roofline_hpc_input", "edges_after_timed_region", "cpu_baseline"}
-    assert j["roofline_hpc_input"] is None and j["ascii_in"] is None and j["edges_after_timed_region"] is None and j["cpu_baseline"] is None and j["roofline"]["traffic"] is None
+    assert set(j["side_errors"]) == {"pmc_traffic", "issue_roofline", "sq_counters", "ascii_in", "roofline_hpc_input", "syncmers", "edges_after_timed_region", "cpu_baseline"}
+    assert j["roofline_hpc_input"] is None and j["syncmers"] is None and j["ascii_in"] is None and j["edges_after_timed_region"] is None and j["cpu_baseline"] is None and j["roofline"]["traffic"] is None
     small = ["--workload", "human", "--genome-mb", "40", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0"]
     two = _bench("--gpus", "2", "--comm", "host", *small, MDBG_BENCH_FAIL_SIDE=every)
     assert two["n_gpus"] == 2 and two["value"] > 0 and two["graph"]["partitions_add_up"] is True
