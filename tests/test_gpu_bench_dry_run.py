@@ -117,3 +117,19 @@ def test_bench_prints_its_line_when_side_measurements_fail():
     two = _bench("--gpus", "2", "--comm", "host", *small, MDBG_BENCH_FAIL_SIDE=every)
     assert two["n_gpus"] == 2 and two["value"] > 0 and two["graph"]["partitions_add_up"] is True
     assert two["no_exchange_anchor"] is None and two["n1_same_workload"] is None and "n1_same_workload" in two["side_errors"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_dry_run_matches_one_rank():
+    """the N = 8 branch the driver's scaling run takes — eight OS processes, one shard each, thin window lists, two rounds per step — with the exchange staged through
+    host memory (eight ranks share this box's one GPU): the same node set as one rank, and the line carries the layer's stage timers beside the eight-rank budget"""
+    small = ["--workload", "human", "--genome-mb", "160", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0"]
+    one = _bench("--gpus", "1", *small)
+    eight = _bench("--gpus", "8", "--comm", "host", *small)
+    assert eight["n_gpus"] == 8 and eight["config"]["batches_per_step"] == 1 and eight["config"]["total_bases"] == one["config"]["total_bases"]
+    assert eight["graph"]["partitions_add_up"] is True and eight["graph"]["nodes"] == one["graph"]["nodes"] > 100000
+    assert one["graph"]["node_digest"] and eight["graph"]["node_digest"] == one["graph"]["node_digest"]
+    lay = eight["exchange"]["layer_ms_per_step"]
+    assert lay["rounds_per_step"] == 2.0 and set(lay["slowest_rank"]) == set(lay["mean"]) and lay["slowest_rank"]["sketch"] > 0 and lay["slowest_rank"]["insert"] > 0
+    assert all(lay["slowest_rank"][s_] >= lay["mean"][s_] - 1e-9 for s_ in lay["mean"])
+    assert eight["exchange"]["budget_ms_per_step_8_ranks_human"]["sum"][0] > 10 and eight["exchange"]["nodes_busiest_rank_over_mean"] < 1.1
