@@ -35,6 +35,7 @@
 #else
 #define GZ_X86 0
 #endif
+#include <functional>
 #include <zlib.h>                   // crc32_combine only
 
 // function clones are resolved through ifuncs, which run before ThreadSanitizer's runtime is up: none in such builds
@@ -620,14 +621,42 @@ struct GzIn {
         }
         return true;
     }
-    // BGZF: the next blocks (about CHUNK bytes of text per thread), every one inflated on its own into its place
+    // BGZF: groups of blocks, every block inflated on its own into its place by a standing crew of threads (round 6; until then every group of ~1 MB per thread spawned and
+    // joined its threads, and the group was inflated into the window and copied out of it by the one thread that reads ahead: 2.1 - 2.8 GB/s of text however many threads)
     std::vector<Inflater*> pool;
-    bool produce_bgzf() {
-        struct Blk { size_t data, end; u32 isize, crc; size_t out; };
-        std::vector<Blk> blks;
-        size_t total = 0, q = at;
-        const size_t budget = CHUNK * (size_t)threads;
-        while (q < n && total < budget) {
+    struct Blk { size_t data, end; u32 isize, crc; size_t out; };
+    struct Crew {
+        std::vector<std::thread> th; std::mutex m; std::condition_variable go, fin;
+        unsigned long long gen = 0; int active = 0, pending = 0; bool quit = false;
+        const std::function<void(int)>* job = nullptr;
+        void ensure(int n) {                                           // helpers 1 .. n - 1 (the caller is number 0)
+            while ((int)th.size() + 1 < n) {
+                const int id = (int)th.size() + 1;
+                th.emplace_back([this, id]() {
+                    unsigned long long seen = 0;
+                    for (;;) {
+                        const std::function<void(int)>* f = nullptr;
+                        { std::unique_lock<std::mutex> g(m); go.wait(g, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; if (id < active) f = job; }
+                        if (f) { (*f)(id); std::lock_guard<std::mutex> g(m); if (--pending == 0) fin.notify_all(); }
+                    }
+                });
+            }
+        }
+        void run(int n, const std::function<void(int)>& f) {
+            if (n <= 1) { f(0); return; }
+            ensure(n);
+            { std::lock_guard<std::mutex> g(m); job = &f; active = n; pending = n - 1; ++gen; }
+            go.notify_all();
+            f(0);
+            std::unique_lock<std::mutex> g(m); fin.wait(g, [&] { return pending == 0; });
+        }
+        void stop() { { std::lock_guard<std::mutex> g(m); quit = true; } go.notify_all(); for (auto& t : th) t.join(); th.clear(); quit = false; }
+        ~Crew() { stop(); }
+    } crew;
+    // the BGZF blocks from `at` on whose text fits `room` bytes (out: offsets from 0): q <- the position behind them
+    bool collect_bgzf(size_t room, std::vector<Blk>& blks, size_t& total, size_t& q) {
+        blks.clear(); total = 0; q = at;
+        while (q < n) {
             Member m;
             if (!parse_header(in, n, q, m)) break;
             if (!m.bgzf || q + m.bsize > n || m.bsize < (m.data - q) + 8) break;          // an ordinary member: the sequential path takes over from here
@@ -635,9 +664,34 @@ struct GzIn {
             const u32 c = in[e - 8] | (u32)in[e - 7] << 8 | (u32)in[e - 6] << 16 | (u32)in[e - 5] << 24;
             const u32 isz = in[e - 4] | (u32)in[e - 3] << 8 | (u32)in[e - 2] << 16 | (u32)in[e - 1] << 24;
             if (isz > 65536) return fail("BGZF block larger than 64 KiB");
+            if (total + isz > room) break;
             blks.push_back(Blk{m.data, e - 8, isz, c, total});
             total += isz; q = e;
         }
+        return true;
+    }
+    bool inflate_blocks(const std::vector<Blk>& blks, u8* base) {
+        const int T = (int)std::min<size_t>((size_t)threads, blks.size());
+        while ((int)pool.size() < T) pool.push_back(new Inflater());
+        std::vector<const char*> errs((size_t)std::max(T, 1), nullptr);
+        const std::function<void(int)> work = [&](int t) {
+            Inflater& f = *pool[(size_t)t];
+            for (size_t b = (size_t)t; b < blks.size(); b += (size_t)T) {
+                const Blk& k = blks[b];
+                f.start(in, k.end, k.data);                           // the block's own trailer is the end of its input
+                size_t op = k.out;
+                if (!f.run(base, k.out, op, k.out + k.isize)) { errs[(size_t)t] = f.err; return; }
+                if (f.st != Inflater::END || f.pend_len || op != k.out + k.isize) { errs[(size_t)t] = "BGZF block length mismatch"; return; }
+                if (crc32(0, base + k.out, k.isize) != k.crc) { errs[(size_t)t] = "gzip CRC mismatch"; return; }
+            }
+        };
+        crew.run(T, work);
+        for (const char* e : errs) if (e) return fail(e);
+        return true;
+    }
+    bool produce_bgzf() {
+        std::vector<Blk> blks; size_t total = 0, q = at;
+        if (!collect_bgzf(CHUNK * (size_t)threads, blks, total, q)) return false;
         if (blks.empty()) {                                            // not a BGZF block here (or the end): one member the ordinary way
             if (q >= n || !begin_member()) { if (!bad) done = true; return false; }
             is_bgzf = false;
@@ -645,32 +699,28 @@ struct GzIn {
         }
         rd = wr = 0; lo = 0;
         if (win.size() < total + 64) win.resize(total + 64);
-        const int T = (int)std::min<size_t>((size_t)threads, blks.size());
-        while ((int)pool.size() < T) pool.push_back(new Inflater());
-        std::vector<const char*> errs((size_t)T, nullptr);
-        auto work = [&](int t) {
-            Inflater& f = *pool[(size_t)t];
-            for (size_t b = (size_t)t; b < blks.size(); b += (size_t)T) {
-                const Blk& k = blks[b];
-                f.start(in, k.end, k.data);                           // the block's own trailer is the end of its input
-                size_t op = k.out;
-                if (!f.run(win.data(), k.out, op, k.out + k.isize)) { errs[(size_t)t] = f.err; return; }
-                if (f.st != Inflater::END || f.pend_len || op != k.out + k.isize) { errs[(size_t)t] = "BGZF block length mismatch"; return; }
-                if (crc32(0, win.data() + k.out, k.isize) != k.crc) { errs[(size_t)t] = "gzip CRC mismatch"; return; }
-            }
-        };
-        {
-            std::vector<std::thread> th;
-            for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-            work(0);
-            for (auto& x : th) x.join();
-        }
-        for (const char* e : errs) if (e) return fail(e);
+        if (!inflate_blocks(blks, win.data())) return false;
         at = q; wr = total;
         if (total == 0) return produce();                              // only empty blocks (the BGZF end marker)
         return true;
     }
-    void close_pool() { for (Inflater* f : pool) delete f; pool.clear(); }
+    // BGZF blocks STRAIGHT into a buffer of the caller's: as many whole blocks as fit [0, room) (room >= 64 KiB).  Returns the bytes written; 0 with `plain` set: the
+    // next member is an ordinary one (or the data ends: `done`), the caller goes on with read(); -1: error
+    long fill_bgzf(u8* dst, size_t room, bool& plain) {
+        plain = false;
+        if (rd != wr || in_member) { plain = true; return 0; }        // (bytes of an ordinary member are still waiting in the window)
+        size_t got = 0;
+        while (got + 65536 <= room) {
+            std::vector<Blk> blks; size_t total = 0, q = at;
+            if (!collect_bgzf(room - got, blks, total, q)) return -1;
+            if (blks.empty()) { if (at >= n) done = true; else plain = true; break; }
+            if (!inflate_blocks(blks, dst + got)) return -1;
+            at = q; got += total;
+            if (at >= n) { done = true; break; }
+        }
+        return (long)got;
+    }
+    void close_pool() { crew.stop(); for (Inflater* f : pool) delete f; pool.clear(); }
 
     int read(u8* dst, size_t want) {                                   // bytes delivered, 0 at the end, -1 on a malformed stream
         size_t got = 0;
@@ -710,9 +760,21 @@ struct GzAhead {
                 { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return stop || s.state == 0; }); if (stop) return; }
                 constexpr size_t H = GzIn::HIST;
                 if (!s.data) s.data.reset(new u8[H + PIECE]);                   // (not zero-filled: touched when written)
-                int r;
-                if (!direct) r = core.read(s.data.get() + H, PIECE);            // BGZF: groups of blocks inflated by several threads into the core's window
-                else {
+                int r; bool last_piece = false, have_last = false;
+                if (!direct) {
+                    // BGZF: whole blocks inflated by the crew straight into the slot; where an ordinary member interrupts them (or bytes of one are still in the
+                    // window) the rest of the piece comes through read()
+                    size_t filled = 0; bool plain = false;
+                    long g = core.fill_bgzf(s.data.get() + H, PIECE, plain);
+                    if (g < 0) r = -1;
+                    else {
+                        filled = (size_t)g;
+                        if (plain) { const int x = core.read(s.data.get() + H + filled, PIECE - filled); if (x < 0) filled = (size_t)-1; else { filled += (size_t)x; last_piece = filled < PIECE; have_last = true; } }
+                        else { last_piece = core.done; have_last = true; }
+                        r = filled == (size_t)-1 ? -1 : (int)filled;
+                    }
+                    if (core.bad) r = -1;
+                } else {
                     // an ordinary stream: decoded straight into the slot; the 32 KiB in front of the piece are the end of the piece before
                     if (n_filled) { const Slot& pv = slot[(size_t)((w + SLOTS - 1) % SLOTS)]; memcpy(s.data.get(), pv.data.get() + pv.n, H); }
                     size_t pos = H;
@@ -720,30 +782,54 @@ struct GzAhead {
                     r = core.bad ? -1 : (int)(pos - H);
                 }
                 ++n_filled;
-                { std::lock_guard<std::mutex> g(mu); s.n = r > 0 ? (size_t)r : 0; s.state = r < 0 ? 3 : (size_t)r < PIECE ? 2 : 1; }
+                const bool last = have_last ? last_piece : (size_t)std::max(r, 0) < PIECE;      // (an ordinary stream: a short piece is the last one)
+                { std::lock_guard<std::mutex> g(mu); s.n = r > 0 ? (size_t)r : 0; s.state = r < 0 ? 3 : last ? 2 : 1; }
                 cv.notify_all();
-                if (r < 0 || (size_t)r < PIECE) return;
+                if (r < 0 || last) return;
             }
         });
     }
-    int read(u8* dst, size_t want) {
+    // the unread bytes of the piece the consumer stands in (waits for the piece): n = 0 at the end of the data; false: the stream is damaged.  consume(k <= n) moves on.
+    // (A caller with threads of its own copies a piece out with all of them: read() below is one memcpy on one thread, ~10 GB/s, between rounds of parallel work.)
+    bool peek(const u8*& p, size_t& n) {
         if (!started) start();
-        size_t got = 0;
-        while (got < want && !finished && !failed) {
+        for (;;) {
+            p = nullptr; n = 0;
+            if (failed) return false;
+            if (finished) return true;
             Slot& s = slot[(size_t)cur];
             int st;
             { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return s.state != 0; }); st = s.state; }
-            if (st == 3) { failed = true; break; }
-            const size_t take = std::min(want - got, s.n - cur_rd);
-            memcpy(dst + got, s.data.get() + GzIn::HIST + cur_rd, take); cur_rd += take; got += take;
-            if (cur_rd == s.n) {
-                if (st == 2) { finished = true; break; }
-                { std::lock_guard<std::mutex> g(mu); s.state = 0; }
-                cv.notify_all();
-                cur = (cur + 1) % SLOTS; cur_rd = 0;
-            }
+            if (st == 3) { failed = true; return false; }
+            if (cur_rd < s.n) { p = s.data.get() + GzIn::HIST + cur_rd; n = s.n - cur_rd; return true; }
+            if (st == 2) { finished = true; return true; }
+            { std::lock_guard<std::mutex> g(mu); s.state = 0; }      // an empty piece that is not the last: on to the next
+            cv.notify_all();
+            cur = (cur + 1) % SLOTS; cur_rd = 0;
         }
-        return failed ? -1 : (int)got;
+    }
+    void consume(size_t k) {
+        Slot& s = slot[(size_t)cur];
+        cur_rd += k;
+        if (cur_rd >= s.n) {
+            int st; { std::lock_guard<std::mutex> g(mu); st = s.state; }
+            if (st == 2) { finished = true; return; }
+            { std::lock_guard<std::mutex> g(mu); s.state = 0; }
+            cv.notify_all();
+            cur = (cur + 1) % SLOTS; cur_rd = 0;
+        }
+    }
+    int read(u8* dst, size_t want) {
+        size_t got = 0;
+        while (got < want) {
+            const u8* p; size_t n;
+            if (!peek(p, n)) return -1;
+            if (!n) break;
+            const size_t take = std::min(want - got, n);
+            memcpy(dst + got, p, take); got += take;
+            consume(take);
+        }
+        return (int)got;
     }
 };
 }  // namespace gz

@@ -863,9 +863,21 @@ static int reader_next_window(mdbg_reader* r, uint64_t max_bases, bool ascii_out
             free(r->gw); r->gw = nb; r->gw_cap = want + want / 8 + 64;
         }
         while (!r->gw_eof && r->gw_len < want) {
-            const int n = r->gzin->read(r->gw + r->gw_len, std::min<size_t>(want - r->gw_len, 1u << 30));
-            if (n < 0) { r->io_error = true; return MDBG_E_IO; }
-            if (n == 0) r->gw_eof = true; else r->gw_len += (size_t)n;
+            // a piece of inflated text -> the window, copied by all the reader's threads (one memcpy on this thread was the serial stretch between the parallel
+            // inflate of BGZF blocks and the parallel parse: 2.3 GB/s of text with 32 threads)
+            const u8* p; size_t n;
+            if (!r->gzin->peek(p, n)) { r->io_error = true; return MDBG_E_IO; }
+            if (n == 0) { r->gw_eof = true; break; }
+            const size_t take = std::min(n, want - r->gw_len);
+            const int T = std::max(1, r->threads);
+            if (T > 1 && take >= (4u << 20)) {
+                if (!r->pool || r->pool->n != T) { delete r->pool; r->pool = new WorkerPool(T); }
+                u8* const d = r->gw + r->gw_len;
+                const size_t per = ((take + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+                const std::function<void(int)> cp = [&](int i) { const size_t a = (size_t)i * per; if (a < take) memcpy(d + a, p + a, std::min(per, take - a)); };
+                if (!r->pool->run(cp)) return MDBG_E_NOMEM;
+            } else memcpy(r->gw + r->gw_len, p, take);
+            r->gzin->consume(take); r->gw_len += take;
         }
         if (r->gw_len == 0) { r->offs.assign(1, 0); return MDBG_OK; }
         E = r->gw_eof ? r->gw_len : complete_prefix(r->gw, r->gw_len, r->fasta);
