@@ -313,6 +313,15 @@ def scale_anchor_n1(R, torch, np, device_index, minabund, oracle_shard=False):
     default N=1 line configs[2] — so the human data set goes through this one GPU once more here, after the timed region (about 3 s), and the curve's anchor sits in
     the same driver record as the headline."""
     k, l, d, gm, cov = 35, 14, 0.003, 3000.0, 52.0
+    # The blocks the library and torch keep for reuse go back to the runtime first, so that the anchor's 13-GB table and 6-GB store are fresh allocations as in a run of
+    # their own.  (The pass varies by +-1.3 % from process to process on one box — five fresh processes: 84.1 / 85.0 / 86.0 / 86.1 / 86.3 ms, scratch/anchor_alone.py —,
+    # which is more than what the legs in front of it cost, if anything: where the table lands is drawn anew with every allocation.)
+    try:
+        from rust_mdbg_amd import api as _api
+        _api.release_cached_memory()
+        torch.cuda.empty_cache()
+    except Exception:
+        pass
     with R.Mdbg(k, l, d, minabund, device=device_index) as mh:
         batches, keep, shard_reads, last_ascii = human_shards(mh, torch, np, gm, cov, range(HUMAN_SHARDS))
 
