@@ -77,3 +77,24 @@ def test_nodes_digest_of_the_device_table_equals_the_oracles():
             assert int(nd.n) == exp["n_nodes"] > 100 and m.nodes_digest(nd) == want
             m.reset(0)
             assert m.nodes_digest(m.finalize_device()) == (0, 0)
+
+
+@pytest.mark.gpu
+def test_segment_and_stage_timer_hooks_answer():
+    """the two measurement entry points of round 6 (include/mdbg_hip.h: mdbg_dbg_segments_ms; include/mdbg_dist.h: mdbg_dist_stage_ms) on a small batch: the counts they
+    report are the owner lists' own, every shipped window adds between 1 and k hashes, and the timers are finite"""
+    import ctypes as C
+    R = _mdbg()
+    W, k, l, d = 4, 21, 12, 0.01
+    with R.Mdbg(k, l, d, 2) as m:
+        m.set_partition(W, 1)
+        db, do, nb = m.synth_reads_device(seed=4, genome_len=2_000_000, n_reads=3000)
+        m.sketch_device(db, do, 3000, nb, 0)
+        cnt, d_lists = m.owner_lists(W)
+        assert sum(cnt) > 10000 and min(cnt) > 0
+        out = (C.c_double * 4)()
+        m.L.mdbg_dbg_segments_ms.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_double)]
+        assert m.L.mdbg_dbg_segments_ms(m.h, W, 1, (C.c_uint64 * W)(*cnt), d_lists, out) == 0
+        shipped = sum(cnt) - cnt[1]
+        assert int(out[2]) == sum(cnt) and shipped <= int(out[3]) <= shipped * k and 0 < out[0] < 1000 and 0 < out[1] < 1000
+        assert m.L.mdbg_dbg_segments_ms(m.h, 65, 0, (C.c_uint64 * W)(*cnt), d_lists, out) != 0      # more than 64 ranks: refused
